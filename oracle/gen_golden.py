@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""
+Generate tests/golden/*.npz by running THE REFERENCE'S OWN, UNMODIFIED code
+(/root/reference/precise/{network_runner,vectorization,params,util,threshold_decoder}.py)
+in the build container.  TEST INFRASTRUCTURE ONLY -- runs here, never on the GPU box
+(/root/reference does not exist there); the committed .npz files are what travels.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+The reference's two third-party arithmetic dependencies are absent, so they are supplied
+through the reference's own seams:
+  * ``sonopy``  -> sys.modules['sonopy'] = oracle.sonopy_restated   (vectorization.py:24)
+  * the network -> ``Listener(..., runner_cls=<numpy Keras-GRU restatement>)``
+                                                                  (network_runner.py:101,106)
+Everything else that executes -- Listener framing/leftover/ring logic, buffer_to_audio,
+vectorize/add_deltas, ListenerParams, ThresholdDecoder -- is reference code.
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True          # never write __pycache__ into /root/reference
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, '/root/reference')
+
+import warnings
+import numpy as np
+
+from oracle import sonopy_restated, keras_gru
+from mycroft_precise_amd import synth
+
+sys.modules['sonopy'] = sonopy_restated
+warnings.simplefilter('ignore', DeprecationWarning)        # np.fromstring in util.py:37
+
+from precise.network_runner import Listener                # noqa: E402  (reference code)
+from precise.threshold_decoder import ThresholdDecoder     # noqa: E402
+from precise.vectorization import vectorize, vectorize_raw, add_deltas   # noqa: E402
+from precise.util import buffer_to_audio                   # noqa: E402
+from precise.params import pr                              # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+
+
+class RecordingRunner(keras_gru.NumpyRunner):
+    last_raw = None
+
+    def run(self, inp):
+        raw = super().run(inp)
+        type(self).last_raw = raw
+        return raw
+
+
+def run_listener(pcm: np.ndarray, chunk_bytes: int, weights):
+    """Feed ``pcm`` (int16 1-D) through the reference Listener in chunk_bytes pieces.
+    Returns raw outputs, decoded outputs, feature ring after every update, leftover length."""
+    cls = type('R', (RecordingRunner,), {'weights': weights})
+    listener = Listener('synthetic-model-not-on-disk', chunk_bytes, runner_cls=cls)
+    data = pcm.tobytes()
+    raws, decs, rings, left = [], [], [], []
+    for off in range(0, len(data) - chunk_bytes + 1, chunk_bytes):
+        dec = listener.update(data[off:off + chunk_bytes])
+        raws.append(cls.last_raw)
+        decs.append(dec)
+        rings.append(listener.mfccs.copy())
+        left.append(len(listener.window_audio))
+    return (np.array(raws, dtype=np.float32), np.array(decs, dtype=np.float64),
+            np.array(rings, dtype=np.float64), np.array(left, dtype=np.int64))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    weights = synth.make_weights()
+
+    # --- params.py derived sizes -------------------------------------------------------
+    np.savez(os.path.join(OUT, 'params_default.npz'),
+             window_samples=pr.window_samples, hop_samples=pr.hop_samples,
+             buffer_samples=pr.buffer_samples, n_features=pr.n_features,
+             max_samples=pr.max_samples, feature_size=pr.feature_size,
+             n_fft=pr.n_fft, n_filt=pr.n_filt, n_mfcc=pr.n_mfcc)
+
+    # --- util.buffer_to_audio ----------------------------------------------------------
+    edge = np.array([0, 1, -1, 32767, -32768, 12345, -12345, 256, -256], dtype='<i2')
+    np.savez(os.path.join(OUT, 'buffer_to_audio.npz'), pcm=edge,
+             audio=buffer_to_audio(edge.tobytes()))
+
+    # --- Listener.update streaming: 1024-sample chunks (runner.py:48 default) ------------
+    cases = [('tone_noise', 0), ('tone_noise', 5), ('tone_noise', 96), ('zeros', 0),
+             ('square', 12), ('square', 3), ('quiet', 1)]
+    n_updates = 40
+    pcm_all, raw_all, dec_all, ring_last, left_all, ring_u7 = [], [], [], [], [], []
+    for kind, s in cases:
+        pcm = synth.stream_pcm(s, n_updates * 1024, kind)
+        raws, decs, rings, left = run_listener(pcm, 2048, weights)
+        pcm_all.append(pcm); raw_all.append(raws); dec_all.append(decs)
+        ring_last.append(rings[-1]); ring_u7.append(rings[7]); left_all.append(left)
+    np.savez_compressed(os.path.join(OUT, 'listener_chunk2048.npz'),
+                        kinds=np.array([k for k, _ in cases]), streams=np.array([s for _, s in cases]),
+                        pcm=np.array(pcm_all), raw=np.array(raw_all), decoded=np.array(dec_all),
+                        ring_last=np.array(ring_last), ring_u7=np.array(ring_u7),
+                        leftover=np.array(left_all))
+
+    # --- other chunk sizes (bytes): 1000, 3200, 6400 and one whole-buffer update ---------
+    odd = {}
+    pcm = synth.stream_pcm(7, 48000, 'tone_noise')
+    for cb in (1000, 3200, 6400, 20000):
+        raws, decs, rings, left = run_listener(pcm, cb, weights)
+        odd['raw_%d' % cb] = raws
+        odd['decoded_%d' % cb] = decs
+        odd['ring_last_%d' % cb] = rings[-1]
+        odd['leftover_%d' % cb] = left
+    # 96000 bytes in ONE update: > n_features new frames at once (network_runner.py:142-143)
+    raws, decs, rings, left = run_listener(pcm, 96000, weights)
+    odd['raw_96000'], odd['decoded_96000'] = raws, decs
+    odd['ring_last_96000'], odd['leftover_96000'] = rings[-1], left
+    np.savez_compressed(os.path.join(OUT, 'listener_oddchunks.npz'), pcm=pcm, **odd)
+
+    # --- vectorize / vectorize_raw / add_deltas (vectorization.py:46-84) ------------------
+    vz = {}
+    for name, n in (('short', 5000), ('exact', 24000), ('long', 40000), ('one_window', 1600)):
+        a = synth.stream_pcm(11, n, 'tone_noise').astype(np.float32) / np.float32(32768.0)
+        vz['audio_' + name] = a
+        vz['vec_' + name] = vectorize(a)
+    a = synth.stream_pcm(11, 8000, 'tone_noise').astype(np.float32) / np.float32(32768.0)
+    vz['raw_feats_8000'] = vectorize_raw(a)
+    vz['deltas_8000'] = add_deltas(vz['raw_feats_8000'])
+    np.savez_compressed(os.path.join(OUT, 'vectorize.npz'), **vz)
+
+    # --- ThresholdDecoder (threshold_decoder.py:38-70) -----------------------------------
+    td = {}
+    grid = np.concatenate([[0.0, 1.0], np.linspace(1e-6, 1 - 1e-6, 197),
+                           1 / (1 + np.exp(-np.linspace(-30, 30, 121)))])
+    thr = np.linspace(0.01, 0.99, 50)
+    for name, cfg, center in (('default', ((6, 4),), 0.2), ('two', ((-3.0, 2.0), (4.0, 1.5)), 0.5),
+                              ('narrow', ((0.0, 0.05),), 0.3)):
+        d = ThresholdDecoder(cfg, center)
+        td['cfg_' + name] = np.array(cfg, dtype=np.float64)
+        td['center_' + name] = center
+        td['decode_' + name] = np.array([d.decode(float(v)) for v in grid])
+        td['encode_' + name] = np.array([d.encode(float(v)) for v in thr])
+        td['cd_len_' + name] = len(d.cd)
+        td['min_out_' + name] = d.min_out
+        td['out_range_' + name] = d.out_range
+    np.savez_compressed(os.path.join(OUT, 'threshold_decoder.npz'), grid=grid, thr=thr, **td)
+
+    # --- weights used by every fixture -----------------------------------------------------
+    k, rk, b = weights['gru'][0]
+    np.savez_compressed(os.path.join(OUT, 'weights_stock_seed42.npz'), kernel=k, recurrent_kernel=rk,
+                        bias=b, dense_kernel=weights['dense_kernel'], dense_bias=weights['dense_bias'])
+    print('golden fixtures written to', OUT)
+    for f in sorted(os.listdir(OUT)):
+        print('  %-32s %8d bytes' % (f, os.path.getsize(os.path.join(OUT, f))))
+
+
+if __name__ == '__main__':
+    main()

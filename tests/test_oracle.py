@@ -1,0 +1,134 @@
+"""
+CPU: the oracle (restatement) against the golden fixtures produced by the reference's own
+unmodified code (oracle/gen_golden.py).  This is what pins the oracle's glue.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import listener as ol
+from oracle import sonopy_restated as so
+from mycroft_precise_amd import synth
+
+
+def test_params_derived_sizes():
+    g = golden('params_default.npz')
+    pr = ol.Params()
+    for k in ('window_samples', 'hop_samples', 'buffer_samples', 'n_features', 'max_samples',
+              'feature_size', 'n_fft', 'n_filt', 'n_mfcc'):
+        assert getattr(pr, k) == int(g[k]), k
+    assert (pr.window_samples, pr.hop_samples, pr.n_features) == (1600, 800, 29)
+
+
+def test_buffer_to_audio_bit_exact():
+    g = golden('buffer_to_audio.npz')
+    out = ol.buffer_to_audio(g['pcm'].tobytes())
+    assert out.dtype == np.float32
+    assert np.array_equal(out, g['audio'])
+
+
+def test_weights_fixture_matches_generator(stock_weights):
+    w = synth.make_weights()
+    for a, b in zip(w['gru'][0], stock_weights['gru'][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(w['dense_kernel'], stock_weights['dense_kernel'])
+
+
+def test_listener_stream_chunk2048(stock_weights):
+    g = golden('listener_chunk2048.npz')
+    for i in range(len(g['streams'])):
+        lis = ol.OracleListener(stock_weights)
+        data = g['pcm'][i].tobytes()
+        raws, decs = [], []
+        for u, off in enumerate(range(0, len(data), 2048)):
+            raw = lis.update_raw(data[off:off + 2048])
+            raws.append(raw)
+            decs.append(lis.threshold_decoder.decode(raw))
+            assert len(lis.window_audio) == g['leftover'][i][u]
+            if u == 7:
+                assert np.array_equal(lis.mfccs, g['ring_u7'][i])
+        assert np.array_equal(lis.mfccs, g['ring_last'][i])
+        assert np.array_equal(np.array(raws, dtype=np.float32), g['raw'][i])
+        assert np.array_equal(np.array(decs), g['decoded'][i])
+
+
+@pytest.mark.parametrize('cb', [1000, 3200, 6400, 20000, 96000])
+def test_listener_odd_chunk_sizes(stock_weights, cb):
+    g = golden('listener_oddchunks.npz')
+    data = g['pcm'].tobytes()
+    lis = ol.OracleListener(stock_weights)
+    raws, decs, left = [], [], []
+    for off in range(0, len(data) - cb + 1, cb):
+        raws.append(lis.update_raw(data[off:off + cb]))
+        decs.append(lis.threshold_decoder.decode(raws[-1]))
+        left.append(len(lis.window_audio))
+    assert np.array_equal(np.array(raws, dtype=np.float32), g['raw_%d' % cb])
+    assert np.array_equal(np.array(decs), g['decoded_%d' % cb])
+    assert np.array_equal(lis.mfccs, g['ring_last_%d' % cb])
+    assert np.array_equal(np.array(left), g['leftover_%d' % cb])
+
+
+def test_empty_chunk_is_eof(stock_weights):
+    with pytest.raises(EOFError):
+        ol.OracleListener(stock_weights).update(b'')
+
+
+def test_vectorize_pad_crop_and_deltas():
+    g = golden('vectorize.npz')
+    pr = ol.Params()
+    for name in ('short', 'exact', 'long', 'one_window'):
+        v = ol.vectorize(g['audio_' + name], pr)
+        assert v.shape == (29, 13)
+        assert np.array_equal(v, g['vec_' + name]), name
+    assert np.array_equal(ol.add_deltas(g['raw_feats_8000']), g['deltas_8000'])
+    with pytest.raises(ValueError):
+        ol.vectorize_raw(np.array([]), pr)
+
+
+@pytest.mark.parametrize('name', ['default', 'two', 'narrow'])
+def test_threshold_decoder(name):
+    g = golden('threshold_decoder.npz')
+    d = ol.ThresholdDecoder([tuple(r) for r in g['cfg_' + name]], float(g['center_' + name]))
+    assert len(d.cd) == int(g['cd_len_' + name])
+    assert d.min_out == int(g['min_out_' + name]) and d.out_range == int(g['out_range_' + name])
+    dec = np.array([d.decode(float(v)) for v in g['grid']])
+    assert np.array_equal(dec, g['decode_' + name])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        enc = np.array([d.encode(float(v)) for v in g['thr']])
+    assert np.array_equal(enc, g['encode_' + name], equal_nan=True)
+
+
+def test_batched_oracle_equals_single_stream(stock_weights):
+    """BatchedOracle (cpu_baseline / GPU checker) == the pinned single-stream restatement."""
+    n_up, streams = 36, [0, 5, 96]
+    pcm = np.stack([synth.stream_pcm(s, n_up * 1024).reshape(n_up, 1024) for s in streams], axis=1)
+    bo = ol.BatchedOracle(stock_weights, len(streams))
+    singles = [ol.OracleListener(stock_weights) for _ in streams]
+    for u in range(n_up):
+        raw_b = bo.update_raw(pcm[u])
+        for j, lis in enumerate(singles):
+            raw_s = lis.update_raw(pcm[u, j].tobytes())
+            assert abs(raw_s - raw_b[j]) < 2e-6
+            assert np.allclose(lis.mfccs, bo.mfccs[j], rtol=0, atol=1e-10)
+
+
+def test_filterbank_shape_and_support():
+    fb = so.filterbanks(16000, 20, 257)
+    assert fb.shape == (20, 257)
+    assert int((fb != 0).sum()) == 455
+    assert fb.min() >= 0.0 and fb.max() == 1.0
+    # every bin feeds at most two filters (triangles only overlap with their neighbours)
+    assert int((fb != 0).sum(0).max()) <= 2
+
+
+def test_frame_crop_quirk_q2():
+    """Only the first n_fft samples of each 1600-sample window reach the FFT."""
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=4000)
+    b = a.copy()
+    b[512:800] = 7.0          # inside window 0, beyond the crop, before window 1
+    b[800 + 512:1600] = -3.0
+    assert np.array_equal(so.mfcc_spec(a, 16000, (1600, 800)), so.mfcc_spec(b, 16000, (1600, 800)))
