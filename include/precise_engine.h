@@ -1,0 +1,143 @@
+/*
+ * precise_engine.h -- C ABI of the MI355X-native wake-word hot path
+ * (libprecise_engine.so, built from mycroft_precise_amd/csrc by hipcc for gfx950).
+ *
+ * The reference (MycroftAI/mycroft-precise) is pure Python, so there is no existing FFI to
+ * mirror; each entry point below replaces one Python-level seam of the reference and cites it
+ * (paths relative to /root/reference).  A maintainer binds this library with ctypes exactly as
+ * mycroft_precise_amd/_lib.py does -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns a pe_status (0 = ok); nothing throws across the ABI;
+ *     pe_last_error() returns a human-readable message for the last failure on that engine
+ *     (pe_last_global_error() for failures of pe_create itself);
+ *   - the caller owns every buffer it passes; the engine copies what it keeps;
+ *   - an engine owns the state of n_streams independent audio streams (leftover PCM + the
+ *     [n_features x n_mfcc] feature window of network_runner.py:102-104) on ONE device; it is
+ *     not thread-safe (the reference's Listener is not either, network_runner.py:98-153);
+ *   - "host" entry points take host pointers and synchronise; "*_device" entry points take
+ *     device pointers of the engine's device plus a hipStream_t (as void*) and are asynchronous;
+ *   - PCM is little-endian int16 mono (util.py:35-37), laid out [n_streams][chunk_samples].
+ */
+#ifndef PRECISE_ENGINE_H
+#define PRECISE_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PE_ABI_VERSION 1
+
+typedef enum pe_status {
+    PE_OK = 0,
+    PE_ERR_INVALID = 1,      /* bad argument (maps to ValueError)                         */
+    PE_ERR_HIP = 2,          /* a HIP runtime call failed                                 */
+    PE_ERR_UNSUPPORTED = 3,  /* parameter combination this build has no kernel for        */
+    PE_ERR_NOMEM = 4,
+    PE_ERR_EOF = 5           /* empty chunk (maps to EOFError, network_runner.py:133-134) */
+} pe_status;
+
+/* ListenerParams (precise/params.py:28-118): the derived sizes the hot path reads. */
+typedef struct pe_params {
+    int32_t sample_rate;     /* 16000                                        params.py:142 */
+    int32_t window_samples;  /* 1600   int(sample_rate*window_t+0.5)         params.py:84  */
+    int32_t hop_samples;     /* 800    int(sample_rate*hop_t+0.5)            params.py:89  */
+    int32_t n_fft;           /* 512    (only 512 has a kernel)               params.py:142 */
+    int32_t n_filt;          /* 20     mel filters, <= 64                    params.py:142 */
+    int32_t n_mfcc;          /* 13     coefficients kept, <= 16              params.py:142 */
+    int32_t n_features;      /* 29     T, timesteps per network input        params.py:79  */
+    int32_t use_delta;       /* 0      (1 is PE_ERR_UNSUPPORTED for now)     params.py:143 */
+    int32_t mfcc_precision;  /* 0 = float64 front end (what the reference computes in,
+                                network_runner.py:102,137);  1 = float32 front end        */
+} pe_params;
+
+/* One Keras GRU layer (precise/model.py:77-81), Keras weight layout, gate order z|r|h. */
+typedef struct pe_gru_layer {
+    int32_t n_in;                    /* F (13) for layer 0, units of the previous layer after */
+    int32_t units;                   /* H (20)                                                */
+    const float* kernel;             /* [n_in][3*units] row-major                              */
+    const float* recurrent_kernel;   /* [units][3*units]                                       */
+    const float* bias;               /* [3*units]                                              */
+} pe_gru_layer;
+
+/* Sequential([GRU..., Dense(1, sigmoid)])   (precise/model.py:76-82) */
+typedef struct pe_weights {
+    int32_t n_layers;                /* 1 in the reference                                     */
+    const pe_gru_layer* layers;
+    const float* dense_kernel;       /* [units_last]                                           */
+    float dense_bias;
+} pe_weights;
+
+typedef struct pe_engine pe_engine;
+
+int pe_abi_version(void);
+const char* pe_last_global_error(void);
+
+/* Replaces Listener.__init__ (network_runner.py:101-108) for n_streams streams at once.
+ * mel_filters: [n_filt][n_fft/2+1] float64 row-major triangular filterbank, built by the host
+ * exactly as the vectorizer the reference calls does (vectorization.py:36-39 -> sonopy). */
+int pe_create(const pe_params* params, const double* mel_filters, const pe_weights* weights,
+              int32_t n_streams, int32_t device, pe_engine** out);
+int pe_destroy(pe_engine* e);
+const char* pe_last_error(const pe_engine* e);
+
+/* Listener.clear (network_runner.py:121-123).  mask: n_streams bytes, non-zero = clear that
+ * stream; NULL = clear all. */
+int pe_clear(pe_engine* e, const uint8_t* mask);
+
+/* Listener.update up to, not including, ThresholdDecoder.decode (network_runner.py:148-152):
+ * append one chunk per stream, emit any new MFCC frames into the feature window, run the
+ * network on the window.  raw_out[n_streams] = raw sigmoid output (float32).
+ * chunk_samples == 0 -> PE_ERR_EOF. */
+int pe_update(pe_engine* e, const int16_t* pcm_host, int32_t chunk_samples, float* raw_out_host);
+int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples,
+                     float* raw_out_dev, void* hip_stream);
+
+/* Listener.update_vectors (network_runner.py:125-146): as pe_update without the network;
+ * feats_out[n_streams][n_features][n_mfcc] float32, oldest row first (may be NULL). */
+int pe_update_vectors(pe_engine* e, const int16_t* pcm_host, int32_t chunk_samples,
+                      float* feats_out_host);
+int pe_update_vectors_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples,
+                             float* feats_out_dev, void* hip_stream);
+
+/* Listener.mfccs (network_runner.py:104,144): copy out the current feature windows,
+ * feats_out[n_streams][n_features][n_mfcc] float32, oldest row first; consumes no audio. */
+int pe_get_vectors(pe_engine* e, float* feats_out_host);
+
+/* Run the network on the current feature windows without consuming audio. */
+int pe_run_device(pe_engine* e, float* raw_out_dev, void* hip_stream);
+
+/* Runner.predict (network_runner.py:35-38): feats[n][n_features][n_mfcc] float32 -> out[n]. */
+int pe_predict(pe_engine* e, const float* feats_host, int32_t n, float* out_host);
+int pe_predict_device(pe_engine* e, const float* feats_dev, int32_t n, float* out_dev,
+                      void* hip_stream);
+
+/* vectorize_raw (vectorization.py:46-50) for the Vectorizer.mfccs entry (:36-39): stateless
+ * MFCC of one whole buffer.  audio: float64 samples in [-1,1) (what the reference's vectorizer
+ * receives).  feats_out[max_frames][n_mfcc] float64; *n_frames_out = 1+(n-window)//hop or 0. */
+int pe_vectorize_raw(pe_engine* e, const double* audio_host, int64_t n_samples,
+                     double* feats_out_host, int64_t max_frames, int64_t* n_frames_out);
+
+/* Introspection used by tests and the bench. */
+typedef struct pe_info {
+    int32_t n_streams, n_features, n_mfcc, units, n_layers, ring_slots, carry_capacity;
+    int32_t mfcc_precision;
+    int64_t device_bytes;            /* HBM held by this engine                                */
+} pe_info;
+int pe_get_info(const pe_engine* e, pe_info* out);
+
+/* Per-stream streaming state, for tests: q = samples held toward the next frame (may be
+ * negative inside the dead zone between windows), frames computed / emitted so far (mod 2^32). */
+int pe_get_stream_state(pe_engine* e, int32_t* q_out, uint32_t* computed_out, uint32_t* emitted_out);
+
+/* HIP-event timing of the kernels launched by the last *_device/host update on this engine
+ * (milliseconds; measured on the stream the kernels ran on).  Enabled with pe_set_timing(e,1). */
+int pe_set_timing(pe_engine* e, int32_t enabled);
+int pe_get_last_timing(pe_engine* e, float* mfcc_ms, float* gru_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRECISE_ENGINE_H */

@@ -1,0 +1,287 @@
+"""
+ctypes binding of libprecise_engine.so (C ABI: include/precise_engine.h).
+
+There is NO CPU fallback: if the HIP library is missing or a call fails this module raises.
+"""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libprecise_engine.so')
+
+PE_OK, PE_ERR_INVALID, PE_ERR_HIP, PE_ERR_UNSUPPORTED, PE_ERR_NOMEM, PE_ERR_EOF = range(6)
+ABI_VERSION = 1
+
+
+class PeParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'sample_rate', 'window_samples', 'hop_samples', 'n_fft', 'n_filt', 'n_mfcc', 'n_features',
+        'use_delta', 'mfcc_precision')]
+
+
+class PeGruLayer(C.Structure):
+    _fields_ = [('n_in', C.c_int32), ('units', C.c_int32),
+                ('kernel', C.POINTER(C.c_float)), ('recurrent_kernel', C.POINTER(C.c_float)),
+                ('bias', C.POINTER(C.c_float))]
+
+
+class PeWeights(C.Structure):
+    _fields_ = [('n_layers', C.c_int32), ('layers', C.POINTER(PeGruLayer)),
+                ('dense_kernel', C.POINTER(C.c_float)), ('dense_bias', C.c_float)]
+
+
+class PeInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'n_streams', 'n_features', 'n_mfcc', 'units', 'n_layers', 'ring_slots', 'carry_capacity',
+        'mfcc_precision')] + [('device_bytes', C.c_int64)]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    'pe_abi_version': (C.c_int, []),
+    'pe_last_global_error': (C.c_char_p, []),
+    'pe_create': (C.c_int, [C.POINTER(PeParams), C.POINTER(C.c_double), C.POINTER(PeWeights), C.c_int32,
+                            C.c_int32, C.POINTER(C.c_void_p)]),
+    'pe_destroy': (C.c_int, [C.c_void_p]),
+    'pe_last_error': (C.c_char_p, [C.c_void_p]),
+    'pe_clear': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'pe_update': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    'pe_update_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'pe_update_vectors': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    'pe_update_vectors_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'pe_get_vectors': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'pe_run_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pe_predict': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    'pe_predict_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'pe_vectorize_raw': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                   C.POINTER(C.c_int64)]),
+    'pe_get_info': (C.c_int, [C.c_void_p, C.POINTER(PeInfo)]),
+    'pe_get_stream_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pe_set_timing': (C.c_int, [C.c_void_p, C.c_int32]),
+    'pe_get_last_timing': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+class HipLibraryMissing(ImportError):
+    pass
+
+
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP
+    runtimes in one process do not share devices pointers or streams, so when torch is installed
+    its copy is loaded first and libprecise_engine.so binds to it -- whatever the import order."""
+    if os.environ.get('PRECISE_AMD_HIP_RUNTIME', '') == 'system':
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+def load():
+    """Load (once) and return the bound library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            'libprecise_engine.so is not built (expected at %s). Build it with '
+            '`python -m mycroft_precise_amd._build`; there is no CPU fallback.' % LIB_PATH)
+    _preload_hip_runtime()
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)       # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pe_abi_version() != ABI_VERSION:
+        raise HipLibraryMissing('libprecise_engine.so ABI %d != expected %d; rebuild' %
+                                (lib.pe_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('precise_engine error %d: %s' % (code, msg))
+        self.code = code
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class HipEngine:
+    """
+    One C-ABI engine: the streaming state of ``n_streams`` audio streams plus one network on one
+    MI355X.  Thin, allocation-free wrapper; the reference-shaped classes live in
+    ``network_runner.py``.
+    """
+
+    def __init__(self, params, weights, n_streams=1, device=0, mfcc_precision='f64', mel_filters=None):
+        from .vectorization import mel_filterbank
+        self._lib = load()
+        self._h = C.c_void_p()
+        self.n_streams = int(n_streams)
+        self.n_features = int(params.n_features)
+        self.n_mfcc = int(params.n_mfcc)
+        prec = {'f64': 0, 'f32': 1}[mfcc_precision]
+        p = PeParams(params.sample_rate, params.window_samples, params.hop_samples, params.n_fft,
+                     params.n_filt, params.n_mfcc, params.n_features, int(bool(params.use_delta)), prec)
+        if mel_filters is None:
+            mel_filters = mel_filterbank(params.sample_rate, params.n_filt, params.n_fft // 2 + 1)
+        mel = np.ascontiguousarray(mel_filters, dtype=np.float64)
+        if mel.shape != (params.n_filt, params.n_fft // 2 + 1):
+            raise ValueError('mel filterbank has shape %r' % (mel.shape,))
+        layers = weights['gru']
+        keep = []                      # keep numpy buffers alive across the call
+        arr = (PeGruLayer * len(layers))()
+        for i, (k, rk, b) in enumerate(layers):
+            k = np.ascontiguousarray(k, dtype=np.float32)
+            rk = np.ascontiguousarray(rk, dtype=np.float32)
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            units = rk.shape[0]
+            if k.shape[1] != 3 * units or rk.shape != (units, 3 * units) or b.shape != (3 * units,):
+                raise ValueError('GRU layer %d has inconsistent shapes' % i)
+            keep += [k, rk, b]
+            arr[i] = PeGruLayer(k.shape[0], units, _fptr(k), _fptr(rk), _fptr(b))
+        dk = np.ascontiguousarray(weights['dense_kernel'], dtype=np.float32).reshape(-1)
+        db = float(np.asarray(weights['dense_bias'], dtype=np.float32).reshape(-1)[0])
+        w = PeWeights(len(layers), arr, _fptr(dk), db)
+        rc = self._lib.pe_create(C.byref(p), mel.ctypes.data_as(C.POINTER(C.c_double)), C.byref(w),
+                                 self.n_streams, int(device), C.byref(self._h))
+        if rc != PE_OK:
+            msg = self._lib.pe_last_global_error().decode()
+            self._h = C.c_void_p()
+            self._raise(rc, msg)
+        self.units = layers[-1][1].shape[0]
+        self._win_hop = (int(params.window_samples), int(params.hop_samples))
+
+    # -- errors -------------------------------------------------------------------------
+    @staticmethod
+    def _raise(rc, msg):
+        if rc == PE_ERR_EOF:
+            raise EOFError
+        if rc == PE_ERR_INVALID:
+            raise ValueError(msg)
+        if rc == PE_ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        if rc == PE_ERR_NOMEM:
+            raise MemoryError(msg)
+        raise EngineError(rc, msg)
+
+    def _check(self, rc):
+        if rc != PE_OK:
+            self._raise(rc, self._lib.pe_last_error(self._h).decode())
+
+    def _pcm(self, pcm):
+        pcm = np.ascontiguousarray(pcm, dtype='<i2')
+        if pcm.ndim == 1:
+            pcm = pcm.reshape(1, -1)
+        if pcm.ndim != 2 or pcm.shape[0] != self.n_streams:
+            raise ValueError('pcm must be int16 [n_streams=%d, chunk_samples], got %r' %
+                             (self.n_streams, pcm.shape))
+        return pcm
+
+    # -- host entry points --------------------------------------------------------------
+    def update(self, pcm) -> np.ndarray:
+        """int16 [n_streams, chunk] -> raw network outputs float32 [n_streams]."""
+        pcm = self._pcm(pcm)
+        out = np.empty(self.n_streams, dtype=np.float32)
+        self._check(self._lib.pe_update(self._h, pcm.ctypes.data, pcm.shape[1], out.ctypes.data))
+        return out
+
+    def update_vectors(self, pcm, want_features=True):
+        pcm = self._pcm(pcm)
+        feats = np.empty((self.n_streams, self.n_features, self.n_mfcc), dtype=np.float32) if want_features else None
+        self._check(self._lib.pe_update_vectors(self._h, pcm.ctypes.data, pcm.shape[1],
+                                                feats.ctypes.data if want_features else None))
+        return feats
+
+    def get_vectors(self) -> np.ndarray:
+        """Current feature windows float32 [n_streams, T, F], oldest row first."""
+        feats = np.empty((self.n_streams, self.n_features, self.n_mfcc), dtype=np.float32)
+        self._check(self._lib.pe_get_vectors(self._h, feats.ctypes.data))
+        return feats
+
+    def predict(self, feats) -> np.ndarray:
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        if feats.ndim != 3 or feats.shape[1:] != (self.n_features, self.n_mfcc):
+            raise ValueError('inputs must be [N, %d, %d], got %r' % (self.n_features, self.n_mfcc, feats.shape))
+        out = np.empty((feats.shape[0], 1), dtype=np.float32)
+        self._check(self._lib.pe_predict(self._h, feats.ctypes.data, feats.shape[0], out.ctypes.data))
+        return out
+
+    def vectorize_raw(self, audio) -> np.ndarray:
+        """float64 audio [n] -> MFCC frames float64 [1 + (n - window)//hop, n_mfcc] (stateless)."""
+        audio = np.ascontiguousarray(audio, dtype=np.float64).reshape(-1)
+        win, hop = self._win_hop
+        max_frames = 1 + (audio.size - win) // hop if audio.size >= win else 0
+        out = np.empty((max_frames, self.n_mfcc), dtype=np.float64)
+        n = C.c_int64(0)
+        self._check(self._lib.pe_vectorize_raw(self._h, audio.ctypes.data if audio.size else None, audio.size,
+                                               out.ctypes.data if max_frames else None, max_frames, C.byref(n)))
+        return out[:n.value]
+
+    def clear(self, mask=None):
+        if mask is None:
+            self._check(self._lib.pe_clear(self._h, None))
+        else:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            if m.shape != (self.n_streams,):
+                raise ValueError('mask must have shape (%d,)' % self.n_streams)
+            self._check(self._lib.pe_clear(self._h, m.ctypes.data))
+
+    # -- device entry points (pointers are ints, e.g. torch.Tensor.data_ptr()) ---------------
+    def update_device(self, pcm_ptr: int, chunk_samples: int, out_ptr: int, stream: int = 0):
+        self._check(self._lib.pe_update_device(self._h, pcm_ptr, chunk_samples, out_ptr, stream))
+
+    def update_vectors_device(self, pcm_ptr: int, chunk_samples: int, feats_ptr: int = 0, stream: int = 0):
+        self._check(self._lib.pe_update_vectors_device(self._h, pcm_ptr, chunk_samples, feats_ptr or None, stream))
+
+    def run_device(self, out_ptr: int, stream: int = 0):
+        self._check(self._lib.pe_run_device(self._h, out_ptr, stream))
+
+    def predict_device(self, feats_ptr: int, n: int, out_ptr: int, stream: int = 0):
+        self._check(self._lib.pe_predict_device(self._h, feats_ptr, n, out_ptr, stream))
+
+    # -- introspection ------------------------------------------------------------------
+    def info(self) -> PeInfo:
+        i = PeInfo()
+        self._check(self._lib.pe_get_info(self._h, C.byref(i)))
+        return i
+
+    def stream_state(self):
+        q = np.empty(self.n_streams, dtype=np.int32)
+        kc = np.empty(self.n_streams, dtype=np.uint32)
+        ke = np.empty(self.n_streams, dtype=np.uint32)
+        self._check(self._lib.pe_get_stream_state(self._h, q.ctypes.data, kc.ctypes.data, ke.ctypes.data))
+        return q, kc, ke
+
+    def set_timing(self, enabled: bool):
+        self._check(self._lib.pe_set_timing(self._h, int(bool(enabled))))
+
+    def last_timing(self):
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(self._lib.pe_get_last_timing(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if getattr(self, '_h', None) and self._h.value:
+            self._lib.pe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

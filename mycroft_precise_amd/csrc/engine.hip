@@ -1,0 +1,549 @@
+// C ABI of libprecise_engine.so (declared in include/precise_engine.h): host-side state,
+// constant tables, weight packing and kernel sequencing for the MI355X wake-word hot path.
+// The arithmetic lives in mfcc_kernels.hip / gru_kernels.hip; nothing here computes on the CPU
+// beyond building constant tables once per engine.
+#include "../../include/precise_engine.h"
+#include "pe_common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace pe;
+
+namespace {
+
+thread_local std::string g_global_error;
+
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct pe_engine {
+    pe_params prm{};
+    int device = 0;
+    int n_streams = 0, n_tiles = 0, n_padded = 0;
+    int units = 0, n_in = 0, n_layers = 0;
+    int ring_slots = 0;
+    int mel_nnz = 0;
+    float dense_bias = 0.f;
+    std::string err;
+    std::vector<void*> allocs;
+    int64_t device_bytes = 0;
+    // streaming state
+    int16_t* carry = nullptr;
+    int32_t* st_q = nullptr;
+    uint32_t* st_kc = nullptr;
+    uint32_t* st_ke = nullptr;
+    float* ring = nullptr;
+    // tables (both precisions share the int tables)
+    void* tw256 = nullptr; void* w512 = nullptr; void* mel_w = nullptr; void* dct = nullptr;
+    int* mel_start = nullptr; int* mel_off = nullptr;
+    // packed network
+    float* wx = nullptr; float* wr1 = nullptr; float* wr2 = nullptr; float* bias = nullptr; float* wd = nullptr;
+    // staging for the host entry points (grown on demand)
+    DeviceBuf st_pcm, st_out, st_feats, st_mask, st_audio, st_mfcc;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool ev_valid = false, ev_has_gru = false;
+};
+
+namespace {
+
+int fail(pe_engine* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf; else g_global_error = buf;
+    return code;
+}
+
+#define PE_HIP(e, call)                                                                      \
+    do {                                                                                     \
+        hipError_t _err = (call);                                                            \
+        if (_err != hipSuccess)                                                              \
+            return fail((e), PE_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_err), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+template <class T>
+int dev_alloc(pe_engine* e, T** out, size_t count) {
+    void* p = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    hipError_t err = hipMalloc(&p, bytes);
+    if (err != hipSuccess) return fail(e, PE_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+    e->allocs.push_back(p);
+    e->device_bytes += (int64_t)bytes;
+    *out = static_cast<T*>(p);
+    return PE_OK;
+}
+
+template <class T>
+int dev_upload(pe_engine* e, T** out, const std::vector<T>& host) {
+    int rc = dev_alloc(e, out, host.size());
+    if (rc) return rc;
+    if (!host.empty()) PE_HIP(e, hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PE_OK;
+}
+
+int ensure(pe_engine* e, DeviceBuf& b, size_t bytes) {
+    if (b.bytes >= bytes) return PE_OK;
+    if (b.p) { (void)hipFree(b.p); e->device_bytes -= (int64_t)b.bytes; b.p = nullptr; b.bytes = 0; }
+    hipError_t err = hipMalloc(&b.p, bytes);
+    if (err != hipSuccess) return fail(e, PE_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+    b.bytes = bytes;
+    e->device_bytes += (int64_t)bytes;
+    return PE_OK;
+}
+
+int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+template <class R>
+int build_tables(pe_engine* e, const double* mel_filters) {
+    const double PI = 3.14159265358979323846;
+    const int n_filt = e->prm.n_filt, n_mfcc = e->prm.n_mfcc;
+    std::vector<cplx<R>> tw(256), w5(129);
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int r = 0; r < 16; ++r) {
+            const double ang = -2.0 * PI * (double)(r * k1) / 256.0;
+            tw[k1 * 16 + r] = {(R)std::cos(ang), (R)std::sin(ang)};
+        }
+    for (int p = 0; p <= 128; ++p) {
+        const double ang = -2.0 * PI * (double)p / 512.0;
+        w5[p] = {(R)std::cos(ang), (R)std::sin(ang)};
+    }
+    // scipy.fftpack.dct(type=2, norm='ortho') as a matrix: y[k] = s_k sum_n x[n] cos(pi k (2n+1) / (2N))
+    std::vector<R> dct((size_t)n_mfcc * n_filt);
+    for (int k = 0; k < n_mfcc; ++k) {
+        const double sk = (k == 0) ? std::sqrt(1.0 / n_filt) : std::sqrt(2.0 / n_filt);
+        for (int n = 0; n < n_filt; ++n)
+            dct[(size_t)k * n_filt + n] = (R)(sk * std::cos(PI * k * (2 * n + 1) / (2.0 * n_filt)));
+    }
+    // trim each dense triangular filter to its support
+    std::vector<R> mw;
+    std::vector<int> ms(n_filt), mo(n_filt + 1);
+    for (int f = 0; f < n_filt; ++f) {
+        const double* row = mel_filters + (size_t)f * kBins;
+        int lo = -1, hi = -1;
+        for (int b = 0; b < kBins; ++b)
+            if (row[b] != 0.0) { if (lo < 0) lo = b; hi = b; }
+        mo[f] = (int)mw.size();
+        ms[f] = lo < 0 ? 0 : lo;
+        if (lo >= 0) for (int b = lo; b <= hi; ++b) mw.push_back((R)row[b]);
+    }
+    mo[n_filt] = (int)mw.size();
+    if ((int)mw.size() > kMaxMelNnz) return fail(e, PE_ERR_UNSUPPORTED, "mel filterbank has %zu non-zeros, limit %d", mw.size(), kMaxMelNnz);
+    e->mel_nnz = (int)mw.size();
+    int rc;
+    cplx<R>* d_tw; cplx<R>* d_w5; R* d_mw; R* d_dct;
+    if ((rc = dev_upload(e, &d_tw, tw))) return rc;
+    if ((rc = dev_upload(e, &d_w5, w5))) return rc;
+    if ((rc = dev_upload(e, &d_mw, mw))) return rc;
+    if ((rc = dev_upload(e, &d_dct, dct))) return rc;
+    if ((rc = dev_upload(e, &e->mel_start, ms))) return rc;
+    if ((rc = dev_upload(e, &e->mel_off, mo))) return rc;
+    e->tw256 = d_tw; e->w512 = d_w5; e->mel_w = d_mw; e->dct = d_dct;
+    return PE_OK;
+}
+
+// Arrange the Keras matrices as MFMA A-operands (see the layout comment in gru_kernels.hip).
+int pack_gru_weights(pe_engine* e, const pe_gru_layer& L, const float* dense_kernel) {
+    const int H = L.units, F = L.n_in;
+    const int R = gru_small_regs(H), NT = gru_small_tiles(H);
+    std::vector<float> wx((size_t)NT * 4 * 64, 0.f), wr1((size_t)NT * R * 64, 0.f), wr2((size_t)NT * R * 64, 0.f);
+    std::vector<float> bias((size_t)NT * 4 * 64, 0.f), wd((size_t)R * 64, 0.f);
+    for (int tile = 0; tile < NT; ++tile)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, g = lane >> 4;
+            {   // A operand: row i of the tile, k-slot g
+                const int reg = i & 3, gout = i >> 2;
+                const int slot = 4 * tile + reg;
+                const int gate = slot / R, rho = slot % R, u = 4 * rho + gout;
+                if (slot < 3 * R && u < H) {
+                    const int col = gate * H + u;
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int phi = 4 * g + kk;
+                        if (phi < F) wx[((size_t)tile * 4 + kk) * 64 + lane] = L.kernel[(size_t)phi * 3 * H + col];
+                    }
+                    for (int rs = 0; rs < R; ++rs) {
+                        const int usrc = 4 * rs + g;
+                        if (usrc >= H) continue;
+                        const float w = L.recurrent_kernel[(size_t)usrc * 3 * H + col];
+                        (gate < 2 ? wr1 : wr2)[((size_t)tile * R + rs) * 64 + lane] = w;
+                    }
+                }
+            }
+            for (int q = 0; q < 4; ++q) {   // C operand: this lane's output rows 4g + q
+                const int slot = 4 * tile + q;
+                const int gate = slot / R, rho = slot % R, u = 4 * rho + g;
+                if (slot < 3 * R && u < H) bias[((size_t)tile * 4 + q) * 64 + lane] = L.bias[gate * H + u];
+            }
+        }
+    for (int rho = 0; rho < R; ++rho)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int u = 4 * rho + (lane >> 4);
+            if (u < H) wd[(size_t)rho * 64 + lane] = dense_kernel[u];
+        }
+    int rc;
+    if ((rc = dev_upload(e, &e->wx, wx))) return rc;
+    if ((rc = dev_upload(e, &e->wr1, wr1))) return rc;
+    if ((rc = dev_upload(e, &e->wr2, wr2))) return rc;
+    if ((rc = dev_upload(e, &e->bias, bias))) return rc;
+    if ((rc = dev_upload(e, &e->wd, wd))) return rc;
+    return PE_OK;
+}
+
+StreamGeom geom(const pe_engine* e) {
+    StreamGeom g;
+    g.n_streams = e->n_streams;
+    g.window = e->prm.window_samples;
+    g.hop = e->prm.hop_samples;
+    g.frame_len = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
+    g.n_filt = e->prm.n_filt;
+    g.n_mfcc = e->prm.n_mfcc;
+    g.n_features = e->prm.n_features;
+    g.ring_slots = e->ring_slots;
+    return g;
+}
+
+template <class R>
+MfccTables<R> tables(const pe_engine* e) {
+    MfccTables<R> t;
+    t.tw256 = static_cast<const cplx<R>*>(e->tw256);
+    t.w512 = static_cast<const cplx<R>*>(e->w512);
+    t.mel_w = static_cast<const R*>(e->mel_w);
+    t.dct = static_cast<const R*>(e->dct);
+    t.mel_start = e->mel_start;
+    t.mel_off = e->mel_off;
+    t.mel_nnz = e->mel_nnz;
+    return t;
+}
+
+int launch_mfcc(pe_engine* e, const int16_t* pcm_dev, int chunk, hipStream_t s) {
+    const int pairs_ok = ((chunk & 1) == 0) && ((reinterpret_cast<uintptr_t>(pcm_dev) & 3u) == 0);
+    if (e->prm.mfcc_precision == 0) {
+        MfccStreamArgs<double> a;
+        a.geo = geom(e); a.tab = tables<double>(e);
+        a.pcm = pcm_dev; a.chunk = chunk; a.pcm_pairs_ok = pairs_ok;
+        a.carry = e->carry; a.st_q = e->st_q; a.st_kc = e->st_kc; a.st_ke = e->st_ke; a.ring = e->ring;
+        PE_HIP(e, launch_mfcc_stream_f64(a, s));
+    } else {
+        MfccStreamArgs<float> a;
+        a.geo = geom(e); a.tab = tables<float>(e);
+        a.pcm = pcm_dev; a.chunk = chunk; a.pcm_pairs_ok = pairs_ok;
+        a.carry = e->carry; a.st_q = e->st_q; a.st_kc = e->st_kc; a.st_ke = e->st_ke; a.ring = e->ring;
+        PE_HIP(e, launch_mfcc_stream_f32(a, s));
+    }
+    return PE_OK;
+}
+
+GruArgs gru_args(const pe_engine* e) {
+    GruArgs a{};
+    a.n_streams = e->n_streams;
+    a.n_features = e->prm.n_features;
+    a.n_in = e->n_in;
+    a.units = e->units;
+    a.wx = e->wx; a.wr1 = e->wr1; a.wr2 = e->wr2; a.bias = e->bias; a.wd = e->wd;
+    a.dense_bias = e->dense_bias;
+    a.ring = e->ring; a.st_ke = e->st_ke; a.ring_slots = e->ring_slots;
+    a.feats = nullptr; a.out = nullptr;
+    return a;
+}
+
+int launch_gru_ring(pe_engine* e, float* out_dev, hipStream_t s) {
+    GruArgs a = gru_args(e);
+    a.out = out_dev;
+    PE_HIP(e, launch_gru_small(a, true, s));
+    return PE_OK;
+}
+
+int check_chunk(pe_engine* e, const void* pcm, int chunk) {
+    if (!e) return PE_ERR_INVALID;
+    if (chunk == 0) return fail(e, PE_ERR_EOF, "empty chunk");
+    if (chunk < 0 || !pcm) return fail(e, PE_ERR_INVALID, "bad pcm buffer / chunk_samples=%d", chunk);
+    return PE_OK;
+}
+
+int do_update(pe_engine* e, const int16_t* pcm_dev, int chunk, float* raw_out_dev, float* feats_out_dev,
+              hipStream_t s) {
+    int rc;
+    const bool t = e->timing;
+    if (t) { PE_HIP(e, hipEventRecord(e->ev[0], s)); }
+    if ((rc = launch_mfcc(e, pcm_dev, chunk, s))) return rc;
+    if (t) { PE_HIP(e, hipEventRecord(e->ev[1], s)); }
+    if (raw_out_dev) {
+        if ((rc = launch_gru_ring(e, raw_out_dev, s))) return rc;
+    }
+    if (t) { PE_HIP(e, hipEventRecord(e->ev[2], s)); e->ev_valid = true; e->ev_has_gru = raw_out_dev != nullptr; }
+    if (feats_out_dev) {
+        GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->ring, e->st_ke, feats_out_dev};
+        PE_HIP(e, launch_gather(g, s));
+    }
+    return PE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pe_abi_version(void) { return PE_ABI_VERSION; }
+const char* pe_last_global_error(void) { return g_global_error.c_str(); }
+const char* pe_last_error(const pe_engine* e) { return e ? e->err.c_str() : g_global_error.c_str(); }
+
+int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w, int32_t n_streams,
+              int32_t device, pe_engine** out) {
+    if (!p || !mel_filters || !w || !out) return fail(nullptr, PE_ERR_INVALID, "null argument to pe_create");
+    *out = nullptr;
+    if (n_streams <= 0) return fail(nullptr, PE_ERR_INVALID, "n_streams must be positive, got %d", n_streams);
+    if (p->n_fft != kNfft) return fail(nullptr, PE_ERR_UNSUPPORTED, "only n_fft=512 has a kernel (got %d)", p->n_fft);
+    if (p->n_mfcc < 1 || p->n_mfcc > kRowFloats) return fail(nullptr, PE_ERR_UNSUPPORTED, "n_mfcc must be in 1..16 (got %d)", p->n_mfcc);
+    if (p->n_filt < 1 || p->n_filt > kMaxFilt || p->n_mfcc > p->n_filt)
+        return fail(nullptr, PE_ERR_UNSUPPORTED, "need 1 <= n_mfcc <= n_filt <= 64 (got n_filt=%d n_mfcc=%d)", p->n_filt, p->n_mfcc);
+    if (p->hop_samples < 1 || p->window_samples < 1 || p->n_features < 1)
+        return fail(nullptr, PE_ERR_INVALID, "window/hop/n_features must be positive");
+    if (p->use_delta) return fail(nullptr, PE_ERR_UNSUPPORTED, "use_delta=True has no kernel yet");
+    if (p->mfcc_precision != 0 && p->mfcc_precision != 1) return fail(nullptr, PE_ERR_INVALID, "mfcc_precision must be 0 (f64) or 1 (f32)");
+    if (w->n_layers != 1 || !w->layers) return fail(nullptr, PE_ERR_UNSUPPORTED, "only single-layer GRU networks have a kernel (got %d layers)", w->n_layers);
+    const pe_gru_layer& L = w->layers[0];
+    if (L.units < 1 || L.units > 32) return fail(nullptr, PE_ERR_UNSUPPORTED, "register-resident GRU kernel needs 1 <= units <= 32 (got %d)", L.units);
+    if (L.n_in != p->n_mfcc) return fail(nullptr, PE_ERR_INVALID, "layer n_in=%d does not match n_mfcc=%d", L.n_in, p->n_mfcc);
+    if (!L.kernel || !L.recurrent_kernel || !L.bias || !w->dense_kernel) return fail(nullptr, PE_ERR_INVALID, "null weight pointer");
+
+    hipError_t herr = hipSetDevice(device);
+    if (herr != hipSuccess) return fail(nullptr, PE_ERR_HIP, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(herr));
+
+    pe_engine* e = new pe_engine();
+    e->prm = *p;
+    e->device = device;
+    e->n_streams = n_streams;
+    e->n_tiles = (n_streams + kTileStreams - 1) / kTileStreams;
+    e->n_padded = e->n_tiles * kTileStreams;
+    e->units = L.units; e->n_in = L.n_in; e->n_layers = 1;
+    e->dense_bias = w->dense_bias;
+    const int flen = p->window_samples < kNfft ? p->window_samples : kNfft;
+    const int pending = (p->window_samples - flen + p->hop_samples - 1) / p->hop_samples + 1;
+    e->ring_slots = next_pow2(p->n_features + pending + 1);
+
+    int rc = PE_OK;
+    do {
+        if ((rc = dev_alloc(e, &e->carry, (size_t)e->n_padded * kCarryCap))) break;
+        if ((rc = dev_alloc(e, &e->st_q, (size_t)e->n_padded))) break;
+        if ((rc = dev_alloc(e, &e->st_kc, (size_t)e->n_padded))) break;
+        if ((rc = dev_alloc(e, &e->st_ke, (size_t)e->n_padded))) break;
+        if ((rc = dev_alloc(e, &e->ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kRowFloats))) break;
+        rc = (p->mfcc_precision == 0) ? build_tables<double>(e, mel_filters) : build_tables<float>(e, mel_filters);
+        if (rc) break;
+        if ((rc = pack_gru_weights(e, L, w->dense_kernel))) break;
+        for (auto& ev : e->ev)
+            if (hipEventCreate(&ev) != hipSuccess) { rc = fail(e, PE_ERR_HIP, "hipEventCreate failed"); break; }
+        if (rc) break;
+        const size_t lds = mfcc_lds_bytes(p->mfcc_precision == 0 ? 8 : 4, p->n_filt, p->n_mfcc, e->mel_nnz);
+        if (lds > 160 * 1024) { rc = fail(e, PE_ERR_UNSUPPORTED, "MFCC kernel would need %zu bytes of LDS", lds); break; }
+        if ((rc = pe_clear(e, nullptr))) break;
+        hipError_t se = hipDeviceSynchronize();
+        if (se != hipSuccess) { rc = fail(e, PE_ERR_HIP, "device sync after init failed: %s", hipGetErrorString(se)); break; }
+    } while (false);
+    if (rc) {
+        g_global_error = e->err;
+        pe_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return PE_OK;
+}
+
+int pe_destroy(pe_engine* e) {
+    if (!e) return PE_OK;
+    (void)hipSetDevice(e->device);
+    for (void* p : e->allocs) (void)hipFree(p);
+    for (DeviceBuf* b : {&e->st_pcm, &e->st_out, &e->st_feats, &e->st_mask, &e->st_audio, &e->st_mfcc})
+        if (b->p) (void)hipFree(b->p);
+    for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    delete e;
+    return PE_OK;
+}
+
+int pe_clear(pe_engine* e, const uint8_t* mask_host) {
+    if (!e) return PE_ERR_INVALID;
+    PE_HIP(e, hipSetDevice(e->device));
+    const uint8_t* mask_dev = nullptr;
+    if (mask_host) {
+        int rc = ensure(e, e->st_mask, (size_t)e->n_streams);
+        if (rc) return rc;
+        PE_HIP(e, hipMemcpy(e->st_mask.p, mask_host, (size_t)e->n_streams, hipMemcpyHostToDevice));
+        mask_dev = static_cast<const uint8_t*>(e->st_mask.p);
+    }
+    ClearArgs a{e->n_padded, e->ring_slots, mask_dev, e->st_q, e->st_kc, e->st_ke, e->ring};
+    if (mask_dev) a.n_streams = e->n_streams;
+    PE_HIP(e, launch_clear(a, nullptr));
+    PE_HIP(e, hipStreamSynchronize(nullptr));
+    return PE_OK;
+}
+
+int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, float* raw_out_dev, void* stream) {
+    int rc = check_chunk(e, pcm_dev, chunk);
+    if (rc) return rc;
+    if (!raw_out_dev) return fail(e, PE_ERR_INVALID, "raw_out_dev is null");
+    return do_update(e, pcm_dev, chunk, raw_out_dev, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int pe_update_vectors_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, float* feats_out_dev, void* stream) {
+    int rc = check_chunk(e, pcm_dev, chunk);
+    if (rc) return rc;
+    return do_update(e, pcm_dev, chunk, nullptr, feats_out_dev, static_cast<hipStream_t>(stream));
+}
+
+int pe_run_device(pe_engine* e, float* raw_out_dev, void* stream) {
+    if (!e || !raw_out_dev) return fail(e, PE_ERR_INVALID, "null argument to pe_run_device");
+    return launch_gru_ring(e, raw_out_dev, static_cast<hipStream_t>(stream));
+}
+
+int pe_update(pe_engine* e, const int16_t* pcm_host, int32_t chunk, float* raw_out_host) {
+    int rc = check_chunk(e, pcm_host, chunk);
+    if (rc) return rc;
+    if (!raw_out_host) return fail(e, PE_ERR_INVALID, "raw_out_host is null");
+    PE_HIP(e, hipSetDevice(e->device));
+    const size_t pcm_bytes = (size_t)e->n_streams * chunk * sizeof(int16_t);
+    if ((rc = ensure(e, e->st_pcm, pcm_bytes))) return rc;
+    if ((rc = ensure(e, e->st_out, (size_t)e->n_streams * sizeof(float)))) return rc;
+    PE_HIP(e, hipMemcpy(e->st_pcm.p, pcm_host, pcm_bytes, hipMemcpyHostToDevice));
+    if ((rc = do_update(e, static_cast<const int16_t*>(e->st_pcm.p), chunk, static_cast<float*>(e->st_out.p), nullptr, nullptr))) return rc;
+    PE_HIP(e, hipMemcpy(raw_out_host, e->st_out.p, (size_t)e->n_streams * sizeof(float), hipMemcpyDeviceToHost));
+    return PE_OK;
+}
+
+int pe_update_vectors(pe_engine* e, const int16_t* pcm_host, int32_t chunk, float* feats_out_host) {
+    int rc = check_chunk(e, pcm_host, chunk);
+    if (rc) return rc;
+    PE_HIP(e, hipSetDevice(e->device));
+    const size_t pcm_bytes = (size_t)e->n_streams * chunk * sizeof(int16_t);
+    const size_t feat_bytes = (size_t)e->n_streams * e->prm.n_features * e->prm.n_mfcc * sizeof(float);
+    if ((rc = ensure(e, e->st_pcm, pcm_bytes))) return rc;
+    if (feats_out_host && (rc = ensure(e, e->st_feats, feat_bytes))) return rc;
+    PE_HIP(e, hipMemcpy(e->st_pcm.p, pcm_host, pcm_bytes, hipMemcpyHostToDevice));
+    if ((rc = do_update(e, static_cast<const int16_t*>(e->st_pcm.p), chunk, nullptr,
+                        feats_out_host ? static_cast<float*>(e->st_feats.p) : nullptr, nullptr))) return rc;
+    if (feats_out_host) PE_HIP(e, hipMemcpy(feats_out_host, e->st_feats.p, feat_bytes, hipMemcpyDeviceToHost));
+    else PE_HIP(e, hipStreamSynchronize(nullptr));
+    return PE_OK;
+}
+
+int pe_get_vectors(pe_engine* e, float* feats_out_host) {
+    if (!e || !feats_out_host) return fail(e, PE_ERR_INVALID, "null argument to pe_get_vectors");
+    PE_HIP(e, hipSetDevice(e->device));
+    int rc;
+    const size_t feat_bytes = (size_t)e->n_streams * e->prm.n_features * e->prm.n_mfcc * sizeof(float);
+    if ((rc = ensure(e, e->st_feats, feat_bytes))) return rc;
+    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->ring, e->st_ke, static_cast<float*>(e->st_feats.p)};
+    PE_HIP(e, launch_gather(g, nullptr));
+    PE_HIP(e, hipMemcpy(feats_out_host, e->st_feats.p, feat_bytes, hipMemcpyDeviceToHost));
+    return PE_OK;
+}
+
+int pe_predict_device(pe_engine* e, const float* feats_dev, int32_t n, float* out_dev, void* stream) {
+    if (!e) return PE_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!feats_dev || !out_dev))) return fail(e, PE_ERR_INVALID, "bad arguments to pe_predict_device");
+    if (n == 0) return PE_OK;
+    GruArgs a = gru_args(e);
+    a.n_streams = n;
+    a.feats = feats_dev;
+    a.out = out_dev;
+    PE_HIP(e, launch_gru_small(a, false, static_cast<hipStream_t>(stream)));
+    return PE_OK;
+}
+
+int pe_predict(pe_engine* e, const float* feats_host, int32_t n, float* out_host) {
+    if (!e) return PE_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!feats_host || !out_host))) return fail(e, PE_ERR_INVALID, "bad arguments to pe_predict");
+    if (n == 0) return PE_OK;
+    PE_HIP(e, hipSetDevice(e->device));
+    int rc;
+    const size_t fb = (size_t)n * e->prm.n_features * e->n_in * sizeof(float);
+    if ((rc = ensure(e, e->st_feats, fb))) return rc;
+    if ((rc = ensure(e, e->st_out, (size_t)n * sizeof(float)))) return rc;
+    PE_HIP(e, hipMemcpy(e->st_feats.p, feats_host, fb, hipMemcpyHostToDevice));
+    if ((rc = pe_predict_device(e, static_cast<const float*>(e->st_feats.p), n, static_cast<float*>(e->st_out.p), nullptr))) return rc;
+    PE_HIP(e, hipMemcpy(out_host, e->st_out.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return PE_OK;
+}
+
+int pe_vectorize_raw(pe_engine* e, const double* audio_host, int64_t n_samples, double* feats_out_host,
+                     int64_t max_frames, int64_t* n_frames_out) {
+    if (!e || !n_frames_out) return fail(e, PE_ERR_INVALID, "null argument to pe_vectorize_raw");
+    if (n_samples < 0 || (n_samples > 0 && !audio_host)) return fail(e, PE_ERR_INVALID, "bad audio buffer");
+    const int64_t win = e->prm.window_samples, hop = e->prm.hop_samples;
+    const int64_t n_frames = n_samples >= win ? 1 + (n_samples - win) / hop : 0;
+    *n_frames_out = n_frames;
+    if (n_frames == 0) return PE_OK;
+    if (!feats_out_host || max_frames < n_frames) return fail(e, PE_ERR_INVALID, "output holds %lld frames, need %lld", (long long)max_frames, (long long)n_frames);
+    PE_HIP(e, hipSetDevice(e->device));
+    int rc;
+    const size_t ab = (size_t)n_samples * sizeof(double), fb = (size_t)n_frames * e->prm.n_mfcc * sizeof(double);
+    if ((rc = ensure(e, e->st_audio, ab))) return rc;
+    if ((rc = ensure(e, e->st_mfcc, fb))) return rc;
+    PE_HIP(e, hipMemcpy(e->st_audio.p, audio_host, ab, hipMemcpyHostToDevice));
+    if (e->prm.mfcc_precision == 0) {
+        MfccOfflineArgs<double> a{geom(e), tables<double>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, static_cast<double*>(e->st_mfcc.p)};
+        PE_HIP(e, launch_mfcc_offline_f64(a, nullptr));
+    } else {
+        MfccOfflineArgs<float> a{geom(e), tables<float>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, static_cast<double*>(e->st_mfcc.p)};
+        PE_HIP(e, launch_mfcc_offline_f32(a, nullptr));
+    }
+    PE_HIP(e, hipMemcpy(feats_out_host, e->st_mfcc.p, fb, hipMemcpyDeviceToHost));
+    return PE_OK;
+}
+
+int pe_get_info(const pe_engine* e, pe_info* out) {
+    if (!e || !out) return PE_ERR_INVALID;
+    out->n_streams = e->n_streams;
+    out->n_features = e->prm.n_features;
+    out->n_mfcc = e->prm.n_mfcc;
+    out->units = e->units;
+    out->n_layers = e->n_layers;
+    out->ring_slots = e->ring_slots;
+    out->carry_capacity = kCarryCap;
+    out->mfcc_precision = e->prm.mfcc_precision;
+    out->device_bytes = e->device_bytes;
+    return PE_OK;
+}
+
+int pe_get_stream_state(pe_engine* e, int32_t* q_out, uint32_t* computed_out, uint32_t* emitted_out) {
+    if (!e) return PE_ERR_INVALID;
+    PE_HIP(e, hipSetDevice(e->device));
+    PE_HIP(e, hipDeviceSynchronize());
+    const size_t n = (size_t)e->n_streams;
+    if (q_out) PE_HIP(e, hipMemcpy(q_out, e->st_q, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (computed_out) PE_HIP(e, hipMemcpy(computed_out, e->st_kc, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (emitted_out) PE_HIP(e, hipMemcpy(emitted_out, e->st_ke, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return PE_OK;
+}
+
+int pe_set_timing(pe_engine* e, int32_t enabled) {
+    if (!e) return PE_ERR_INVALID;
+    e->timing = enabled != 0;
+    e->ev_valid = false;
+    return PE_OK;
+}
+
+int pe_get_last_timing(pe_engine* e, float* mfcc_ms, float* gru_ms) {
+    if (!e) return PE_ERR_INVALID;
+    if (!e->ev_valid) return fail(e, PE_ERR_INVALID, "no timed update recorded (call pe_set_timing(e, 1) first)");
+    PE_HIP(e, hipEventSynchronize(e->ev[2]));
+    float a = 0.f, b = 0.f;
+    PE_HIP(e, hipEventElapsedTime(&a, e->ev[0], e->ev[1]));
+    PE_HIP(e, hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
+    if (mfcc_ms) *mfcc_ms = a;
+    if (gru_ms) *gru_ms = e->ev_has_gru ? b : 0.f;
+    return PE_OK;
+}
+
+}  // extern "C"

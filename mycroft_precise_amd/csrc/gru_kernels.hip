@@ -1,0 +1,227 @@
+// GRU + Dense(1, sigmoid) forward over the sliding [T x F] feature window, for gfx950.
+//
+// Network: /root/reference/precise/model.py:76-82 (GRU(units, activation='linear') -> Dense(1,
+// 'sigmoid')), executed by Runner.predict (/root/reference/precise/network_runner.py:69-74).
+// Keras GRUCell (implementation 1, reset_after=False, hard_sigmoid), h0 = 0 for every window:
+//     z = hs(x Wz + bz + h Uz)      r = hs(x Wr + br + h Ur)      hs(v) = clip(0.2 v + 0.5, 0, 1)
+//     hh = x Wh + bh + (r*h) Uh     h' = z*h + (1-z)*hh           p = sigmoid(h_T . Wd + bd)
+//
+// Mapping to the machine: the three gate matmuls are the one dense contraction of the path, so
+// they run on the f32 matrix cores as v_mfma_f32_16x16x4_f32 with the problem TRANSPOSED:
+//     gates^T [gate rows x 16 streams] = W^T [gate rows x K] . x^T / h^T [K x 16 streams]
+//   * N = 16 streams of one tile, one wave per tile; weights are the A operand and stay in
+//     registers for the whole window (one VGPR per tile and k-step), biases are the C operand of
+//     the first MFMA of each chain;
+//   * hidden unit u lives in lane group g = u % 4 (lane >> 4), register rho = u / 4.  Gate values
+//     are laid out in "slots": slot s = gate*R + rho occupies MFMA output register s % 4 of tile
+//     s / 4, whose row 4g + reg is unit 4 rho + g.  So z, r, candidate and h of one unit sit in
+//     the same lane, and the D registers of one step ARE the B operands (k-slot g) of the next
+//     step's recurrent MFMAs -- no transpose, no LDS, no cross-lane traffic inside the recurrence;
+//   * tiles holding z/r slots accumulate h.U in phase 1, tiles holding candidate slots accumulate
+//     (r*h).U in phase 2; a tile holding both kinds gets both, with the other rows' weights zero;
+//   * the feature ring is stored [tile][slot][stream][16 floats], so lane (g, j) fetches features
+//     4g..4g+3 of stream j with one 16-byte load and the wave reads 1 KiB contiguous per timestep
+//     (k-step kk of the input projection <-> feature 4g + kk).
+#include "pe_common.h"
+
+namespace pe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float hard_sigmoid(float v) {
+    // Keras/TF: x = (0.2 * x) + 0.5 as two ops, then clip(0, 1)
+    const float y = __fadd_rn(__fmul_rn(0.2f, v), 0.5f);
+    return __builtin_amdgcn_fmed3f(y, 0.0f, 1.0f);
+}
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int R> struct GruShape {
+    static constexpr int SLOTS = 3 * R;
+    static constexpr int NT = (SLOTS + 3) / 4;       // output tiles
+    static constexpr int P1_END = (2 * R + 3) / 4;   // tiles [0, P1_END) hold z/r slots
+    static constexpr int P2_BEGIN = (2 * R) / 4;     // tiles [P2_BEGIN, NT) hold candidate slots
+    static constexpr int NP2 = NT - P2_BEGIN;
+};
+
+template <int R, bool FROM_RING>
+__global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
+    using G = GruShape<R>;
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, j = lane & 15;
+    const int tile = blockIdx.x;
+    const long long stream = (long long)tile * kTileStreams + j;
+    const bool valid = stream < a.n_streams;
+    const int T = a.n_features;
+
+    // ---- resident operands ------------------------------------------------------------
+    float wx[G::NT][4], wr1[G::P1_END][R], wr2[G::NP2][R], wd[R];
+    f32x4 bias[G::NT];
+#pragma unroll
+    for (int t = 0; t < G::NT; ++t) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wx[t][kk] = a.wx[(t * 4 + kk) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias[t][q] = a.bias[(t * 4 + q) * 64 + lane];
+    }
+#pragma unroll
+    for (int t = 0; t < G::P1_END; ++t)
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) wr1[t][rho] = a.wr1[(t * R + rho) * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < G::NP2; ++t)
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) wr2[t][rho] = a.wr2[((t + G::P2_BEGIN) * R + rho) * 64 + lane];
+#pragma unroll
+    for (int rho = 0; rho < R; ++rho) wd[rho] = a.wd[rho * 64 + lane];
+
+    // ---- input addressing -------------------------------------------------------------
+    const float* xbase = nullptr;
+    uint32_t first = 0;           // ring: frame index of timestep 0
+    const uint32_t mask = (uint32_t)(a.ring_slots - 1);
+    if (FROM_RING) {
+        const uint32_t ke = valid ? a.st_ke[stream] : 0u;
+        first = ke - (uint32_t)T;
+        xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats + 4 * g;
+    } else {
+        xbase = a.feats + (size_t)stream * T * a.n_in;
+    }
+    auto load_x = [&](int t) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!valid || t >= T) return v;
+        if (FROM_RING) {
+            const uint32_t slot = (first + (uint32_t)t) & mask;
+            v = *reinterpret_cast<const f32x4*>(xbase + (size_t)slot * kTileStreams * kRowFloats);
+        } else {
+            const float* p = xbase + (size_t)t * a.n_in + 4 * g;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) v[kk] = (4 * g + kk < a.n_in) ? p[kk] : 0.f;
+        }
+        return v;
+    };
+
+    float h[R];
+#pragma unroll
+    for (int rho = 0; rho < R; ++rho) h[rho] = 0.f;
+
+    f32x4 x = load_x(0);
+    for (int t = 0; t < T; ++t) {
+        const f32x4 xn = load_x(t + 1);      // prefetch next timestep's features
+        f32x4 acc[G::NT];
+        // input projection, bias as the initial accumulator
+#pragma unroll
+        for (int tl = 0; tl < G::NT; ++tl) {
+            acc[tl] = mfma(wx[tl][0], x[0], bias[tl]);
+#pragma unroll
+            for (int kk = 1; kk < 4; ++kk) acc[tl] = mfma(wx[tl][kk], x[kk], acc[tl]);
+        }
+        // phase 1: + h . U for the z / r rows
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho)
+#pragma unroll
+            for (int tl = 0; tl < G::P1_END; ++tl) acc[tl] = mfma(wr1[tl][rho], h[rho], acc[tl]);
+        float z[R], rh[R];
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) {
+            const int sz = rho, sr = R + rho;
+            z[rho] = hard_sigmoid(acc[sz >> 2][sz & 3]);
+            const float r = hard_sigmoid(acc[sr >> 2][sr & 3]);
+            rh[rho] = __fmul_rn(r, h[rho]);
+        }
+        // phase 2: + (r*h) . U for the candidate rows
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho)
+#pragma unroll
+            for (int tl = G::P2_BEGIN; tl < G::NT; ++tl) acc[tl] = mfma(wr2[tl - G::P2_BEGIN][rho], rh[rho], acc[tl]);
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) {
+            const int sh = 2 * R + rho;
+            const float hh = acc[sh >> 2][sh & 3];
+            h[rho] = __fadd_rn(__fmul_rn(z[rho], h[rho]), __fmul_rn(__fsub_rn(1.0f, z[rho]), hh));
+        }
+        x = xn;
+    }
+
+    // Dense(1) + sigmoid: reduce over this lane's units, then over the four lane groups
+    float part = 0.f;
+#pragma unroll
+    for (int rho = 0; rho < R; ++rho) part = fmaf(h[rho], wd[rho], part);
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    if (valid && g == 0) {
+        const float logit = part + a.dense_bias;
+        a.out[stream] = 1.0f / (1.0f + expf(-logit));
+    }
+}
+
+int gru_small_regs(int units) { return (units + 3) / 4; }
+int gru_small_tiles(int units) { return (3 * gru_small_regs(units) + 3) / 4; }
+
+template <int R>
+static hipError_t launch_r(const GruArgs& a, bool from_ring, hipStream_t s) {
+    const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
+    if (tiles == 0) return hipSuccess;
+    if (from_ring) hipLaunchKernelGGL((gru_small_kernel<R, true>), dim3(tiles), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((gru_small_kernel<R, false>), dim3(tiles), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gru_small(const GruArgs& a, bool from_ring, hipStream_t s) {
+    switch (gru_small_regs(a.units)) {
+        case 1: return launch_r<1>(a, from_ring, s);
+        case 2: return launch_r<2>(a, from_ring, s);
+        case 3: return launch_r<3>(a, from_ring, s);
+        case 4: return launch_r<4>(a, from_ring, s);
+        case 5: return launch_r<5>(a, from_ring, s);
+        case 6: return launch_r<6>(a, from_ring, s);
+        case 7: return launch_r<7>(a, from_ring, s);
+        case 8: return launch_r<8>(a, from_ring, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---- small utility kernels ---------------------------------------------------------------
+__global__ void gather_kernel(const GatherArgs a) {
+    // out[s][t][f] = ring row of frame (ke - T + t) of stream s      (Listener.mfccs, oldest first)
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)a.n_streams * a.n_features * a.n_mfcc;
+    if (idx >= total) return;
+    const int f = (int)(idx % a.n_mfcc);
+    const int t = (int)((idx / a.n_mfcc) % a.n_features);
+    const long long s = idx / ((long long)a.n_mfcc * a.n_features);
+    const uint32_t slot = (a.st_ke[s] - (uint32_t)a.n_features + (uint32_t)t) & (uint32_t)(a.ring_slots - 1);
+    const long long tile = s / kTileStreams;
+    const int j = (int)(s % kTileStreams);
+    a.out[idx] = a.ring[(((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kRowFloats + f];
+}
+
+__global__ void clear_kernel(const ClearArgs a) {
+    // one workgroup per stream: zero its counters and every ring row
+    const long long s = blockIdx.x;
+    if (s >= a.n_streams) return;
+    if (a.mask && !a.mask[s]) return;
+    if (threadIdx.x == 0) { a.st_q[s] = 0; a.st_kc[s] = 0u; a.st_ke[s] = 0u; }
+    const long long tile = s / kTileStreams;
+    const int j = (int)(s % kTileStreams);
+    for (int i = threadIdx.x; i < a.ring_slots * kRowFloats; i += blockDim.x) {
+        const int slot = i / kRowFloats, f = i % kRowFloats;
+        a.ring[(((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kRowFloats + f] = 0.0f;
+    }
+}
+
+hipError_t launch_gather(const GatherArgs& a, hipStream_t s) {
+    const long long total = (long long)a.n_streams * a.n_features * a.n_mfcc;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_clear(const ClearArgs& a, hipStream_t s) {
+    if (a.n_streams == 0) return hipSuccess;
+    hipLaunchKernelGGL(clear_kernel, dim3(a.n_streams), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace pe

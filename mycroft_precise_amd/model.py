@@ -1,0 +1,71 @@
+"""
+Network description and weight files: the inference-side counterpart of ``precise.model``
+(/root/reference/precise/model.py:28-91).
+
+The reference builds ``Sequential([GRU(units, activation='linear', name='net'), Dense(1,
+'sigmoid')])`` (model.py:76-82) and stores it as Keras ``.net`` (HDF5) or frozen-graph ``.pb``.
+Neither TensorFlow, Keras nor h5py exist on the target, and the reference ships no model file,
+so this module defines the weights as plain arrays in Keras layout:
+
+    {'gru': [(kernel[F,3H], recurrent_kernel[H,3H], bias[3H]), ...],   gate order z | r | h
+     'dense_kernel': [H,1], 'dense_bias': [1]}
+
+stored as ``<model>.npz`` next to the usual ``<model>.npz.params`` JSON.
+"""
+import numpy as np
+
+from .params import inject_params, pr
+
+
+class ModelParams:
+    """Same fields and defaults as the reference's attrs class (model.py:28-45); only
+    ``recurrent_units`` matters for inference."""
+
+    def __init__(self, recurrent_units=20, dropout=0.2, extra_metrics=False, skip_acc=False,
+                 loss_bias=0.7, freeze_till=0):
+        self.recurrent_units = recurrent_units
+        self.dropout = dropout
+        self.extra_metrics = extra_metrics
+        self.skip_acc = skip_acc
+        self.loss_bias = loss_bias
+        self.freeze_till = freeze_till
+
+
+def save_weights(model_name: str, weights: dict):
+    arrays = {'n_layers': np.int32(len(weights['gru'])),
+              'dense_kernel': np.asarray(weights['dense_kernel'], np.float32),
+              'dense_bias': np.asarray(weights['dense_bias'], np.float32)}
+    for i, (k, rk, b) in enumerate(weights['gru']):
+        arrays['kernel_%d' % i] = np.asarray(k, np.float32)
+        arrays['recurrent_kernel_%d' % i] = np.asarray(rk, np.float32)
+        arrays['bias_%d' % i] = np.asarray(b, np.float32)
+    with open(model_name, 'wb') as f:        # np.savez would append '.npz' to other extensions
+        np.savez(f, **arrays)
+
+
+def load_weights(model_name: str) -> dict:
+    if model_name.endswith('.pb') or model_name.endswith('.net'):
+        raise NotImplementedError(
+            'importing %s needs the frozen-GraphDef / HDF5 reader, which is not built yet; '
+            'convert the weights to .npz (mycroft_precise_amd.model.save_weights)' % model_name)
+    with np.load(model_name, allow_pickle=False) as z:
+        n = int(z['n_layers'])
+        layers = [(z['kernel_%d' % i], z['recurrent_kernel_%d' % i], z['bias_%d' % i]) for i in range(n)]
+        return {'gru': layers, 'dense_kernel': z['dense_kernel'], 'dense_bias': z['dense_bias']}
+
+
+def load_precise_model(model_name: str) -> dict:
+    """Reference name (model.py:48-54): inject the model's params, return its weights."""
+    inject_params(model_name)
+    return load_weights(model_name)
+
+
+def create_model(model_name, params: ModelParams = None, seed: int = 42) -> dict:
+    """Load ``model_name`` if it exists, else a random-init network of the reference's topology
+    for the current ``pr`` (model.py:57-91, forward pass only)."""
+    from os.path import isfile
+    from .synth import make_weights
+    if model_name and isfile(model_name):
+        return load_precise_model(model_name)
+    params = params or ModelParams()
+    return make_weights(n_in=pr.feature_size, units=(params.recurrent_units,), seed=seed)

@@ -1,0 +1,201 @@
+"""
+Audio -> prediction: drop-in for ``precise.network_runner``
+(/root/reference/precise/network_runner.py:31-153) with the arithmetic on an MI355X.
+
+Same surface as the reference -- ``Runner`` (plug-in ABC), ``Listener(model_name, chunk_size=-1,
+runner_cls=None)`` with ``update`` / ``update_vectors`` / ``clear`` / ``find_runner`` and the
+``pr`` / ``mfccs`` / ``window_audio`` / ``runner`` / ``threshold_decoder`` attributes -- plus
+``BatchedListener``, the same thing for B lock-step streams (the natural unit on a GPU).
+
+Where the work happens:
+  * leftover-PCM bookkeeping, framing, MFCC and the [T x F] feature window: ``pe_update*``
+    (mfcc_kernels.hip) -- the state lives in HBM, not in numpy arrays;
+  * the network: ``HipRunner`` -> ``pe_predict`` / fused into ``pe_update`` (gru_kernels.hip);
+  * ``ThresholdDecoder.decode``: host, one float64 per prediction, as in the reference.
+"""
+from abc import ABCMeta, abstractmethod
+from os.path import splitext
+
+import numpy as np
+
+from ._lib import HipEngine
+from .model import load_weights
+from .params import inject_params, pr
+from .threshold_decoder import ThresholdDecoder
+from .util import pcm16_from
+from .vectorization import add_deltas
+
+
+class Runner(metaclass=ABCMeta):
+    """Executes a trained model on vectorized audio (network_runner.py:31-42)."""
+
+    @abstractmethod
+    def predict(self, inputs: np.ndarray) -> np.ndarray:
+        """[N, T, F] -> [N, 1]"""
+
+    @abstractmethod
+    def run(self, inp: np.ndarray) -> float:
+        """[T, F] -> scalar"""
+
+
+def _engine_params(use_delta=None):
+    snap = pr.copy()
+    if use_delta is not None:
+        snap.__dict__['use_delta'] = use_delta
+    return snap
+
+
+class HipRunner(Runner):
+    """The network on the GPU.  ``runner_cls(model_name)`` signature as the reference's runners
+    (network_runner.py:47,79); ``weights`` may be handed over directly instead of a file."""
+
+    def __init__(self, model_name: str = None, weights: dict = None, n_streams: int = 1, device: int = 0,
+                 mfcc_precision: str = 'f64'):
+        if weights is None:
+            weights = load_weights(model_name)
+        self.model_name = model_name
+        self.weights = weights
+        self.engine = HipEngine(_engine_params(), weights, n_streams=n_streams, device=device,
+                                mfcc_precision=mfcc_precision)
+
+    def predict(self, inputs: np.ndarray) -> np.ndarray:
+        return self.engine.predict(inputs)
+
+    def run(self, inp: np.ndarray) -> float:
+        return self.predict(np.asarray(inp)[np.newaxis])[0][0]
+
+
+def _placeholder_weights(n_in):
+    return {'gru': [(np.zeros((n_in, 3), np.float32), np.zeros((1, 3), np.float32), np.zeros(3, np.float32))],
+            'dense_kernel': np.zeros((1, 1), np.float32), 'dense_bias': np.zeros(1, np.float32)}
+
+
+class Listener:
+    """Preprocesses one audio stream into MFCC vectors and executes the network
+    (network_runner.py:98-153)."""
+
+    def __init__(self, model_name: str, chunk_size: int = -1, runner_cls: type = None):
+        self.pr = inject_params(model_name)
+        self.chunk_size = chunk_size
+        runner_cls = runner_cls or self.find_runner(model_name)
+        self.runner = runner_cls(model_name)
+        self.threshold_decoder = ThresholdDecoder(self.pr.threshold_config, pr.threshold_center)
+        self._fused = isinstance(self.runner, HipRunner) and self.runner.engine.n_streams == 1
+        if self._fused:
+            self._engine = self.runner.engine
+        else:       # a foreign Runner plugged into the reference's seam: the GPU still does the MFCC
+            self._engine = HipEngine(_engine_params(use_delta=False), _placeholder_weights(self.pr.n_mfcc))
+        self.window_audio = np.array([])
+        self._mfccs = None
+        self.clear()
+
+    @staticmethod
+    def find_runner(model_name: str):
+        runners = {'.npz': HipRunner, '.net': HipRunner, '.pb': HipRunner}
+        ext = splitext(model_name)[-1]
+        if ext not in runners:
+            raise ValueError('File extension of ' + model_name + ' must be: ' + str(list(runners)))
+        return runners[ext]
+
+    def clear(self):
+        self.window_audio = np.array([])
+        self._engine.clear()
+        self._mfccs = np.zeros((self.pr.n_features, self.pr.n_mfcc))
+
+    @property
+    def mfccs(self) -> np.ndarray:
+        """The [n_features, n_mfcc] feature window (float64 view of the device's float32 ring)."""
+        if self._mfccs is None:
+            self._mfccs = self._engine.get_vectors()[0].astype(np.float64)
+        return self._mfccs
+
+    def _read(self, stream) -> np.ndarray:
+        if isinstance(stream, np.ndarray):
+            return pcm16_from(stream)
+        chunk = stream if isinstance(stream, (bytes, bytearray)) else stream.read(self.chunk_size)
+        if len(chunk) == 0:
+            raise EOFError
+        return pcm16_from(chunk)
+
+    def _track_leftover(self, pcm: np.ndarray):
+        # host mirror of the reference's ``window_audio`` attribute (sample bookkeeping only)
+        self.window_audio = np.concatenate((self.window_audio, pcm.astype(np.float32) / 32768.0))
+        n = len(self.window_audio)
+        if n >= self.pr.window_samples:
+            frames = 1 + (n - self.pr.window_samples) // self.pr.hop_samples
+            self.window_audio = self.window_audio[frames * self.pr.hop_samples:]
+
+    def update_vectors(self, stream) -> np.ndarray:
+        pcm = self._read(stream)
+        if pcm.size == 0:
+            raise EOFError
+        self._track_leftover(pcm)
+        self._mfccs = self._engine.update_vectors(pcm.reshape(1, -1))[0].astype(np.float64)
+        return self._mfccs
+
+    def update_raw(self, stream) -> float:
+        """``update`` without the ThresholdDecoder: the raw network output."""
+        if self._fused and not self.pr.use_delta:
+            pcm = self._read(stream)
+            if pcm.size == 0:
+                raise EOFError
+            self._track_leftover(pcm)
+            self._mfccs = None                     # fetched from the device on demand
+            return float(self._engine.update(pcm.reshape(1, -1))[0])
+        mfccs = self.update_vectors(stream)
+        if self.pr.use_delta:
+            mfccs = add_deltas(mfccs)
+        return self.runner.run(mfccs)
+
+    def update(self, stream) -> float:
+        return float(self.threshold_decoder.decode(self.update_raw(stream)))
+
+
+class BatchedListener:
+    """
+    ``Listener`` for ``n_streams`` independent streams that advance in lock step: every
+    ``update`` takes one equal-sized chunk per stream ([n_streams, chunk_samples] int16, or a list
+    of bytes objects) and returns one prediction per stream.  Stream state never leaves HBM.
+    """
+
+    def __init__(self, model, n_streams: int, device: int = 0, mfcc_precision: str = 'f64', params=None):
+        if isinstance(model, str):
+            self.pr = inject_params(model).copy()
+            weights = load_weights(model)
+        else:
+            self.pr = (params or pr).copy()
+            weights = model
+        self.n_streams = int(n_streams)
+        self.weights = weights
+        self.engine = HipEngine(self.pr, weights, n_streams=self.n_streams, device=device,
+                                mfcc_precision=mfcc_precision)
+        self.threshold_decoder = ThresholdDecoder(self.pr.threshold_config, self.pr.threshold_center)
+
+    def _pcm(self, chunks) -> np.ndarray:
+        if isinstance(chunks, np.ndarray):
+            pcm = chunks
+        else:
+            rows = [pcm16_from(c) for c in chunks]
+            if len({r.size for r in rows}) > 1:
+                raise ValueError('all streams must supply equal-sized chunks')
+            pcm = np.stack(rows) if rows else np.empty((0, 0), dtype='<i2')
+        if pcm.ndim != 2 or pcm.shape[0] != self.n_streams:
+            raise ValueError('expected [%d, chunk_samples] int16, got %r' % (self.n_streams, pcm.shape))
+        if pcm.shape[1] == 0:
+            raise EOFError
+        return pcm
+
+    def clear(self, mask=None):
+        self.engine.clear(mask)
+
+    def update_vectors(self, chunks) -> np.ndarray:
+        """-> [n_streams, n_features, n_mfcc] float32"""
+        return self.engine.update_vectors(self._pcm(chunks))
+
+    def update_raw(self, chunks) -> np.ndarray:
+        """-> raw network outputs float32 [n_streams]"""
+        return self.engine.update(self._pcm(chunks))
+
+    def update(self, chunks) -> np.ndarray:
+        """-> decoded confidences float64 [n_streams]"""
+        return self.threshold_decoder.decode_many(self.update_raw(chunks))
