@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""
+bench.py -- windows/sec of the MI355X wake-word hot path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (pe_update_device: int16 PCM chunk -> MFCC frames -> feature
+window -> GRU -> probability) over one batch of synthetic streams: one 1024-sample chunk for each
+of ``--streams`` (4096) streams per GPU = BASELINE.json configs[1] at N=1 and configs[2] at N=8
+(weak scaling, streams sharded across ranks, no collective on the data path; the per-step
+probabilities of the timed region are all-gathered once at its end, inside the timing).
+The PCM of all W+K steps is resident in HBM before the timed region starts.
+
+Rank 0 prints ONE JSON line: metric/value (whole-job windows/s), ms_per_step, plus
+  "roofline"       GRU kernel vs the dense fp32 MFMA peak (HIP-event time on the launch stream),
+  "roofline_mfcc"  MFCC kernel vs the HBM peak,
+  "cpu_baseline"   the numpy oracle ("port") timed on this box's host cores (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np
+import torch                                   # first: libprecise_engine binds torch's HIP runtime
+import torch.distributed as dist
+
+from mycroft_precise_amd import synth
+from mycroft_precise_amd._lib import HipEngine
+from mycroft_precise_amd.dist import env_world, gather_probabilities
+from mycroft_precise_amd.params import pr
+
+METRIC = 'MFCC+GRU windows/sec (node); max concurrent real-time 16 kHz streams'
+CHUNK = 1024                                   # samples per update (2048-byte chunks, runner.py:48)
+REALTIME_WINDOWS_PER_S = 16000.0 / CHUNK       # 15.625 updates/s keep one stream real-time
+# algorithmic work per window (one update of one stream)
+MFCC_BYTES_PER_WINDOW = 2048 + 1.28 * 13 * 4   # PCM read + fp32 feature rows written = 2114.6 B
+GRU_FLOP_PER_WINDOW = 2 * 29 * (13 * 60 + 20 * 60) + 2 * 20      # 114 880
+HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3                   # dense fp32 matrix peak
+
+
+def synth_pcm_device(n_updates, n_streams, first_stream, device):
+    """Seeded synthetic PCM of the SURVEY 8(d) shape, generated on the device:
+    N(0, 3000^2) + 8000 sin(2 pi f_s t), f_s = 200 + 37 (s mod 97) Hz  ->  int16 [n_updates, B, CHUNK]."""
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 + first_stream)
+    out = torch.empty((n_updates, n_streams, CHUNK), dtype=torch.int16, device=device)
+    sid = torch.arange(first_stream, first_stream + n_streams, device=device, dtype=torch.float64)
+    freq = (200.0 + 37.0 * torch.remainder(sid, 97.0)).view(n_streams, 1)
+    for u in range(n_updates):
+        t = (torch.arange(CHUNK, device=device, dtype=torch.float64) + u * CHUNK).view(1, CHUNK) / 16000.0
+        x = 8000.0 * torch.sin(2.0 * np.pi * freq * t)
+        x = x + 3000.0 * torch.randn((n_streams, CHUNK), generator=g, device=device, dtype=torch.float64)
+        out[u] = torch.clamp(torch.round(x), -32768, 32767).to(torch.int16)
+    return out
+
+
+def _cpu_worker(args):
+    """One host core's share of the cpu_baseline: the numpy oracle on a slice of streams."""
+    first, n_streams, n_updates, seed = args
+    from oracle import listener as oracle_listener          # checker / baseline only
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)                                # one core per worker, no BLAS oversubscription
+    except ImportError:
+        pass
+    weights = synth.make_weights(seed=seed)
+    pcm = synth.batch_pcm(n_streams, n_updates, CHUNK, first_stream=first)
+    oracle = oracle_listener.BatchedOracle(weights, n_streams)
+    t0 = time.perf_counter()
+    for u in range(n_updates):
+        oracle.update_raw(pcm[u])
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(target_seconds=12.0):
+    """Oracle ("port" of the reference's sonopy + Keras arithmetic) on every host core, on a
+    bounded sample of the same workload: each core streams `per_core` streams for `n_updates`
+    updates.  Returns the cpu_baseline JSON object."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    n_updates = 48
+    # calibrate on one core, then size the sample for ~target_seconds of wall time
+    probe = _cpu_worker((0, 16, n_updates, 42))
+    per_window = probe / (16 * n_updates)
+    per_core = int(max(16, min(96, target_seconds / (per_window * n_updates))))
+    jobs = [(c * per_core, per_core, n_updates, 42) for c in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context('fork').Pool(cores) as pool:
+        pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    windows = cores * per_core * n_updates
+    return {'value': windows / wall, 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d streams x %d updates of %d samples (%d windows) in %.1f s, numpy oracle '
+                      '(float64 MFCC + float32 GRU), one process per host core'
+                      % (cores * per_core, n_updates, CHUNK, windows, wall)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=40)
+    ap.add_argument('--streams', type=int, default=4096, help='streams per GPU')
+    ap.add_argument('--mfcc-precision', choices=['f64', 'f32'], default='f64')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--resident-updates', type=int, default=256,
+                    help='distinct PCM chunks kept in HBM per stream (reused cyclically beyond that)')
+    args = ap.parse_args()
+
+    rank, local_rank, world = env_world()
+    # host-core baseline first, before this process owns a GPU context (it forks workers)
+    cpu = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
+                     % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an MI355X (torch.cuda.is_available() is False)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    B = args.streams
+    n_global = B * world
+    steps, warmup = args.steps, args.warmup
+    n_res = min(args.resident_updates, warmup + steps)
+
+    weights = synth.make_weights()
+    engine = HipEngine(pr, weights, n_streams=B, device=local_rank, mfcc_precision=args.mfcc_precision)
+    pcm = synth_pcm_device(n_res, B, rank * B, device)
+    probs = torch.zeros((steps, B), dtype=torch.float32, device=device)
+    scratch = torch.zeros((B,), dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    chunk_bytes = B * CHUNK * 2
+    pcm_base = pcm.data_ptr()
+    probs_base = probs.data_ptr()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def run(first_step, n, out_rows):
+        for i in range(n):
+            u = (first_step + i) % n_res
+            engine.update_device(pcm_base + u * chunk_bytes, CHUNK,
+                                 probs_base + i * B * 4 if out_rows else scratch.data_ptr(), stream)
+
+    # ---- warm-up (fills the 29-row feature windows), untimed --------------------------------
+    run(0, warmup, False)
+    if world > 1:                                # warm the communicator too
+        gather_probabilities(probs[:1], n_global)
+    torch.cuda.synchronize()
+    barrier()
+
+    # ---- timed region: exactly `steps` steps + the final gather of their probabilities -------
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(warmup, steps, True)
+    gathered = gather_probabilities(probs, n_global) if world > 1 else probs
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert gathered.shape[-1] == n_global
+    finite = bool(torch.isfinite(gathered).all().item())
+
+    # ---- instrumented passes: HIP-event time per launch, on the launch stream --------------------
+    def timed_pass(fused):
+        engine.set_fused(fused)
+        engine.set_timing(True)
+        first, second = [], []
+        for i in range(min(steps, 100)):
+            u = (warmup + steps + i) % n_res
+            engine.update_device(pcm_base + u * chunk_bytes, CHUNK, scratch.data_ptr(), stream)
+            a, b = engine.last_timing()
+            first.append(a)
+            second.append(b)
+        engine.set_timing(False)
+        engine.set_fused(True)
+        return float(np.mean(first)), float(np.mean(second))
+
+    fused_ms, _ = timed_pass(True)              # the launch the timed region used: MFCC || GRU roles
+    mfcc_ms, gru_ms = timed_pass(False)         # the two roles as separate dependent launches
+
+    if rank == 0:
+        value = n_global * steps / elapsed
+        def tflops(ms):
+            return GRU_FLOP_PER_WINDOW * B / (ms * 1e-3) / 1e12
+
+        def gbs(ms):
+            return MFCC_BYTES_PER_WINDOW * B / (ms * 1e-3) / 1e9
+
+        mfcc_name = 'double' if args.mfcc_precision == 'f64' else 'float'
+        line = {
+            'metric': METRIC, 'value': value, 'unit': 'windows/s',
+            'n_gpus': world, 'steps': steps, 'warmup': warmup,
+            'ms_per_step': 1e3 * elapsed / steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'stock GRU (default ListenerParams) fp32, batch=%d synthetic 16 kHz '
+                                   'streams per MI355X, one 1024-sample chunk per stream per step' % B,
+                       'streams_per_gpu': B, 'global_streams': n_global, 'chunk_samples': CHUNK,
+                       'gru': 'H=20, T=29, F=13, f32 MFMA 16x16x4', 'mfcc_dtype': args.mfcc_precision,
+                       'parallelism': 'streams sharded over %d rank(s), final all-gather of probabilities' % world},
+            'realtime_streams': value / REALTIME_WINDOWS_PER_S,
+            'outputs_finite': finite,
+            # dominant kernel of the timed region: the fused launch (GRU role is its long pole)
+            'roofline': {'kernel': 'fused_update_kernel<%s,5>' % mfcc_name, 'bound': 'mfma',
+                         'achieved': tflops(fused_ms), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': tflops(fused_ms) / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                         'avg_launch_ms': fused_ms,
+                         'algorithmic': '%d flop/window x %d windows/launch' % (GRU_FLOP_PER_WINDOW, B)},
+            # the two roles launched separately (pe_set_fused(0)), for the per-stage picture
+            'roofline_gru': {'kernel': 'gru_small_kernel<5>', 'bound': 'mfma', 'achieved': tflops(gru_ms),
+                             'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                             'frac': tflops(gru_ms) / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                             'avg_launch_ms': gru_ms},
+            'roofline_mfcc': {'kernel': 'mfcc_stream_kernel<%s>' % mfcc_name, 'bound': 'hbm',
+                              'achieved': gbs(mfcc_ms), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                              'frac': gbs(mfcc_ms) / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': mfcc_ms,
+                              'algorithmic': '%.1f B/window x %d windows/launch' % (MFCC_BYTES_PER_WINDOW, B)},
+        }
+        if cpu is not None:
+            line['cpu_baseline'] = cpu
+        print(json.dumps(line), flush=True)
+
+    engine.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

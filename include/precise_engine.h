@@ -132,8 +132,14 @@ int pe_get_info(const pe_engine* e, pe_info* out);
  * negative inside the dead zone between windows), frames computed / emitted so far (mod 2^32). */
 int pe_get_stream_state(pe_engine* e, int32_t* q_out, uint32_t* computed_out, uint32_t* emitted_out);
 
+/* Kernel sequencing of pe_update*: 1 (default) = when chunk_samples <= window - min(window,
+ * n_fft) -- no frame computed by an update can become visible in the same update -- the MFCC
+ * and network roles run concurrently inside ONE launch; 0 = always two dependent launches. */
+int pe_set_fused(pe_engine* e, int32_t enabled);
+
 /* HIP-event timing of the kernels launched by the last *_device/host update on this engine
- * (milliseconds; measured on the stream the kernels ran on).  Enabled with pe_set_timing(e,1). */
+ * (milliseconds; measured on the stream the kernels ran on).  Enabled with pe_set_timing(e,1).
+ * With a fused launch mfcc_ms is the whole update and gru_ms is 0. */
 int pe_set_timing(pe_engine* e, int32_t enabled);
 int pe_get_last_timing(pe_engine* e, float* mfcc_ms, float* gru_ms);
 

@@ -16,8 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ_DIR = os.path.join(CSRC, 'build')
 LIB_PATH = os.path.join(HERE, 'libprecise_engine.so')
-SOURCES = ['engine.hip', 'mfcc_kernels.hip', 'gru_kernels.hip']
-HEADERS = [os.path.join(CSRC, 'pe_common.h'),
+SOURCES = ['engine.hip', 'kernels.hip']
+HEADERS = [os.path.join(CSRC, 'pe_common.h'), os.path.join(CSRC, 'mfcc_device.h'),
+           os.path.join(CSRC, 'gru_device.h'),
            os.path.join(os.path.dirname(HERE), 'include', 'precise_engine.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 

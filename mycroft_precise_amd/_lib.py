@@ -60,6 +60,7 @@ EXPORTS = {
                                    C.POINTER(C.c_int64)]),
     'pe_get_info': (C.c_int, [C.c_void_p, C.POINTER(PeInfo)]),
     'pe_get_stream_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pe_set_fused': (C.c_int, [C.c_void_p, C.c_int32]),
     'pe_set_timing': (C.c_int, [C.c_void_p, C.c_int32]),
     'pe_get_last_timing': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
@@ -266,6 +267,9 @@ class HipEngine:
         ke = np.empty(self.n_streams, dtype=np.uint32)
         self._check(self._lib.pe_get_stream_state(self._h, q.ctypes.data, kc.ctypes.data, ke.ctypes.data))
         return q, kc, ke
+
+    def set_fused(self, enabled: bool):
+        self._check(self._lib.pe_set_fused(self._h, int(bool(enabled))))
 
     def set_timing(self, enabled: bool):
         self._check(self._lib.pe_set_timing(self._h, int(bool(enabled))))

@@ -38,9 +38,12 @@ struct pe_engine {
     int64_t device_bytes = 0;
     // streaming state
     int16_t* carry = nullptr;
-    int32_t* st_q = nullptr;
-    uint32_t* st_kc = nullptr;
-    uint32_t* st_ke = nullptr;
+    // per-stream counters, ping-pong: [cur] is the state now, [cur ^ 1] receives the next update's
+    int32_t* st_q[2] = {nullptr, nullptr};
+    uint32_t* st_kc[2] = {nullptr, nullptr};
+    uint32_t* st_ke[2] = {nullptr, nullptr};
+    int cur = 0;
+    bool fused = true;      // MFCC || GRU in one launch when the chunk size allows it
     float* ring = nullptr;
     // tables (both precisions share the int tables)
     void* tw256 = nullptr; void* w512 = nullptr; void* mel_w = nullptr; void* dct = nullptr;
@@ -228,21 +231,27 @@ MfccTables<R> tables(const pe_engine* e) {
     return t;
 }
 
+template <class R>
+MfccStreamArgs<R> mfcc_args(const pe_engine* e, const int16_t* pcm_dev, int chunk) {
+    MfccStreamArgs<R> a;
+    a.geo = geom(e);
+    a.tab = tables<R>(e);
+    a.pcm = pcm_dev;
+    a.chunk = chunk;
+    a.pcm_pairs_ok = ((chunk & 1) == 0) && ((reinterpret_cast<uintptr_t>(pcm_dev) & 3u) == 0);
+    a.carry = e->carry;
+    const int c = e->cur, n = e->cur ^ 1;
+    a.st_q = e->st_q[c]; a.st_kc = e->st_kc[c]; a.st_ke = e->st_ke[c];
+    a.st_q_next = e->st_q[n]; a.st_kc_next = e->st_kc[n]; a.st_ke_next = e->st_ke[n];
+    a.ring = e->ring;
+    return a;
+}
+
+// MFCC alone: consumes state[cur], publishes state[cur ^ 1], then flips.
 int launch_mfcc(pe_engine* e, const int16_t* pcm_dev, int chunk, hipStream_t s) {
-    const int pairs_ok = ((chunk & 1) == 0) && ((reinterpret_cast<uintptr_t>(pcm_dev) & 3u) == 0);
-    if (e->prm.mfcc_precision == 0) {
-        MfccStreamArgs<double> a;
-        a.geo = geom(e); a.tab = tables<double>(e);
-        a.pcm = pcm_dev; a.chunk = chunk; a.pcm_pairs_ok = pairs_ok;
-        a.carry = e->carry; a.st_q = e->st_q; a.st_kc = e->st_kc; a.st_ke = e->st_ke; a.ring = e->ring;
-        PE_HIP(e, launch_mfcc_stream_f64(a, s));
-    } else {
-        MfccStreamArgs<float> a;
-        a.geo = geom(e); a.tab = tables<float>(e);
-        a.pcm = pcm_dev; a.chunk = chunk; a.pcm_pairs_ok = pairs_ok;
-        a.carry = e->carry; a.st_q = e->st_q; a.st_kc = e->st_kc; a.st_ke = e->st_ke; a.ring = e->ring;
-        PE_HIP(e, launch_mfcc_stream_f32(a, s));
-    }
+    if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_mfcc_stream_f64(mfcc_args<double>(e, pcm_dev, chunk), s));
+    else PE_HIP(e, launch_mfcc_stream_f32(mfcc_args<float>(e, pcm_dev, chunk), s));
+    e->cur ^= 1;
     return PE_OK;
 }
 
@@ -254,7 +263,12 @@ GruArgs gru_args(const pe_engine* e) {
     a.units = e->units;
     a.wx = e->wx; a.wr1 = e->wr1; a.wr2 = e->wr2; a.bias = e->bias; a.wd = e->wd;
     a.dense_bias = e->dense_bias;
-    a.ring = e->ring; a.st_ke = e->st_ke; a.ring_slots = e->ring_slots;
+    a.ring = e->ring; a.st_ke = e->st_ke[e->cur]; a.ring_slots = e->ring_slots;
+    a.predict_ke = 0;
+    a.st_q = e->st_q[e->cur]; a.st_kc = e->st_kc[e->cur];
+    a.chunk = 0;
+    a.window = e->prm.window_samples; a.hop = e->prm.hop_samples;
+    a.frame_len = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
     a.feats = nullptr; a.out = nullptr;
     return a;
 }
@@ -273,19 +287,37 @@ int check_chunk(pe_engine* e, const void* pcm, int chunk) {
     return PE_OK;
 }
 
+// True when no frame computed by an update of `chunk` samples can become visible in that same
+// update (it needs window - frame_len more samples), so the network does not depend on it.
+bool can_fuse(const pe_engine* e, int chunk) {
+    const int flen = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
+    return e->fused && chunk <= e->prm.window_samples - flen;
+}
+
 int do_update(pe_engine* e, const int16_t* pcm_dev, int chunk, float* raw_out_dev, float* feats_out_dev,
               hipStream_t s) {
     int rc;
     const bool t = e->timing;
     if (t) { PE_HIP(e, hipEventRecord(e->ev[0], s)); }
-    if ((rc = launch_mfcc(e, pcm_dev, chunk, s))) return rc;
-    if (t) { PE_HIP(e, hipEventRecord(e->ev[1], s)); }
-    if (raw_out_dev) {
-        if ((rc = launch_gru_ring(e, raw_out_dev, s))) return rc;
+    if (raw_out_dev && can_fuse(e, chunk)) {
+        GruArgs g = gru_args(e);             // state BEFORE the update; the waves predict ke
+        g.predict_ke = 1;
+        g.chunk = chunk;
+        g.out = raw_out_dev;
+        if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_fused_f64(mfcc_args<double>(e, pcm_dev, chunk), g, s));
+        else PE_HIP(e, launch_fused_f32(mfcc_args<float>(e, pcm_dev, chunk), g, s));
+        e->cur ^= 1;
+        if (t) { PE_HIP(e, hipEventRecord(e->ev[1], s)); PE_HIP(e, hipEventRecord(e->ev[2], s)); e->ev_valid = true; e->ev_has_gru = false; }
+    } else {
+        if ((rc = launch_mfcc(e, pcm_dev, chunk, s))) return rc;
+        if (t) { PE_HIP(e, hipEventRecord(e->ev[1], s)); }
+        if (raw_out_dev) {
+            if ((rc = launch_gru_ring(e, raw_out_dev, s))) return rc;
+        }
+        if (t) { PE_HIP(e, hipEventRecord(e->ev[2], s)); e->ev_valid = true; e->ev_has_gru = raw_out_dev != nullptr; }
     }
-    if (t) { PE_HIP(e, hipEventRecord(e->ev[2], s)); e->ev_valid = true; e->ev_has_gru = raw_out_dev != nullptr; }
     if (feats_out_dev) {
-        GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->ring, e->st_ke, feats_out_dev};
+        GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->ring, e->st_ke[e->cur], feats_out_dev};
         PE_HIP(e, launch_gather(g, s));
     }
     return PE_OK;
@@ -330,15 +362,20 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     e->units = L.units; e->n_in = L.n_in; e->n_layers = 1;
     e->dense_bias = w->dense_bias;
     const int flen = p->window_samples < kNfft ? p->window_samples : kNfft;
-    const int pending = (p->window_samples - flen + p->hop_samples - 1) / p->hop_samples + 1;
-    e->ring_slots = next_pow2(p->n_features + pending + 1);
+    // frames computed (first flen samples arrived) but not yet emitted (whole window arrived):
+    // at most ceil((window - flen) / hop) of them exist at any time; T + that many rows are live
+    const int pending = (p->window_samples - flen + p->hop_samples - 1) / p->hop_samples;
+    e->ring_slots = next_pow2(p->n_features + pending);
 
     int rc = PE_OK;
     do {
         if ((rc = dev_alloc(e, &e->carry, (size_t)e->n_padded * kCarryCap))) break;
-        if ((rc = dev_alloc(e, &e->st_q, (size_t)e->n_padded))) break;
-        if ((rc = dev_alloc(e, &e->st_kc, (size_t)e->n_padded))) break;
-        if ((rc = dev_alloc(e, &e->st_ke, (size_t)e->n_padded))) break;
+        for (int b = 0; b < 2 && !rc; ++b) {
+            if ((rc = dev_alloc(e, &e->st_q[b], (size_t)e->n_padded))) break;
+            if ((rc = dev_alloc(e, &e->st_kc[b], (size_t)e->n_padded))) break;
+            if ((rc = dev_alloc(e, &e->st_ke[b], (size_t)e->n_padded))) break;
+        }
+        if (rc) break;
         if ((rc = dev_alloc(e, &e->ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kRowFloats))) break;
         rc = (p->mfcc_precision == 0) ? build_tables<double>(e, mel_filters) : build_tables<float>(e, mel_filters);
         if (rc) break;
@@ -382,7 +419,7 @@ int pe_clear(pe_engine* e, const uint8_t* mask_host) {
         PE_HIP(e, hipMemcpy(e->st_mask.p, mask_host, (size_t)e->n_streams, hipMemcpyHostToDevice));
         mask_dev = static_cast<const uint8_t*>(e->st_mask.p);
     }
-    ClearArgs a{e->n_padded, e->ring_slots, mask_dev, e->st_q, e->st_kc, e->st_ke, e->ring};
+    ClearArgs a{e->n_padded, e->ring_slots, mask_dev, e->st_q[e->cur], e->st_kc[e->cur], e->st_ke[e->cur], e->ring};
     if (mask_dev) a.n_streams = e->n_streams;
     PE_HIP(e, launch_clear(a, nullptr));
     PE_HIP(e, hipStreamSynchronize(nullptr));
@@ -443,7 +480,7 @@ int pe_get_vectors(pe_engine* e, float* feats_out_host) {
     int rc;
     const size_t feat_bytes = (size_t)e->n_streams * e->prm.n_features * e->prm.n_mfcc * sizeof(float);
     if ((rc = ensure(e, e->st_feats, feat_bytes))) return rc;
-    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->ring, e->st_ke, static_cast<float*>(e->st_feats.p)};
+    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->ring, e->st_ke[e->cur], static_cast<float*>(e->st_feats.p)};
     PE_HIP(e, launch_gather(g, nullptr));
     PE_HIP(e, hipMemcpy(feats_out_host, e->st_feats.p, feat_bytes, hipMemcpyDeviceToHost));
     return PE_OK;
@@ -521,9 +558,15 @@ int pe_get_stream_state(pe_engine* e, int32_t* q_out, uint32_t* computed_out, ui
     PE_HIP(e, hipSetDevice(e->device));
     PE_HIP(e, hipDeviceSynchronize());
     const size_t n = (size_t)e->n_streams;
-    if (q_out) PE_HIP(e, hipMemcpy(q_out, e->st_q, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (computed_out) PE_HIP(e, hipMemcpy(computed_out, e->st_kc, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (emitted_out) PE_HIP(e, hipMemcpy(emitted_out, e->st_ke, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (q_out) PE_HIP(e, hipMemcpy(q_out, e->st_q[e->cur], n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (computed_out) PE_HIP(e, hipMemcpy(computed_out, e->st_kc[e->cur], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (emitted_out) PE_HIP(e, hipMemcpy(emitted_out, e->st_ke[e->cur], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return PE_OK;
+}
+
+int pe_set_fused(pe_engine* e, int32_t enabled) {
+    if (!e) return PE_ERR_INVALID;
+    e->fused = enabled != 0;
     return PE_OK;
 }
 
@@ -541,7 +584,7 @@ int pe_get_last_timing(pe_engine* e, float* mfcc_ms, float* gru_ms) {
     float a = 0.f, b = 0.f;
     PE_HIP(e, hipEventElapsedTime(&a, e->ev[0], e->ev[1]));
     PE_HIP(e, hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
-    if (mfcc_ms) *mfcc_ms = a;
+    if (mfcc_ms) *mfcc_ms = a;      // fused launch: the whole update; else the MFCC kernel
     if (gru_ms) *gru_ms = e->ev_has_gru ? b : 0.f;
     return PE_OK;
 }

@@ -22,6 +22,7 @@
 //   * the feature ring is stored [tile][slot][stream][16 floats], so lane (g, j) fetches features
 //     4g..4g+3 of stream j with one 16-byte load and the wave reads 1 KiB contiguous per timestep
 //     (k-step kk of the input projection <-> feature 4g + kk).
+#pragma once
 #include "pe_common.h"
 
 namespace pe {
@@ -46,12 +47,11 @@ template <int R> struct GruShape {
     static constexpr int NP2 = NT - P2_BEGIN;
 };
 
+// One wave = one tile of 16 streams, whole window, weights resident in registers.
 template <int R, bool FROM_RING>
-__global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
+__device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const int lane) {
     using G = GruShape<R>;
-    const int lane = threadIdx.x;
     const int g = lane >> 4, j = lane & 15;
-    const int tile = blockIdx.x;
     const long long stream = (long long)tile * kTileStreams + j;
     const bool valid = stream < a.n_streams;
     const int T = a.n_features;
@@ -82,7 +82,18 @@ __global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
     uint32_t first = 0;           // ring: frame index of timestep 0
     const uint32_t mask = (uint32_t)(a.ring_slots - 1);
     if (FROM_RING) {
-        const uint32_t ke = valid ? a.st_ke[stream] : 0u;
+        uint32_t ke = valid ? a.st_ke[stream] : 0u;
+        if (a.predict_ke && valid) {
+            // running beside the MFCC role of the same update: derive the emitted-frame count this
+            // update will produce from the state before it (same arithmetic as mfcc_stream_tile)
+            const int q = a.st_q[stream];
+            const uint32_t kc = a.st_kc[stream];
+            const int avail = q + a.chunk;
+            const int nnew = avail >= a.frame_len ? 1 + (avail - a.frame_len) / a.hop : 0;
+            const int qn = avail - nnew * a.hop;
+            const int m = qn + a.hop * (int)(kc + (uint32_t)nnew - ke);
+            if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
+        }
         first = ke - (uint32_t)T;
         xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats + 4 * g;
     } else {
@@ -154,74 +165,6 @@ __global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
         const float logit = part + a.dense_bias;
         a.out[stream] = 1.0f / (1.0f + expf(-logit));
     }
-}
-
-int gru_small_regs(int units) { return (units + 3) / 4; }
-int gru_small_tiles(int units) { return (3 * gru_small_regs(units) + 3) / 4; }
-
-template <int R>
-static hipError_t launch_r(const GruArgs& a, bool from_ring, hipStream_t s) {
-    const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
-    if (tiles == 0) return hipSuccess;
-    if (from_ring) hipLaunchKernelGGL((gru_small_kernel<R, true>), dim3(tiles), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((gru_small_kernel<R, false>), dim3(tiles), dim3(64), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_gru_small(const GruArgs& a, bool from_ring, hipStream_t s) {
-    switch (gru_small_regs(a.units)) {
-        case 1: return launch_r<1>(a, from_ring, s);
-        case 2: return launch_r<2>(a, from_ring, s);
-        case 3: return launch_r<3>(a, from_ring, s);
-        case 4: return launch_r<4>(a, from_ring, s);
-        case 5: return launch_r<5>(a, from_ring, s);
-        case 6: return launch_r<6>(a, from_ring, s);
-        case 7: return launch_r<7>(a, from_ring, s);
-        case 8: return launch_r<8>(a, from_ring, s);
-        default: return hipErrorInvalidValue;
-    }
-}
-
-// ---- small utility kernels ---------------------------------------------------------------
-__global__ void gather_kernel(const GatherArgs a) {
-    // out[s][t][f] = ring row of frame (ke - T + t) of stream s      (Listener.mfccs, oldest first)
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)a.n_streams * a.n_features * a.n_mfcc;
-    if (idx >= total) return;
-    const int f = (int)(idx % a.n_mfcc);
-    const int t = (int)((idx / a.n_mfcc) % a.n_features);
-    const long long s = idx / ((long long)a.n_mfcc * a.n_features);
-    const uint32_t slot = (a.st_ke[s] - (uint32_t)a.n_features + (uint32_t)t) & (uint32_t)(a.ring_slots - 1);
-    const long long tile = s / kTileStreams;
-    const int j = (int)(s % kTileStreams);
-    a.out[idx] = a.ring[(((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kRowFloats + f];
-}
-
-__global__ void clear_kernel(const ClearArgs a) {
-    // one workgroup per stream: zero its counters and every ring row
-    const long long s = blockIdx.x;
-    if (s >= a.n_streams) return;
-    if (a.mask && !a.mask[s]) return;
-    if (threadIdx.x == 0) { a.st_q[s] = 0; a.st_kc[s] = 0u; a.st_ke[s] = 0u; }
-    const long long tile = s / kTileStreams;
-    const int j = (int)(s % kTileStreams);
-    for (int i = threadIdx.x; i < a.ring_slots * kRowFloats; i += blockDim.x) {
-        const int slot = i / kRowFloats, f = i % kRowFloats;
-        a.ring[(((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kRowFloats + f] = 0.0f;
-    }
-}
-
-hipError_t launch_gather(const GatherArgs& a, hipStream_t s) {
-    const long long total = (long long)a.n_streams * a.n_features * a.n_mfcc;
-    if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_clear(const ClearArgs& a, hipStream_t s) {
-    if (a.n_streams == 0) return hipSuccess;
-    hipLaunchKernelGGL(clear_kernel, dim3(a.n_streams), dim3(64), 0, s, a);
-    return hipGetLastError();
 }
 
 }  // namespace pe

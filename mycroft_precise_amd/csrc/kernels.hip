@@ -1,0 +1,165 @@
+// Every __global__ entry point of libprecise_engine.so and its launcher.  The device code lives
+// in mfcc_device.h (MFCC front end) and gru_device.h (GRU + Dense on the f32 matrix cores).
+#include "mfcc_device.h"
+#include "gru_device.h"
+
+namespace pe {
+
+// ---- MFCC, streaming: one workgroup per 16-stream tile ---------------------------------------
+template <class R>
+__global__ __launch_bounds__(256) void mfcc_stream_kernel(const MfccStreamArgs<R> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    mfcc_stream_tile<R>(a, blockIdx.x, smem);
+}
+
+template <class R>
+__global__ __launch_bounds__(256) void mfcc_offline_kernel(const MfccOfflineArgs<R> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    mfcc_offline_block<R>(a, smem);
+}
+
+// ---- GRU: one wave per 16-stream tile ----------------------------------------------------------
+template <int R, bool FROM_RING>
+__global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
+    gru_tile<R, FROM_RING>(a, blockIdx.x, threadIdx.x);
+}
+
+// ---- fused update: GRU role || MFCC role in ONE launch ------------------------------------------
+// Workgroups [0, n_gru_blocks) run the network (4 waves = 4 tiles each) on the feature windows as
+// they will stand after this update; workgroups [n_gru_blocks, n_gru_blocks + n_tiles) compute this
+// update's MFCC frames.  The GRU workgroups are dispatched first: they are the long pole.
+template <class R, int RG>
+__global__ __launch_bounds__(256) void fused_update_kernel(const MfccStreamArgs<R> m, const GruArgs g,
+                                                           const int n_gru_blocks, const int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    if (b < n_gru_blocks) {
+        const int tile = b * 4 + (threadIdx.x >> 6);
+        if (tile < n_tiles) gru_tile<RG, true>(g, tile, threadIdx.x & 63);
+    } else {
+        mfcc_stream_tile<R>(m, b - n_gru_blocks, smem);
+    }
+}
+
+size_t mfcc_lds_bytes(int real_size, int n_filt, int n_mfcc, int mel_nnz) {
+    return lds_layout_bytes(real_size, n_filt, n_mfcc, mel_nnz);
+}
+
+template <class R>
+static hipError_t launch_stream(const MfccStreamArgs<R>& a, hipStream_t s) {
+    const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
+    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc, a.tab.mel_nnz);
+    hipLaunchKernelGGL(mfcc_stream_kernel<R>, dim3(tiles), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <class R>
+static hipError_t launch_offline(const MfccOfflineArgs<R>& a, hipStream_t s) {
+    if (a.n_frames <= 0) return hipSuccess;
+    const long long blocks = (a.n_frames + 15) / 16;
+    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc, a.tab.mel_nnz);
+    hipLaunchKernelGGL(mfcc_offline_kernel<R>, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mfcc_stream_f64(const MfccStreamArgs<double>& a, hipStream_t s) { return launch_stream<double>(a, s); }
+hipError_t launch_mfcc_stream_f32(const MfccStreamArgs<float>& a, hipStream_t s) { return launch_stream<float>(a, s); }
+hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, hipStream_t s) { return launch_offline<double>(a, s); }
+hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, hipStream_t s) { return launch_offline<float>(a, s); }
+
+int gru_small_regs(int units) { return (units + 3) / 4; }
+int gru_small_tiles(int units) { return (3 * gru_small_regs(units) + 3) / 4; }
+
+template <int R>
+static hipError_t launch_r(const GruArgs& a, bool from_ring, hipStream_t s) {
+    const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
+    if (tiles == 0) return hipSuccess;
+    if (from_ring) hipLaunchKernelGGL((gru_small_kernel<R, true>), dim3(tiles), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((gru_small_kernel<R, false>), dim3(tiles), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gru_small(const GruArgs& a, bool from_ring, hipStream_t s) {
+    switch (gru_small_regs(a.units)) {
+        case 1: return launch_r<1>(a, from_ring, s);
+        case 2: return launch_r<2>(a, from_ring, s);
+        case 3: return launch_r<3>(a, from_ring, s);
+        case 4: return launch_r<4>(a, from_ring, s);
+        case 5: return launch_r<5>(a, from_ring, s);
+        case 6: return launch_r<6>(a, from_ring, s);
+        case 7: return launch_r<7>(a, from_ring, s);
+        case 8: return launch_r<8>(a, from_ring, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <class R, int RG>
+static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const GruArgs& g, hipStream_t s) {
+    const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
+    const int gru_blocks = (tiles + 3) / 4;
+    const size_t lds = lds_layout_bytes(sizeof(R), m.geo.n_filt, m.geo.n_mfcc, m.tab.mel_nnz);
+    hipLaunchKernelGGL((fused_update_kernel<R, RG>), dim3(gru_blocks + tiles), dim3(256), lds, s, m, g, gru_blocks, tiles);
+    return hipGetLastError();
+}
+
+template <class R>
+static hipError_t launch_fused(const MfccStreamArgs<R>& m, const GruArgs& g, hipStream_t s) {
+    switch (gru_small_regs(g.units)) {
+        case 1: return launch_fused_rg<R, 1>(m, g, s);
+        case 2: return launch_fused_rg<R, 2>(m, g, s);
+        case 3: return launch_fused_rg<R, 3>(m, g, s);
+        case 4: return launch_fused_rg<R, 4>(m, g, s);
+        case 5: return launch_fused_rg<R, 5>(m, g, s);
+        case 6: return launch_fused_rg<R, 6>(m, g, s);
+        case 7: return launch_fused_rg<R, 7>(m, g, s);
+        case 8: return launch_fused_rg<R, 8>(m, g, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const GruArgs& g, hipStream_t s) { return launch_fused<double>(m, g, s); }
+hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const GruArgs& g, hipStream_t s) { return launch_fused<float>(m, g, s); }
+
+// ---- small utility kernels ---------------------------------------------------------------------
+__global__ void gather_kernel(const GatherArgs a) {
+    // out[s][t][f] = ring row of frame (ke - T + t) of stream s      (Listener.mfccs, oldest first)
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)a.n_streams * a.n_features * a.n_mfcc;
+    if (idx >= total) return;
+    const int f = (int)(idx % a.n_mfcc);
+    const int t = (int)((idx / a.n_mfcc) % a.n_features);
+    const long long s = idx / ((long long)a.n_mfcc * a.n_features);
+    const uint32_t slot = (a.st_ke[s] - (uint32_t)a.n_features + (uint32_t)t) & (uint32_t)(a.ring_slots - 1);
+    const long long tile = s / kTileStreams;
+    const int j = (int)(s % kTileStreams);
+    a.out[idx] = a.ring[(((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kRowFloats + f];
+}
+
+__global__ void clear_kernel(const ClearArgs a) {
+    // one workgroup per stream: zero its counters and every ring row
+    const long long s = blockIdx.x;
+    if (s >= a.n_streams) return;
+    if (a.mask && !a.mask[s]) return;
+    if (threadIdx.x == 0) { a.st_q[s] = 0; a.st_kc[s] = 0u; a.st_ke[s] = 0u; }
+    const long long tile = s / kTileStreams;
+    const int j = (int)(s % kTileStreams);
+    for (int i = threadIdx.x; i < a.ring_slots * kRowFloats; i += blockDim.x) {
+        const int slot = i / kRowFloats, f = i % kRowFloats;
+        a.ring[(((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kRowFloats + f] = 0.0f;
+    }
+}
+
+hipError_t launch_gather(const GatherArgs& a, hipStream_t s) {
+    const long long total = (long long)a.n_streams * a.n_features * a.n_mfcc;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_clear(const ClearArgs& a, hipStream_t s) {
+    if (a.n_streams == 0) return hipSuccess;
+    hipLaunchKernelGGL(clear_kernel, dim3(a.n_streams), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace pe

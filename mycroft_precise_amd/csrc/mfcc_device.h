@@ -20,6 +20,7 @@
 //     that straddles two chunks are carried in HBM, and the 36 % of every window that the crop
 //     makes dead is never read;
 //   * arithmetic type R is double (what the reference computes in) or float.
+#pragma once
 #include "pe_common.h"
 
 namespace pe {
@@ -134,10 +135,6 @@ __host__ __device__ inline size_t lds_layout_bytes(int real_size, int n_filt, in
     b += ((size_t)(2 * n_filt + 1) * sizeof(int) + 15) & ~(size_t)15;
     b += (size_t)16 * kGroupScratch * real_size;    // 16 groups per workgroup
     return b;
-}
-
-size_t mfcc_lds_bytes(int real_size, int n_filt, int n_mfcc, int mel_nnz) {
-    return lds_layout_bytes(real_size, n_filt, n_mfcc, mel_nnz);
 }
 
 template <class R>
@@ -285,9 +282,11 @@ struct PcmView {
     }
 };
 
+// One workgroup (256 threads) = one tile of 16 streams.  Reads the stream state of this update
+// (st_*), writes the state after it (st_*_next): the two may alias only when no other role reads
+// the old state concurrently.
 template <class R>
-__global__ __launch_bounds__(256) void mfcc_stream_kernel(const MfccStreamArgs<R> a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, const int tile, unsigned char* smem) {
     using K = RealK<R>;
     const StreamGeom& geo = a.geo;
     LdsTab<R> tab;
@@ -296,7 +295,7 @@ __global__ __launch_bounds__(256) void mfcc_stream_kernel(const MfccStreamArgs<R
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, r = lane & 15;
     const int j = wave * 4 + grp;                           // stream within the tile
-    const long long s = (long long)blockIdx.x * kTileStreams + j;
+    const long long s = (long long)tile * kTileStreams + j;
     if (s >= geo.n_streams) return;
     R* S = scratch + (wave * 4 + grp) * kGroupScratch;
 
@@ -314,7 +313,7 @@ __global__ __launch_bounds__(256) void mfcc_stream_kernel(const MfccStreamArgs<R
     pv.pairs = a.pcm_pairs_ok && ((q & 1) == 0);
 
     const int slots = geo.ring_slots;
-    float* ring_rows = a.ring + ((size_t)blockIdx.x * slots * kTileStreams + j) * kRowFloats;
+    float* ring_rows = a.ring + ((size_t)tile * slots * kTileStreams + j) * kRowFloats;
 
     for (int f = 0; f < nnew; ++f) {
         if (nnew - f > slots) continue;                      // would be overwritten before anyone reads it
@@ -358,16 +357,15 @@ __global__ __launch_bounds__(256) void mfcc_stream_kernel(const MfccStreamArgs<R
         // Listener.update_vectors only vectorizes when len(window_audio) >= window_samples
         const int m = qn + hop * (int)(kcn - ke);
         if (m >= geo.window) ke += 1u + (uint32_t)((m - geo.window) / hop);
-        a.st_q[s] = qn;
-        a.st_kc[s] = kcn;
-        a.st_ke[s] = ke;
+        a.st_q_next[s] = qn;
+        a.st_kc_next[s] = kcn;
+        a.st_ke_next[s] = ke;
     }
 }
 
-// ---- stateless whole-buffer kernel (vectorize_raw) ------------------------------------------
+// ---- stateless whole-buffer form (vectorize_raw) ----------------------------------------------
 template <class R>
-__global__ __launch_bounds__(256) void mfcc_offline_kernel(const MfccOfflineArgs<R> a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void mfcc_offline_block(const MfccOfflineArgs<R>& a, unsigned char* smem) {
     const StreamGeom& geo = a.geo;
     LdsTab<R> tab;
     R* scratch = lds_setup<R>(smem, a.tab, geo.n_filt, geo.n_mfcc, tab);
@@ -386,27 +384,5 @@ __global__ __launch_bounds__(256) void mfcc_offline_kernel(const MfccOfflineArgs
     const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load);
     if (r < geo.n_mfcc) a.out[fr * geo.n_mfcc + r] = (double)coeff;
 }
-
-template <class R>
-static hipError_t launch_stream(const MfccStreamArgs<R>& a, hipStream_t s) {
-    const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
-    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc, a.tab.mel_nnz);
-    hipLaunchKernelGGL(mfcc_stream_kernel<R>, dim3(tiles), dim3(256), lds, s, a);
-    return hipGetLastError();
-}
-
-template <class R>
-static hipError_t launch_offline(const MfccOfflineArgs<R>& a, hipStream_t s) {
-    if (a.n_frames <= 0) return hipSuccess;
-    const long long blocks = (a.n_frames + 15) / 16;
-    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc, a.tab.mel_nnz);
-    hipLaunchKernelGGL(mfcc_offline_kernel<R>, dim3((unsigned)blocks), dim3(256), lds, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_mfcc_stream_f64(const MfccStreamArgs<double>& a, hipStream_t s) { return launch_stream<double>(a, s); }
-hipError_t launch_mfcc_stream_f32(const MfccStreamArgs<float>& a, hipStream_t s) { return launch_stream<float>(a, s); }
-hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, hipStream_t s) { return launch_offline<double>(a, s); }
-hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, hipStream_t s) { return launch_offline<float>(a, s); }
 
 }  // namespace pe

@@ -50,9 +50,15 @@ struct MfccStreamArgs {
     int chunk;
     int pcm_pairs_ok;       // chunk even and pcm 4-byte aligned: int16 pairs may be loaded as one dword
     int16_t* carry;         // [n_streams_padded][kCarryCap]
-    int32_t* st_q;          // samples held toward the next frame to compute (may be < 0)
-    uint32_t* st_kc;        // frames computed so far (mod 2^32)
-    uint32_t* st_ke;        // frames emitted so far, i.e. visible to the network (mod 2^32)
+    // stream state BEFORE this update (read) ...
+    const int32_t* st_q;    // samples held toward the next frame to compute (may be < 0)
+    const uint32_t* st_kc;  // frames computed so far (mod 2^32)
+    const uint32_t* st_ke;  // frames emitted so far, i.e. visible to the network (mod 2^32)
+    // ... and AFTER it (written).  Ping-pong buffers: the GRU role of a fused launch reads the
+    // old state while MFCC workgroups are already publishing the new one.
+    int32_t* st_q_next;
+    uint32_t* st_kc_next;
+    uint32_t* st_ke_next;
     float* ring;            // [n_tiles][ring_slots][16 streams][16 floats]
 };
 
@@ -85,6 +91,12 @@ struct GruArgs {
     const float* ring;
     const uint32_t* st_ke;
     int ring_slots;
+    // predict_ke != 0: st_q/st_kc/st_ke hold the state BEFORE the update whose chunk is `chunk`
+    // samples; the wave derives the post-update emitted count itself (fused MFCC || GRU launch)
+    int predict_ke;
+    const int32_t* st_q;
+    const uint32_t* st_kc;
+    int chunk, window, hop, frame_len;
     // ... or an explicit [n][T][F] float32 batch (Runner.predict)
     const float* feats;
     float* out;             // [n_streams]
@@ -104,9 +116,14 @@ struct ClearArgs {
     float* ring;
 };
 
-// launchers implemented in the kernel translation units
+// launchers implemented in kernels.hip
 hipError_t launch_mfcc_stream_f64(const MfccStreamArgs<double>& a, hipStream_t s);
 hipError_t launch_mfcc_stream_f32(const MfccStreamArgs<float>& a, hipStream_t s);
+// one launch, two roles: GRU waves read the feature windows as they will be after this update
+// while MFCC workgroups compute this update's frames (legal when chunk <= window - frame_len:
+// no frame computed now becomes visible now)
+hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const GruArgs& g, hipStream_t s);
+hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const GruArgs& g, hipStream_t s);
 hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, hipStream_t s);
 hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, hipStream_t s);
 size_t mfcc_lds_bytes(int real_size, int n_filt, int n_mfcc, int mel_nnz);

@@ -22,6 +22,7 @@ sys.dont_write_bytecode = True          # never write __pycache__ into /root/ref
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, '/root/reference')
+sys.path.insert(0, '/root/reference/runner')
 
 import warnings
 import numpy as np
@@ -37,6 +38,7 @@ from precise.threshold_decoder import ThresholdDecoder     # noqa: E402
 from precise.vectorization import vectorize, vectorize_raw, add_deltas   # noqa: E402
 from precise.util import buffer_to_audio                   # noqa: E402
 from precise.params import pr                              # noqa: E402
+from precise_runner.runner import TriggerDetector, ReadWriteStream   # noqa: E402  (reference code)
 
 OUT = os.path.join(REPO, 'tests', 'golden')
 
@@ -141,6 +143,34 @@ def main():
         td['min_out_' + name] = d.min_out
         td['out_range_' + name] = d.out_range
     np.savez_compressed(os.path.join(OUT, 'threshold_decoder.npz'), grid=grid, thr=thr, **td)
+
+    # --- precise_runner TriggerDetector / ReadWriteStream (runner/precise_runner/runner.py:76-142) ----
+    rng = np.random.default_rng(7)
+    tr = {}
+    for name, chunk_size, sens, level in (('default', 2048, 0.5, 3), ('small', 1024, 0.8, 1),
+                                          ('big', 8192, 0.2, 5), ('lvl0', 4096, 0.5, 0)):
+        # bursts of high probability separated by lulls, plus noise
+        probs = np.clip(rng.random(400) * 0.6 + (np.sin(np.arange(400) / 7.0) > 0.3) * 0.5, 0, 1)
+        det = TriggerDetector(chunk_size, sens, level)
+        fired, act = [], []
+        for p_ in probs:
+            fired.append(det.update(float(p_)))
+            act.append(det.activation)
+        tr['probs_' + name] = probs
+        tr['cfg_' + name] = np.array([chunk_size, sens, level], dtype=np.float64)
+        tr['fired_' + name] = np.array(fired, dtype=np.bool_)
+        tr['activation_' + name] = np.array(act, dtype=np.int64)
+    # every read carries a timeout: the reference's read() blocks forever when a chop leaves
+    # fewer bytes than requested
+    s = ReadWriteStream(b'0123456789abcde', chop_samples=10)      # 15 % 10 = 5 bytes survive the chop
+    s.write(b'FGHIJKLM')                                           # 23 % 10 = 3 survive
+    tr['rws_chop_read'] = np.frombuffer(s.read(2, timeout=0.2), dtype=np.uint8)
+    tr['rws_chop_left'] = np.frombuffer(s.read(1, timeout=0.2), dtype=np.uint8)
+    tr['rws_chop_short'] = np.frombuffer(s.read(5, timeout=0.05), dtype=np.uint8)   # times out -> b''
+    s = ReadWriteStream(b'0123456789abcdef', chop_samples=8)      # len % chop == 0: nothing is dropped
+    tr['rws_nochop_read'] = np.frombuffer(s.read(3, timeout=0.2), dtype=np.uint8)
+    tr['rws_nochop_len'] = len(s)
+    np.savez_compressed(os.path.join(OUT, 'precise_runner.npz'), **tr)
 
     # --- weights used by every fixture -----------------------------------------------------
     k, rk, b = weights['gru'][0]

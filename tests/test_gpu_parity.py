@@ -1,0 +1,312 @@
+"""
+-m gpu: parity of the HIP path (through the C ABI) with
+  (1) the golden fixtures produced by the reference's own Listener / vectorize code, and
+  (2) the oracle (oracle/, the checker) on seeded synthetic inputs,
+plus size-independent properties at BASELINE.json's full batch size.
+
+Tolerances (north_star): raw probability within 1e-4 (fp32 network); the float64 MFCC front end
+is compared at 1e-9 in float64 (offline path) and at float32 rounding (2e-5 abs on features of
+magnitude <= 40) where it is read back from the float32 feature ring.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import golden, REPO
+from mycroft_precise_amd import synth
+from mycroft_precise_amd import params as P
+from oracle import listener as ol, keras_gru
+
+pytestmark = pytest.mark.gpu
+
+TOL_RAW = 1e-4          # north_star bar
+GUARD_RAW = 2e-5        # regression guard: what the kernels actually achieve, with margin
+TOL_FEAT32 = 2e-5       # float32 rounding of |feature| <= 40
+TOL_DECODE = 2e-3       # one LUT bin of ThresholdDecoder (step function of logit(raw))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from mycroft_precise_amd import _lib
+    return _lib
+
+
+@pytest.fixture()
+def model_file(tmp_path, stock_weights):
+    from mycroft_precise_amd.model import save_weights
+    path = str(tmp_path / 'synthetic.npz')
+    save_weights(path, stock_weights)
+    return path
+
+
+# ---- golden fixtures from the reference's own code -------------------------------------------------
+def test_listener_matches_reference_listener_chunk2048(model_file):
+    """Drop-in Listener(model).update(bytes) vs the reference's Listener on the same PCM."""
+    from mycroft_precise_amd.network_runner import Listener
+    g = golden('listener_chunk2048.npz')
+    for i in range(len(g['streams'])):
+        lis = Listener(model_file, 2048)
+        data = g['pcm'][i].tobytes()
+        worst_raw = worst_dec = 0.0
+        for u, off in enumerate(range(0, len(data), 2048)):
+            raw = lis.update_raw(data[off:off + 2048])
+            worst_raw = max(worst_raw, abs(raw - float(g['raw'][i][u])))
+            dec = lis.threshold_decoder.decode(raw)
+            worst_dec = max(worst_dec, abs(dec - float(g['decoded'][i][u])))
+            assert len(lis.window_audio) == g['leftover'][i][u]
+            if u == 7:
+                assert np.abs(lis.mfccs - g['ring_u7'][i]).max() <= TOL_FEAT32
+        assert np.abs(lis.mfccs - g['ring_last'][i]).max() <= TOL_FEAT32
+        assert worst_raw <= TOL_RAW and worst_raw <= GUARD_RAW, (str(g['kinds'][i]), worst_raw)
+        assert worst_dec <= TOL_DECODE, (str(g['kinds'][i]), worst_dec)
+
+
+@pytest.mark.parametrize('cb', [1000, 3200, 6400, 20000, 96000])
+def test_listener_matches_reference_odd_chunk_sizes(model_file, cb):
+    from mycroft_precise_amd.network_runner import Listener
+    g = golden('listener_oddchunks.npz')
+    data = g['pcm'].tobytes()
+    lis = Listener(model_file, cb)
+    raws = [lis.update_raw(data[off:off + cb]) for off in range(0, len(data) - cb + 1, cb)]
+    assert np.abs(np.array(raws) - g['raw_%d' % cb]).max() <= GUARD_RAW
+    assert np.abs(lis.mfccs - g['ring_last_%d' % cb]).max() <= TOL_FEAT32
+    assert len(lis.window_audio) == g['leftover_%d' % cb][-1]
+
+
+def test_listener_update_decodes_like_reference(model_file):
+    from mycroft_precise_amd.network_runner import Listener
+    g = golden('listener_chunk2048.npz')
+    lis = Listener(model_file, 2048)
+    data = g['pcm'][0].tobytes()
+    decs = [lis.update(data[off:off + 2048]) for off in range(0, len(data), 2048)]
+    assert all(isinstance(d, float) for d in decs)
+    assert np.abs(np.array(decs) - g['decoded'][0]).max() <= TOL_DECODE
+
+
+def test_listener_error_conventions(model_file):
+    from mycroft_precise_amd.network_runner import Listener
+    lis = Listener(model_file, 2048)
+    with pytest.raises(EOFError):
+        lis.update(b'')
+    with pytest.raises(ValueError):
+        lis.update(b'\x00\x01\x02')
+    import io
+    with pytest.raises(EOFError):
+        lis.update(io.BytesIO(b''))
+    # stream objects are read chunk_size bytes at a time (network_runner.py:131)
+    stream = io.BytesIO(synth.stream_pcm(0, 4096).tobytes())
+    a, b = lis.update(stream), lis.update(stream)
+    assert 0.0 <= a <= 1.0 and 0.0 <= b <= 1.0 and stream.tell() == 4096
+    lis.clear()
+    assert np.array_equal(lis.mfccs, np.zeros((29, 13))) and len(lis.window_audio) == 0
+
+
+def test_foreign_runner_plugs_into_the_runner_seam(stock_weights):
+    """Listener(..., runner_cls=X): the reference's plug-in seam; MFCC stays on the GPU."""
+    from mycroft_precise_amd.network_runner import Listener
+    g = golden('listener_chunk2048.npz')
+    lis = Listener('not-a-file.npz', 2048, runner_cls=keras_gru.make_runner_cls(stock_weights))
+    data = g['pcm'][1].tobytes()
+    raws = [lis.update_raw(data[off:off + 2048]) for off in range(0, len(data), 2048)]
+    assert np.abs(np.array(raws) - g['raw'][1]).max() <= GUARD_RAW
+
+
+def test_vectorize_matches_reference_vectorize():
+    """vectorization.vectorize / vectorize_raw through the HIP offline kernel (float64 end to end)."""
+    from mycroft_precise_amd import vectorization as V
+    g = golden('vectorize.npz')
+    for name in ('short', 'exact', 'long', 'one_window'):
+        v = V.vectorize(g['audio_' + name])
+        assert v.shape == (29, 13) and v.dtype == np.float64
+        assert np.abs(v - g['vec_' + name]).max() <= 1e-9, name
+    a = synth.stream_pcm(11, 8000).astype(np.float32) / np.float32(32768.0)
+    assert np.abs(V.vectorize_raw(a) - g['raw_feats_8000']).max() <= 1e-9
+    assert V.vectorize_raw(np.zeros(1599)).shape == (0, 13)           # shorter than one window
+    assert np.abs(V.vectorize_delta(g['audio_exact']) - V.add_deltas(g['vec_exact'])).max() <= 1e-9
+
+
+# ---- oracle on seeded synthetic inputs -------------------------------------------------------------
+def _stream_batch(kinds, n_up, chunk=1024):
+    return np.stack([synth.stream_pcm(s, n_up * chunk, k).reshape(n_up, chunk)
+                     for s, k in enumerate(kinds)], axis=1)
+
+
+@pytest.mark.parametrize('prec,guard', [('f64', GUARD_RAW), ('f32', TOL_RAW)])
+def test_batched_streams_match_oracle(stock_weights, prec, guard):
+    """37 streams (ragged last tile), every input kind incl. all-zero (eps clip) and full-scale
+    square (saturation), 40 updates: features and raw outputs after every update."""
+    from mycroft_precise_amd.network_runner import BatchedListener
+    kinds = (['tone_noise'] * 30) + ['zeros', 'square', 'square', 'quiet', 'quiet', 'zeros', 'tone_noise']
+    n_up = 40
+    pcm = _stream_batch(kinds, n_up)
+    hip = BatchedListener(stock_weights, len(kinds), mfcc_precision=prec)
+    ref = ol.BatchedOracle(stock_weights, len(kinds))
+    for u in range(n_up):
+        raw = hip.update_raw(pcm[u])
+        want = ref.update_raw(pcm[u])
+        assert np.abs(raw.astype(np.float64) - want).max() <= guard, u
+        feats = hip.engine.get_vectors()
+        ftol = TOL_FEAT32 if prec == 'f64' else 2e-4
+        assert np.abs(feats.astype(np.float64) - ref.mfccs).max() <= ftol, u
+    q, kc, ke = hip.engine.stream_state()
+    assert np.all(q + 800 * (kc - ke).astype(np.int64) == ref.window_audio.shape[1])
+
+
+def test_fused_launch_equals_two_dependent_launches(stock_weights):
+    """pe_set_fused: MFCC || GRU in one launch (GRU waves predict the post-update frame count) must be
+    bit-identical to MFCC-then-GRU; a chunk too large to fuse (> window - n_fft) silently uses two."""
+    from mycroft_precise_amd.network_runner import BatchedListener
+    n, n_up = 70, 45
+    for chunk in (1024, 1088, 1090, 300):
+        pcm = _stream_batch(['tone_noise'] * (n - 2) + ['zeros', 'square'], n_up, chunk)
+        a, b = BatchedListener(stock_weights, n), BatchedListener(stock_weights, n)
+        b.engine.set_fused(False)
+        for u in range(n_up):
+            ra, rb = a.update_raw(pcm[u]), b.update_raw(pcm[u])
+            assert np.array_equal(ra, rb), (chunk, u)
+        for x, y in zip(a.engine.stream_state(), b.engine.stream_state()):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a.engine.get_vectors(), b.engine.get_vectors())
+
+
+def test_update_vectors_and_masked_clear_desynchronise_streams(stock_weights):
+    """pe_clear(mask) restarts some streams mid-way: afterwards streams of one tile sit at
+    different positions of their feature rings; each must still match its own oracle."""
+    from mycroft_precise_amd.network_runner import BatchedListener
+    n, n_up = 20, 50
+    pcm = _stream_batch(['tone_noise'] * n, n_up)
+    hip = BatchedListener(stock_weights, n)
+    refs = [ol.OracleListener(stock_weights) for _ in range(n)]
+    for u in range(n_up):
+        if u in (7, 19, 33):
+            mask = np.zeros(n, dtype=np.uint8)
+            mask[u % 5::5] = 1
+            hip.clear(mask)
+            for j in np.nonzero(mask)[0]:
+                refs[j].clear()
+        if u % 2:
+            raw = hip.update_raw(pcm[u])
+            want = np.array([r.update_raw(pcm[u, j].tobytes()) for j, r in enumerate(refs)])
+            assert np.abs(raw - want).max() <= GUARD_RAW, u
+        else:
+            feats = hip.update_vectors(pcm[u])
+            want = np.stack([r.update_vectors(pcm[u, j].tobytes()) for j, r in enumerate(refs)])
+            assert feats.shape == (n, 29, 13) and np.abs(feats - want).max() <= TOL_FEAT32, u
+
+
+@pytest.mark.parametrize('chunk', [160, 801, 1600, 4000])
+def test_other_chunk_sizes_including_odd_sample_counts(stock_weights, chunk):
+    """Odd chunk lengths break the 4-byte alignment of sample pairs: exercises the scalar PCM path."""
+    from mycroft_precise_amd.network_runner import BatchedListener
+    n, total = 5, 40000
+    n_up = total // chunk
+    pcm = _stream_batch(['tone_noise', 'quiet', 'square', 'tone_noise', 'zeros'], n_up, chunk)
+    hip = BatchedListener(stock_weights, n)
+    refs = [ol.OracleListener(stock_weights) for _ in range(n)]
+    for u in range(n_up):
+        raw = hip.update_raw(pcm[u])
+        want = np.array([r.update_raw(pcm[u, j].tobytes()) for j, r in enumerate(refs)])
+        assert np.abs(raw - want).max() <= GUARD_RAW, (chunk, u)
+
+
+def test_runner_predict_matches_oracle_ragged_and_empty(stock_weights):
+    from mycroft_precise_amd.network_runner import HipRunner
+    runner = HipRunner(weights=stock_weights)
+    rng = np.random.default_rng(5)
+    for n in (1, 15, 16, 17, 1000):
+        x = rng.normal(0, 3, (n, 29, 13)).astype(np.float32)
+        got = runner.predict(x)
+        assert got.shape == (n, 1) and got.dtype == np.float32
+        assert np.abs(got - keras_gru.predict(x, stock_weights)).max() <= GUARD_RAW
+    assert runner.predict(np.zeros((0, 29, 13), np.float32)).shape == (0, 1)
+    one = rng.normal(0, 3, (29, 13))
+    assert abs(runner.run(one) - keras_gru.predict(one[None], stock_weights)[0, 0]) <= GUARD_RAW
+    with pytest.raises(ValueError):
+        runner.predict(np.zeros((3, 28, 13), np.float32))
+    # saturation: huge features drive the sigmoid to exactly 0.0 / 1.0 like the float32 oracle
+    big = np.full((4, 29, 13), 1e4, np.float32)
+    big[2:] *= -1
+    assert np.array_equal(runner.predict(big), keras_gru.predict(big, stock_weights))
+
+
+@pytest.mark.parametrize('units', [1, 4, 7, 16, 20, 24, 32])
+def test_other_gru_widths(units):
+    """Every instantiation of the register-resident GRU kernel (R = ceil(units/4) = 1..8)."""
+    from mycroft_precise_amd._lib import HipEngine
+    w = synth.make_weights(units=(units,), seed=100 + units)
+    eng = HipEngine(P.pr, w, n_streams=1)
+    x = np.random.default_rng(units).normal(0, 2, (50, 29, 13)).astype(np.float32)
+    assert np.abs(eng.predict(x) - keras_gru.predict(x, w)).max() <= GUARD_RAW
+    eng.close()
+
+
+def test_other_listener_params_overlapping_windows():
+    """window 400 / hop 160 (frames overlap, window < n_fft so frames are zero padded), 26 filters,
+    16 coefficients, T = 98: the generic paths of carry, ring sizing and tables."""
+    from mycroft_precise_amd._lib import HipEngine
+    kw = dict(buffer_t=1.0, window_t=0.025, hop_t=0.01, n_filt=26, n_mfcc=16)
+    opr = ol.Params(**kw)
+    hpr = P.pr.copy()
+    hpr.__dict__.update(kw)
+    assert hpr.n_features == opr.n_features == 98
+    w = synth.make_weights(n_in=16, units=(12,), seed=9)
+    n, n_up, chunk = 3, 30, 1000
+    pcm = _stream_batch(['tone_noise', 'quiet', 'tone_noise'], n_up, chunk)
+    eng = HipEngine(hpr, w, n_streams=n)
+    refs = [ol.OracleListener(w, opr) for _ in range(n)]
+    for u in range(n_up):
+        raw = eng.update(pcm[u])
+        want = np.array([r.update_raw(pcm[u, j].tobytes()) for j, r in enumerate(refs)])
+        assert np.abs(raw - want).max() <= GUARD_RAW, u
+    feats = eng.get_vectors()
+    assert np.abs(feats - np.stack([r.mfccs for r in refs])).max() <= TOL_FEAT32
+    eng.close()
+
+
+# ---- full-size properties (BASELINE configs[1]: 4096 streams on one GPU) ----------------------------
+def test_full_batch_4096_streams_properties(stock_weights):
+    from mycroft_precise_amd.network_runner import BatchedListener
+    B, n_up, n_check = 4096, 34, 48
+    rng = np.random.default_rng(2024)
+    base = synth.batch_pcm(n_check, n_up)                       # [n_up, n_check, 1024]
+    # every stream is a copy of one of the n_check seeded streams, in a shuffled order
+    owner = rng.integers(0, n_check, B)
+    owner[:n_check] = np.arange(n_check)
+    hip = BatchedListener(stock_weights, B)
+    ref = ol.BatchedOracle(stock_weights, n_check)
+    first_pass = []
+    for u in range(n_up):
+        raw = hip.update_raw(base[u][owner])
+        want = ref.update_raw(base[u])
+        assert raw.shape == (B,) and np.all(np.isfinite(raw))
+        # (a) parity with the oracle on the seeded streams
+        assert np.abs(raw[:n_check] - want).max() <= GUARD_RAW, u
+        # (b) streams are independent: identical input -> bit-identical output wherever it sits
+        assert np.array_equal(raw, raw[:n_check][owner]), u
+        first_pass.append(raw)
+    # (c) clear() + same input -> bit-identical outputs (stateless apart from the stream state)
+    hip.clear()
+    for u in range(n_up):
+        assert np.array_equal(hip.update_raw(base[u][owner]), first_pass[u]), u
+    info = hip.engine.info()
+    assert info.n_streams == B and info.ring_slots == 32 and info.device_bytes > B * 2048
+
+
+# ---- BASELINE configs[0]: one stream through the engine executable (plumbing) ------------------------
+def test_precise_engine_subprocess_protocol(model_file, stock_weights):
+    """PreciseEngine + `python -m mycroft_precise_amd.scripts.engine`: raw int16 on stdin, one ASCII
+    float per chunk on stdout (runner.py:54-67 <-> engine.py:53-63)."""
+    from mycroft_precise_amd.runner import PreciseEngine
+    g = golden('listener_chunk2048.npz')
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    eng = PreciseEngine([sys.executable, '-m', 'mycroft_precise_amd.scripts.engine'], model_file, 2048)
+    eng.proc = subprocess.Popen(eng.exe_args, stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env, cwd=REPO)
+    try:
+        data = g['pcm'][0].tobytes()
+        got = [eng.get_prediction(data[off:off + 2048]) for off in range(0, 2048 * 12, 2048)]
+    finally:
+        eng.stop()
+    assert np.abs(np.array(got) - g['decoded'][0][:12]).max() <= TOL_DECODE

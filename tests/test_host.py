@@ -1,0 +1,260 @@
+"""CPU: the host-side mirror of the reference interface (params, util, ThresholdDecoder,
+precise_runner classes, engine wire protocol) against the golden fixtures produced by the
+reference's own code."""
+import io
+import re
+import sys
+import threading
+import time
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from mycroft_precise_amd import params as P
+from mycroft_precise_amd import util, vectorization as V
+from mycroft_precise_amd.threshold_decoder import ThresholdDecoder
+from mycroft_precise_amd.runner import (ReadWriteStream, TriggerDetector, PreciseRunner, PreciseEngine,
+                                        ListenerEngine, Engine)
+from oracle import sonopy_restated as so
+
+
+def test_params_defaults_and_derived_sizes():
+    g = golden('params_default.npz')
+    for k in ('window_samples', 'hop_samples', 'buffer_samples', 'n_features', 'max_samples',
+              'feature_size', 'n_fft', 'n_filt', 'n_mfcc'):
+        assert getattr(P.pr, k) == int(g[k]), k
+    assert P.pr.vectorizer == P.Vectorizer.mfccs and P.pr.use_delta is False
+    assert P.pr.threshold_config == ((6, 4),) and P.pr.threshold_center == 0.2
+    with pytest.raises(AttributeError):
+        P.pr.n_fft = 1024
+
+
+def test_inject_and_save_params_roundtrip(tmp_path):
+    saved = dict(P.pr.__dict__)
+    try:
+        model = str(tmp_path / 'm.npz')
+        open(model, 'wb').close()
+        P.pr.__dict__['n_mfcc'] = 11
+        P.pr.__dict__['threshold_center'] = 0.35
+        P.save_params(model)
+        P.pr.__dict__.update(saved)
+        out = P.inject_params(model)
+        assert out is P.pr and P.pr.n_mfcc == 11 and P.pr.threshold_center == 0.35
+        # a legacy file without the 'vectorizer' key selects the speechpy vectorizer (params.py:147)
+        (tmp_path / 'old.npz.params').write_text('{"n_mfcc": 13}')
+        open(str(tmp_path / 'old.npz'), 'wb').close()
+        P.pr.__dict__.update(saved)
+        P.inject_params(str(tmp_path / 'old.npz'))
+        assert P.pr.vectorizer == P.Vectorizer.speechpy_mfccs
+        # missing params file: defaults stay, no exception
+        P.pr.__dict__.update(saved)
+        P.inject_params(str(tmp_path / 'nothing-here.npz'))
+        assert P.pr.__dict__ == saved
+    finally:
+        P.pr.__dict__.clear()
+        P.pr.__dict__.update(saved)
+
+
+def test_buffer_to_audio_bit_exact_and_inverse():
+    g = golden('buffer_to_audio.npz')
+    out = util.buffer_to_audio(g['pcm'].tobytes())
+    assert out.dtype == np.float32 and np.array_equal(out, g['audio'])
+    assert util.audio_to_buffer(out) == g['pcm'].tobytes()
+
+
+def test_pcm16_from_accepts_what_listener_update_accepts():
+    pcm = np.array([0, 1, -1, 32767, -32768], dtype='<i2')
+    assert np.array_equal(util.pcm16_from(pcm.tobytes()), pcm)
+    assert np.array_equal(util.pcm16_from(pcm), pcm)
+    assert np.array_equal(util.pcm16_from(util.buffer_to_audio(pcm.tobytes())), pcm)
+    assert np.array_equal(util.pcm16_from(pcm.astype(np.float64) / 32768.0), pcm)
+    with pytest.raises(ValueError):
+        util.pcm16_from(b'\x00\x01\x02')
+    with pytest.raises(TypeError):
+        util.pcm16_from(np.array([0.1234567]))
+
+
+def test_chunk_audio():
+    a = np.arange(10)
+    assert [c.tolist() for c in util.chunk_audio(a, 4)] == [[0, 1, 2, 3], [4, 5, 6, 7]]
+
+
+@pytest.mark.parametrize('name', ['default', 'two', 'narrow'])
+def test_threshold_decoder_matches_reference(name):
+    g = golden('threshold_decoder.npz')
+    d = ThresholdDecoder([tuple(r) for r in g['cfg_' + name]], float(g['center_' + name]))
+    assert len(d.cd) == int(g['cd_len_' + name])
+    dec = np.array([d.decode(float(v)) for v in g['grid']])
+    assert np.array_equal(dec, g['decode_' + name])
+    assert np.array_equal(d.decode_many(g['grid']), g['decode_' + name])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        enc = np.array([d.encode(float(v)) for v in g['thr']])
+    assert np.array_equal(enc, g['encode_' + name], equal_nan=True)
+
+
+def test_add_deltas_matches_reference():
+    g = golden('vectorize.npz')
+    assert np.array_equal(V.add_deltas(g['raw_feats_8000']), g['deltas_8000'])
+
+
+def test_mel_filterbank_table_equals_oracle():
+    assert np.array_equal(V.mel_filterbank(16000, 20, 257), so.filterbanks(16000, 20, 257))
+    assert np.array_equal(V.mel_filterbank(8000, 26, 257), so.filterbanks(8000, 26, 257))
+
+
+def test_vectorize_raw_rejects_empty_audio_and_unsupported_vectorizers():
+    with pytest.raises(util.InvalidAudio):
+        V.vectorize_raw(np.array([]))
+    with pytest.raises(NotImplementedError):
+        V.vectorizers[P.Vectorizer.mels](np.zeros(2000))
+    with pytest.raises(NotImplementedError):
+        V.vectorizers[P.Vectorizer.speechpy_mfccs](np.zeros(2000))
+
+
+# ---- precise_runner drop-in ---------------------------------------------------------------
+class TestReadWriteStream:          # the reference's own unit tests (runner/test/test_runner.py:4-18)
+    def test_read_write(self):
+        s = ReadWriteStream(b'1234567890')
+        assert s.read(2) == b'12'
+        assert s.read(2) == b'34'
+        s.write(b'hi')
+        assert s.read() == b'567890hi'
+        s.write(b'hello')
+        assert s.read() == b'hello'
+        assert s.read(1, timeout=0.1) == b''
+
+    def test_chop(self):
+        s = ReadWriteStream(chop_samples=10)
+        s.write(b'1234567890hello')
+        assert s.read(5) == b'hello'
+
+    def test_against_reference_fixture(self):
+        g = golden('precise_runner.npz')
+        s = ReadWriteStream(b'0123456789abcde', chop_samples=10)
+        s.write(b'FGHIJKLM')
+        assert s.read(2, timeout=0.2) == g['rws_chop_read'].tobytes()
+        assert s.read(1, timeout=0.2) == g['rws_chop_left'].tobytes()
+        assert s.read(5, timeout=0.05) == g['rws_chop_short'].tobytes() == b''
+        s = ReadWriteStream(b'0123456789abcdef', chop_samples=8)
+        assert s.read(3, timeout=0.2) == g['rws_nochop_read'].tobytes()
+        assert len(s) == int(g['rws_nochop_len'])
+
+    def test_blocking_read_wakes_on_write(self):
+        s = ReadWriteStream()
+        threading.Timer(0.05, lambda: s.write(b'abcd')).start()
+        t0 = time.time()
+        assert s.read(4, timeout=2.0) == b'abcd'
+        assert time.time() - t0 < 1.5
+
+
+@pytest.mark.parametrize('name', ['default', 'small', 'big', 'lvl0'])
+def test_trigger_detector_matches_reference(name):
+    g = golden('precise_runner.npz')
+    chunk_size, sens, level = g['cfg_' + name]
+    det = TriggerDetector(int(chunk_size), float(sens), int(level))
+    fired, act = [], []
+    for p in g['probs_' + name]:
+        fired.append(det.update(float(p)))
+        act.append(det.activation)
+    assert np.array_equal(np.array(fired), g['fired_' + name])
+    assert np.array_equal(np.array(act), g['activation_' + name])
+    assert g['fired_' + name].sum() > 0
+
+
+def test_precise_engine_argv_and_chunk_check():
+    e = PreciseEngine('precise-engine', 'model.pb', 4096)
+    assert e.exe_args == ['precise-engine', 'model.pb', '4096'] and e.chunk_size == 4096
+    e2 = PreciseEngine(['python', 'engine.py'], 'm.npz')
+    assert e2.exe_args == ['python', 'engine.py', 'm.npz', '2048']
+    with pytest.raises(ValueError):
+        e.get_prediction(b'\0' * 10)
+    with pytest.raises(NotImplementedError):
+        Engine().get_prediction(b'')
+
+
+def test_precise_runner_drives_engine_and_detector():
+    class FakeListener:
+        def __init__(self):
+            self.n = 0
+
+        def update(self, chunk):
+            assert len(chunk) == 2048
+            self.n += 1
+            return 0.9 if 5 <= self.n <= 12 else 0.1
+
+    stream = ReadWriteStream()
+    preds, acts = [], []
+    runner = PreciseRunner(ListenerEngine(FakeListener()), trigger_level=3, sensitivity=0.5, stream=stream,
+                           on_prediction=preds.append, on_activation=lambda: acts.append(len(preds)))
+    runner.start()
+    stream.write(b'\0' * 2048 * 20)
+    deadline = time.time() + 5
+    while len(preds) < 20 and time.time() < deadline:
+        time.sleep(0.01)
+    runner.stop()
+    assert len(preds) >= 20 and preds[4] == 0.9 and preds[0] == 0.1
+    assert acts == [8]           # 4th consecutive hot chunk: activation 4 > trigger_level 3
+
+
+# ---- engine executable wire protocol (engine.py:53-67), listener faked on CPU ---------------------
+class FakeStdin:
+    def __init__(self, data: bytes):
+        self.buffer = io.BytesIO(data)
+
+    def isatty(self):
+        return False
+
+
+class FakeStdout:
+    def __init__(self):
+        self.buffer = io.BytesIO()
+
+
+def test_engine_script_protocol(monkeypatch):
+    import mycroft_precise_amd.network_runner as nr
+    from mycroft_precise_amd.scripts import engine as eng
+
+    class FakeListener:
+        def __init__(self, model_name, chunk_size):
+            assert (model_name, chunk_size) == ('m.npz', 2048)
+            self.k = 0
+
+        def update(self, stream):
+            chunk = stream.read(2048)
+            if len(chunk) == 0:
+                raise EOFError
+            print('noise that must not reach stdout')
+            self.k += 1
+            return 0.25 * self.k
+
+    monkeypatch.setattr(nr, 'Listener', FakeListener)
+    out = FakeStdout()
+    monkeypatch.setattr(sys, 'stdin', FakeStdin(b'\1' * 2048 * 3))
+    monkeypatch.setattr(sys, 'stdout', out)
+    eng.EngineScript.create(model_name='m.npz', chunk_size=2048).run()
+    assert sys.stdout is out                       # restored
+    lines = out.buffer.getvalue().split(b'\n')
+    assert lines == [b'0.25', b'0.5', b'0.75', b'']
+    assert all(re.fullmatch(rb'[01]\.[0-9]+', ln) for ln in lines[:-1])     # test_engine.py:50
+
+
+def test_engine_script_refuses_a_tty(monkeypatch):
+    from mycroft_precise_amd.scripts import engine as eng
+
+    class Tty:
+        def isatty(self):
+            return True
+    monkeypatch.setattr(sys, 'stdin', Tty())
+    with pytest.raises(ValueError):
+        eng.EngineScript.create(model_name='m.npz')
+
+
+def test_find_runner_extension_dispatch():
+    from mycroft_precise_amd.network_runner import Listener, HipRunner
+    assert Listener.find_runner('a/b/model.npz') is HipRunner
+    assert Listener.find_runner('model.pb') is HipRunner
+    with pytest.raises(ValueError):
+        Listener.find_runner('model.txt')
