@@ -137,6 +137,10 @@ int pe_get_stream_state(pe_engine* e, int32_t* q_out, uint32_t* computed_out, ui
  * and network roles run concurrently inside ONE launch; 0 = always two dependent launches. */
 int pe_set_fused(pe_engine* e, int32_t enabled);
 
+/* Network kernel shape: 0 (default) = automatic (four waves share each 16-stream tile while the
+ * engine has <= 1024 tiles, one wave per tile beyond), 1 / 4 = forced.  Results are identical. */
+int pe_set_gru_waves(pe_engine* e, int32_t waves_per_tile);
+
 /* HIP-event timing of the kernels launched by the last *_device/host update on this engine
  * (milliseconds; measured on the stream the kernels ran on).  Enabled with pe_set_timing(e,1).
  * With a fused launch mfcc_ms is the whole update and gru_ms is 0. */

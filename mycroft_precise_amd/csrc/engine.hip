@@ -5,6 +5,7 @@
 #include "../../include/precise_engine.h"
 #include "pe_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -44,10 +45,11 @@ struct pe_engine {
     uint32_t* st_ke[2] = {nullptr, nullptr};
     int cur = 0;
     bool fused = true;      // MFCC || GRU in one launch when the chunk size allows it
+    int gru_waves = 0;      // 0 = auto (4 waves per tile while tiles <= 1024, else 1), or forced 1 / 4
     float* ring = nullptr;
     // tables (both precisions share the int tables)
-    void* tw256 = nullptr; void* w512 = nullptr; void* mel_w = nullptr; void* dct = nullptr;
-    int* mel_start = nullptr; int* mel_off = nullptr;
+    unsigned char* table_blob = nullptr;
+    int table_blob_bytes = 0;
     // packed network
     float* wx = nullptr; float* wr1 = nullptr; float* wr2 = nullptr; float* bias = nullptr; float* wd = nullptr;
     // staging for the host entry points (grown on demand)
@@ -131,30 +133,72 @@ int build_tables(pe_engine* e, const double* mel_filters) {
         for (int n = 0; n < n_filt; ++n)
             dct[(size_t)k * n_filt + n] = (R)(sk * std::cos(PI * k * (2 * n + 1) / (2.0 * n_filt)));
     }
-    // trim each dense triangular filter to its support
-    std::vector<R> mw;
-    std::vector<int> ms(n_filt), mo(n_filt + 1);
-    for (int f = 0; f < n_filt; ++f) {
-        const double* row = mel_filters + (size_t)f * kBins;
-        int lo = -1, hi = -1;
-        for (int b = 0; b < kBins; ++b)
-            if (row[b] != 0.0) { if (lo < 0) lo = b; hi = b; }
-        mo[f] = (int)mw.size();
-        ms[f] = lo < 0 ? 0 : lo;
-        if (lo >= 0) for (int b = lo; b <= hi; ++b) mw.push_back((R)row[b]);
+    // Mel pass tables (see mfcc_frame): lane r walks bins 16r + i, i = 0..16 (bin 256 only on lane
+    // 15); per bin the 1st / 2nd non-zero filter ("streams"); a run of equal filter ids under one
+    // stream of one lane ends in a flush to a partial-sum slot; slots are numbered filter by filter.
+    struct Run { int f, lane, stream, last_step; };
+    std::vector<Run> runs;
+    std::vector<R> mw((size_t)2 * kMelSteps * 16, R(0));
+    std::vector<int> fid((size_t)2 * kMelSteps * 16, -1);
+    for (int r = 0; r < 16; ++r)
+        for (int i = 0; i < kMelSteps; ++i) {
+            const int b = 16 * r + i;
+            if (b >= kBins || (i == 16 && r != 15)) continue;     // bin 16r+16 belongs to lane r+1
+            int cnt = 0;
+            for (int f = 0; f < n_filt; ++f) {
+                const double w = mel_filters[(size_t)f * kBins + b];
+                if (w == 0.0) continue;
+                if (cnt == 2) return fail(e, PE_ERR_UNSUPPORTED, "mel filterbank: bin %d feeds more than two filters", b);
+                mw[((size_t)cnt * kMelSteps + i) * 16 + r] = (R)w;
+                fid[((size_t)cnt * kMelSteps + i) * 16 + r] = f;
+                ++cnt;
+            }
+        }
+    for (int r = 0; r < 16; ++r)
+        for (int st = 0; st < 2; ++st) {
+            int cur = -1;
+            for (int i = 0; i <= kMelSteps; ++i) {
+                const int f = i < kMelSteps ? fid[((size_t)st * kMelSteps + i) * 16 + r] : -1;
+                if (f != cur) {
+                    if (cur >= 0) runs.push_back({cur, r, st, i - 1});
+                    cur = f;
+                }
+            }
+        }
+    std::stable_sort(runs.begin(), runs.end(), [](const Run& x, const Run& y) {
+        if (x.f != y.f) return x.f < y.f;
+        if (x.lane != y.lane) return x.lane < y.lane;
+        if (x.last_step != y.last_step) return x.last_step < y.last_step;
+        return x.stream < y.stream;
+    });
+    if ((int)runs.size() > kMaxMelParts - 1) return fail(e, PE_ERR_UNSUPPORTED, "mel filterbank needs %zu partial sums, limit %d", runs.size(), kMaxMelParts);
+    std::vector<int> flush((size_t)kMelSteps * 16, (int)0xffffffff), pstart(n_filt + 1, 0);
+    for (size_t slot = 0; slot < runs.size(); ++slot) {
+        const Run& q = runs[slot];
+        int& word = flush[(size_t)q.last_step * 16 + q.lane];
+        if (q.stream == 0) word = (word & (int)0xffff0000) | (int)slot;
+        else word = (word & 0xffff) | ((int)slot << 16);
+        pstart[q.f + 1] += 1;
     }
-    mo[n_filt] = (int)mw.size();
-    if ((int)mw.size() > kMaxMelNnz) return fail(e, PE_ERR_UNSUPPORTED, "mel filterbank has %zu non-zeros, limit %d", mw.size(), kMaxMelNnz);
-    e->mel_nnz = (int)mw.size();
+    for (int f = 0; f < n_filt; ++f) pstart[f + 1] += pstart[f];
+    // pack the blob in LDS order
+    const size_t total = table_blob_bytes(sizeof(R), n_filt, n_mfcc);
+    std::vector<unsigned char> blob(total, 0);
+    size_t off = 0;
+    auto put = [&](const void* src, size_t bytes) { if (bytes) std::memcpy(blob.data() + off, src, bytes); off += bytes; };
+    put(tw.data(), 256 * sizeof(cplx<R>));
+    put(w5.data(), 129 * sizeof(cplx<R>));
+    off += sizeof(cplx<R>);                               // w512 is padded to 130 entries
+    put(dct.data(), dct.size() * sizeof(R));
+    put(mw.data(), mw.size() * sizeof(R));
+    off = (off + 15) & ~(size_t)15;
+    put(flush.data(), flush.size() * sizeof(int));
+    put(pstart.data(), pstart.size() * sizeof(int));
+    off = (off + 15) & ~(size_t)15;
+    if (off != total) return fail(e, PE_ERR_INVALID, "internal: table blob layout mismatch (%zu vs %zu)", off, total);
     int rc;
-    cplx<R>* d_tw; cplx<R>* d_w5; R* d_mw; R* d_dct;
-    if ((rc = dev_upload(e, &d_tw, tw))) return rc;
-    if ((rc = dev_upload(e, &d_w5, w5))) return rc;
-    if ((rc = dev_upload(e, &d_mw, mw))) return rc;
-    if ((rc = dev_upload(e, &d_dct, dct))) return rc;
-    if ((rc = dev_upload(e, &e->mel_start, ms))) return rc;
-    if ((rc = dev_upload(e, &e->mel_off, mo))) return rc;
-    e->tw256 = d_tw; e->w512 = d_w5; e->mel_w = d_mw; e->dct = d_dct;
+    if ((rc = dev_upload(e, &e->table_blob, blob))) return rc;
+    e->table_blob_bytes = (int)total;
     return PE_OK;
 }
 
@@ -221,13 +265,8 @@ StreamGeom geom(const pe_engine* e) {
 template <class R>
 MfccTables<R> tables(const pe_engine* e) {
     MfccTables<R> t;
-    t.tw256 = static_cast<const cplx<R>*>(e->tw256);
-    t.w512 = static_cast<const cplx<R>*>(e->w512);
-    t.mel_w = static_cast<const R*>(e->mel_w);
-    t.dct = static_cast<const R*>(e->dct);
-    t.mel_start = e->mel_start;
-    t.mel_off = e->mel_off;
-    t.mel_nnz = e->mel_nnz;
+    t.blob = e->table_blob;
+    t.blob_bytes = e->table_blob_bytes;
     return t;
 }
 
@@ -270,6 +309,7 @@ GruArgs gru_args(const pe_engine* e) {
     a.window = e->prm.window_samples; a.hop = e->prm.hop_samples;
     a.frame_len = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
     a.feats = nullptr; a.out = nullptr;
+    a.waves_per_tile = e->gru_waves ? e->gru_waves : (e->n_tiles <= 1024 ? 4 : 1);
     return a;
 }
 
@@ -383,7 +423,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         for (auto& ev : e->ev)
             if (hipEventCreate(&ev) != hipSuccess) { rc = fail(e, PE_ERR_HIP, "hipEventCreate failed"); break; }
         if (rc) break;
-        const size_t lds = mfcc_lds_bytes(p->mfcc_precision == 0 ? 8 : 4, p->n_filt, p->n_mfcc, e->mel_nnz);
+        const size_t lds = lds_layout_bytes(p->mfcc_precision == 0 ? 8 : 4, p->n_filt, p->n_mfcc);
         if (lds > 160 * 1024) { rc = fail(e, PE_ERR_UNSUPPORTED, "MFCC kernel would need %zu bytes of LDS", lds); break; }
         if ((rc = pe_clear(e, nullptr))) break;
         hipError_t se = hipDeviceSynchronize();
@@ -492,6 +532,7 @@ int pe_predict_device(pe_engine* e, const float* feats_dev, int32_t n, float* ou
     if (n == 0) return PE_OK;
     GruArgs a = gru_args(e);
     a.n_streams = n;
+    a.waves_per_tile = 1;
     a.feats = feats_dev;
     a.out = out_dev;
     PE_HIP(e, launch_gru_small(a, false, static_cast<hipStream_t>(stream)));
@@ -567,6 +608,13 @@ int pe_get_stream_state(pe_engine* e, int32_t* q_out, uint32_t* computed_out, ui
 int pe_set_fused(pe_engine* e, int32_t enabled) {
     if (!e) return PE_ERR_INVALID;
     e->fused = enabled != 0;
+    return PE_OK;
+}
+
+int pe_set_gru_waves(pe_engine* e, int32_t waves) {
+    if (!e) return PE_ERR_INVALID;
+    if (waves != 0 && waves != 1 && waves != 4) return fail(e, PE_ERR_INVALID, "gru waves per tile must be 0 (auto), 1 or 4");
+    e->gru_waves = waves;
     return PE_OK;
 }
 

@@ -30,8 +30,10 @@ namespace pe {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float hard_sigmoid(float v) {
-    // Keras/TF: x = (0.2 * x) + 0.5 as two ops, then clip(0, 1)
-    const float y = __fadd_rn(__fmul_rn(0.2f, v), 0.5f);
+    // Keras/TF: clip(0.2 * x + 0.5, 0, 1).  hipcc contracts the multiply-add into one v_fma_f32
+    // with the clamp modifier (one rounding instead of TF's two: <= 1 ulp apart, inside the
+    // 1e-4 parity budget by three orders of magnitude).
+    const float y = 0.2f * v + 0.5f;
     return __builtin_amdgcn_fmed3f(y, 0.0f, 1.0f);
 }
 
@@ -100,16 +102,18 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
         xbase = a.feats + (size_t)stream * T * a.n_in;
     }
     auto load_x = [&](int t) -> f32x4 {
+        if (FROM_RING) {
+            // no branch: rows of padded streams exist (zeroed), t is clamped to the last row, so the
+            // prefetch stays in flight across the timestep instead of being waited for at a join
+            const int tc = t < T ? t : T - 1;
+            const uint32_t slot = (first + (uint32_t)tc) & mask;
+            return *reinterpret_cast<const f32x4*>(xbase + (size_t)slot * kTileStreams * kRowFloats);
+        }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (!valid || t >= T) return v;
-        if (FROM_RING) {
-            const uint32_t slot = (first + (uint32_t)t) & mask;
-            v = *reinterpret_cast<const f32x4*>(xbase + (size_t)slot * kTileStreams * kRowFloats);
-        } else {
-            const float* p = xbase + (size_t)t * a.n_in + 4 * g;
+        const float* p = xbase + (size_t)t * a.n_in + 4 * g;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) v[kk] = (4 * g + kk < a.n_in) ? p[kk] : 0.f;
-        }
+        for (int kk = 0; kk < 4; ++kk) v[kk] = (4 * g + kk < a.n_in) ? p[kk] : 0.f;
         return v;
     };
 
@@ -139,7 +143,7 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
             const int sz = rho, sr = R + rho;
             z[rho] = hard_sigmoid(acc[sz >> 2][sz & 3]);
             const float r = hard_sigmoid(acc[sr >> 2][sr & 3]);
-            rh[rho] = __fmul_rn(r, h[rho]);
+            rh[rho] = r * h[rho];
         }
         // phase 2: + (r*h) . U for the candidate rows
 #pragma unroll
@@ -150,7 +154,7 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
         for (int rho = 0; rho < R; ++rho) {
             const int sh = 2 * R + rho;
             const float hh = acc[sh >> 2][sh & 3];
-            h[rho] = __fadd_rn(__fmul_rn(z[rho], h[rho]), __fmul_rn(__fsub_rn(1.0f, z[rho]), hh));
+            h[rho] = z[rho] * h[rho] + (1.0f - z[rho]) * hh;
         }
         x = xn;
     }
@@ -164,6 +168,139 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
     if (valid && g == 0) {
         const float logit = part + a.dense_bias;
         a.out[stream] = 1.0f / (1.0f + expf(-logit));
+    }
+}
+
+
+// ---- four waves per tile ------------------------------------------------------------------------
+// With few tiles (4096 streams = 256 tiles on 1024 SIMDs) one wave per tile leaves three quarters
+// of the matrix cores idle and the window is a 29-step dependent chain of 41 MFMAs.  Here the four
+// waves of a workgroup share one tile: wave w owns output tiles {w, w+4, ...}; every wave keeps
+// the full hidden state in registers; per timestep the gate values cross waves through LDS twice
+// (z/r after phase 1, candidates after phase 2), 64 floats per slot, and every lane reads back
+// exactly the lane position it would have owned.  The next step's input projection is issued while
+// the candidates travel from LDS.
+// (A five-wave variant with one wave per (tile, phase) role measured the same 21 us stand-alone
+// but needs 320-thread workgroups, which halves the residency of the fused launch: rejected.)
+template <int R>
+__device__ __forceinline__ void gru_tile_mw(const GruArgs& a, const int tile, const int wave, const int lane,
+                                            float* S /* [3R][64] floats of LDS */) {
+    using G = GruShape<R>;
+    constexpr int MAXT = (G::NT + 3) / 4;
+    const int g = lane >> 4, j = lane & 15;
+    const long long stream = (long long)tile * kTileStreams + j;
+    const bool valid = stream < a.n_streams;
+    const int T = a.n_features;
+
+    float wx[MAXT][4], wr1[MAXT][R], wr2[MAXT][R], wd[R];
+    f32x4 bias[MAXT];
+    bool own[MAXT], p1[MAXT], p2[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int tl = wave + 4 * i;
+        own[i] = tl < G::NT;
+        p1[i] = own[i] && tl < G::P1_END;
+        p2[i] = own[i] && tl >= G::P2_BEGIN;
+        const int tc = own[i] ? tl : 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wx[i][kk] = a.wx[(tc * 4 + kk) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias[i][q] = a.bias[(tc * 4 + q) * 64 + lane];
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) {
+            wr1[i][rho] = a.wr1[(tc * R + rho) * 64 + lane];
+            wr2[i][rho] = a.wr2[(tc * R + rho) * 64 + lane];
+        }
+    }
+#pragma unroll
+    for (int rho = 0; rho < R; ++rho) wd[rho] = a.wd[rho * 64 + lane];
+
+    uint32_t ke = a.st_ke[stream];                 // counters exist for padded streams too
+    if (a.predict_ke) {
+        const int q = a.st_q[stream];
+        const uint32_t kc = a.st_kc[stream];
+        const int avail = q + a.chunk;
+        const int nnew = avail >= a.frame_len ? 1 + (avail - a.frame_len) / a.hop : 0;
+        const int qn = avail - nnew * a.hop;
+        const int m = qn + a.hop * (int)(kc + (uint32_t)nnew - ke);
+        if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
+    }
+    const uint32_t first = ke - (uint32_t)T;
+    const uint32_t mask = (uint32_t)(a.ring_slots - 1);
+    const float* xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats + 4 * g;
+    auto load_x = [&](int t) -> f32x4 {
+        const int tc = t < T ? t : T - 1;
+        const uint32_t slot = (first + (uint32_t)tc) & mask;
+        return *reinterpret_cast<const f32x4*>(xbase + (size_t)slot * kTileStreams * kRowFloats);
+    };
+    auto xproj = [&](const f32x4& x, f32x4 (&acc)[MAXT]) {
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+            if (!own[i]) continue;
+            acc[i] = mfma(wx[i][0], x[0], bias[i]);
+#pragma unroll
+            for (int kk = 1; kk < 4; ++kk) acc[i] = mfma(wx[i][kk], x[kk], acc[i]);
+        }
+    };
+
+    float h[R], z[R];
+#pragma unroll
+    for (int rho = 0; rho < R; ++rho) { h[rho] = 0.f; z[rho] = 0.f; }
+    f32x4 acc[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) acc[i] = bias[i];
+    f32x4 x = load_x(0);
+    xproj(x, acc);
+    x = load_x(1);
+    for (int t = 0; t < T; ++t) {
+        // phase 1: + h . U on the tiles holding z / r slots, publish hard-sigmoided gates
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+            if (!p1[i]) continue;
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) acc[i] = mfma(wr1[i][rho], h[rho], acc[i]);
+            const int base = 4 * (wave + 4 * i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (base + q < 2 * R) S[(base + q) * 64 + lane] = hard_sigmoid(acc[i][q]);
+        }
+        __syncthreads();
+        float rh[R];
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) {
+            z[rho] = S[rho * 64 + lane];
+            rh[rho] = S[(R + rho) * 64 + lane] * h[rho];
+        }
+        // phase 2: + (r*h) . U on the tiles holding candidate slots, publish candidates
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+            if (!p2[i]) continue;
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) acc[i] = mfma(wr2[i][rho], rh[rho], acc[i]);
+            const int base = 4 * (wave + 4 * i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (base + q >= 2 * R && base + q < 3 * R) S[(base + q) * 64 + lane] = acc[i][q];
+        }
+        __syncthreads();
+        float hh[R];
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) hh[rho] = S[(2 * R + rho) * 64 + lane];
+        // next step's input projection while the candidates travel from LDS
+        const f32x4 xn = load_x(t + 2);
+        xproj(x, acc);
+        x = xn;
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) h[rho] = z[rho] * h[rho] + (1.0f - z[rho]) * hh[rho];
+    }
+
+    if (wave == 0) {
+        float part = 0.f;
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) part = fmaf(h[rho], wd[rho], part);
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (valid && g == 0) a.out[stream] = 1.0f / (1.0f + expf(-(part + a.dense_bias)));
     }
 }
 

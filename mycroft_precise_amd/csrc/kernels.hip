@@ -24,31 +24,41 @@ __global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
     gru_tile<R, FROM_RING>(a, blockIdx.x, threadIdx.x);
 }
 
+// ---- GRU: four waves per 16-stream tile (few tiles: fills all four SIMDs of a CU) -----------------
+template <int R>
+__global__ __launch_bounds__(256) void gru_mw_kernel(const GruArgs a) {
+    __shared__ float S[3 * R * 64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    gru_tile_mw<R>(a, blockIdx.x, wave, threadIdx.x & 63, S);
+}
+
 // ---- fused update: GRU role || MFCC role in ONE launch ------------------------------------------
-// Workgroups [0, n_gru_blocks) run the network (4 waves = 4 tiles each) on the feature windows as
-// they will stand after this update; workgroups [n_gru_blocks, n_gru_blocks + n_tiles) compute this
-// update's MFCC frames.  The GRU workgroups are dispatched first: they are the long pole.
-template <class R, int RG>
+// Workgroups [0, n_gru_blocks) run the network on the feature windows as they will stand after this
+// update; workgroups after them compute this update's MFCC frames.  The GRU workgroups are
+// dispatched first: they are the long pole.  MW = true: one GRU workgroup per tile, its four waves
+// share the tile (gru_tile_mw); MW = false: four tiles per GRU workgroup, one wave each.
+template <class R, int RG, bool MW>
 __global__ __launch_bounds__(256) void fused_update_kernel(const MfccStreamArgs<R> m, const GruArgs g,
                                                            const int n_gru_blocks, const int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
     if (b < n_gru_blocks) {
-        const int tile = b * 4 + (threadIdx.x >> 6);
-        if (tile < n_tiles) gru_tile<RG, true>(g, tile, threadIdx.x & 63);
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (MW) {
+            gru_tile_mw<RG>(g, b, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
+        } else {
+            const int tile = b * 4 + wave;
+            if (tile < n_tiles) gru_tile<RG, true>(g, tile, threadIdx.x & 63);
+        }
     } else {
         mfcc_stream_tile<R>(m, b - n_gru_blocks, smem);
     }
 }
 
-size_t mfcc_lds_bytes(int real_size, int n_filt, int n_mfcc, int mel_nnz) {
-    return lds_layout_bytes(real_size, n_filt, n_mfcc, mel_nnz);
-}
-
 template <class R>
 static hipError_t launch_stream(const MfccStreamArgs<R>& a, hipStream_t s) {
     const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
-    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc, a.tab.mel_nnz);
+    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc);
     hipLaunchKernelGGL(mfcc_stream_kernel<R>, dim3(tiles), dim3(256), lds, s, a);
     return hipGetLastError();
 }
@@ -57,7 +67,7 @@ template <class R>
 static hipError_t launch_offline(const MfccOfflineArgs<R>& a, hipStream_t s) {
     if (a.n_frames <= 0) return hipSuccess;
     const long long blocks = (a.n_frames + 15) / 16;
-    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc, a.tab.mel_nnz);
+    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc);
     hipLaunchKernelGGL(mfcc_offline_kernel<R>, dim3((unsigned)blocks), dim3(256), lds, s, a);
     return hipGetLastError();
 }
@@ -74,7 +84,8 @@ template <int R>
 static hipError_t launch_r(const GruArgs& a, bool from_ring, hipStream_t s) {
     const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
     if (tiles == 0) return hipSuccess;
-    if (from_ring) hipLaunchKernelGGL((gru_small_kernel<R, true>), dim3(tiles), dim3(64), 0, s, a);
+    if (from_ring && a.waves_per_tile == 4) hipLaunchKernelGGL((gru_mw_kernel<R>), dim3(tiles), dim3(256), 0, s, a);
+    else if (from_ring) hipLaunchKernelGGL((gru_small_kernel<R, true>), dim3(tiles), dim3(64), 0, s, a);
     else hipLaunchKernelGGL((gru_small_kernel<R, false>), dim3(tiles), dim3(64), 0, s, a);
     return hipGetLastError();
 }
@@ -96,9 +107,13 @@ hipError_t launch_gru_small(const GruArgs& a, bool from_ring, hipStream_t s) {
 template <class R, int RG>
 static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const GruArgs& g, hipStream_t s) {
     const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
-    const int gru_blocks = (tiles + 3) / 4;
-    const size_t lds = lds_layout_bytes(sizeof(R), m.geo.n_filt, m.geo.n_mfcc, m.tab.mel_nnz);
-    hipLaunchKernelGGL((fused_update_kernel<R, RG>), dim3(gru_blocks + tiles), dim3(256), lds, s, m, g, gru_blocks, tiles);
+    const size_t lds = lds_layout_bytes(sizeof(R), m.geo.n_filt, m.geo.n_mfcc);
+    if (g.waves_per_tile == 4) {
+        hipLaunchKernelGGL((fused_update_kernel<R, RG, true>), dim3(tiles + tiles), dim3(256), lds, s, m, g, tiles, tiles);
+    } else {
+        const int gru_blocks = (tiles + 3) / 4;
+        hipLaunchKernelGGL((fused_update_kernel<R, RG, false>), dim3(gru_blocks + tiles), dim3(256), lds, s, m, g, gru_blocks, tiles);
+    }
     return hipGetLastError();
 }
 
@@ -161,5 +176,11 @@ hipError_t launch_clear(const ClearArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(clear_kernel, dim3(a.n_streams), dim3(64), 0, s, a);
     return hipGetLastError();
 }
+
+#ifdef PE_SECTION_TIMERS
+extern "C" int pe_debug_read_timers(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pe_dbg_timers), sizeof(unsigned long long) * (n < 32 ? n : 32));
+}
+#endif
 
 }  // namespace pe

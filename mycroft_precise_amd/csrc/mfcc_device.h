@@ -25,6 +25,15 @@
 
 namespace pe {
 
+// Section timers for the tuning harness (tools/mfcc_sections.py builds a -DPE_SECTION_TIMERS copy of
+// the library); compiled out of the product.
+#ifdef PE_SECTION_TIMERS
+__device__ unsigned long long pe_dbg_timers[32];
+#define PE_T(i) do { if (threadIdx.x == 0 && blockIdx.x + 1 == gridDim.x) pe_dbg_timers[i] = clock64(); } while (0)
+#else
+#define PE_T(i) do { } while (0)
+#endif
+
 template <class R> struct RealK;
 template <> struct RealK<double> {
     static constexpr double C1 = 0.92387953251128673848;   // cos(pi/8)
@@ -48,12 +57,12 @@ __device__ __forceinline__ float real_log(float x) { return logf(x); }
 __device__ __forceinline__ double real_fma(double a, double b, double c) { return fma(a, b, c); }
 __device__ __forceinline__ float real_fma(float a, float b, float c) { return fmaf(a, b, c); }
 
-// LDS traffic inside one wave is executed in program order by the hardware; these fences only
-// keep the compiler from moving DS operations across the hand-off and make it wait for them.
+// LDS instructions of one wave execute in program order, so a hand-off between lanes of the same
+// wave needs no counter wait -- only the compiler must not move DS accesses across it.
 __device__ __forceinline__ void group_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    asm volatile("" ::: "memory");
 }
 
 // (a + ib) *= W16^M,  W16 = exp(-2 pi i / 16);  only the exponents a 4x4 split needs.
@@ -117,60 +126,52 @@ struct LdsTab {
     const cplx<R>* tw256;
     const cplx<R>* w512;
     const R* dct;
-    const R* mel_w;
-    const int* mel_start;
-    const int* mel_off;
+    const R* mel_w;         // [2][17][16]
+    const int* mel_flush;   // [17][16]
+    const int* mel_pstart;  // [n_filt + 1]
 };
 
-constexpr int kTrStride = 17;                       // padded row of the 16x16 LDS transpose
-constexpr int kGroupScratch = 16 * kTrStride + kMaxFilt;   // transpose / power buffer + log-mels
-
-__host__ __device__ inline size_t lds_layout_bytes(int real_size, int n_filt, int n_mfcc, int mel_nnz) {
-    size_t b = 0;
-    b += 256 * 2 * (size_t)real_size;               // tw256
-    b += 130 * 2 * (size_t)real_size;               // w512 (129 used)
-    b += (size_t)n_mfcc * n_filt * real_size;       // dct
-    b += (size_t)mel_nnz * real_size;               // mel_w
-    b = (b + 15) & ~(size_t)15;
-    b += ((size_t)(2 * n_filt + 1) * sizeof(int) + 15) & ~(size_t)15;
-    b += (size_t)16 * kGroupScratch * real_size;    // 16 groups per workgroup
-    return b;
-}
-
+// Copy the blob with 16-byte loads (all of a thread's loads in flight before its first store), and
+// carve the pointers.  The caller issues __syncthreads() when it needs the tables.
 template <class R>
 __device__ __forceinline__ R* lds_setup(unsigned char* smem, const MfccTables<R>& g, int n_filt, int n_mfcc,
                                         LdsTab<R>& t) {
+    const int n16 = g.blob_bytes >> 4;
+    const uint4* src = reinterpret_cast<const uint4*>(g.blob);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    const int tid = threadIdx.x;
+    const int i0 = tid, i1 = tid + 256, i2 = tid + 512, i3 = tid + 768;
+    uint4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
+    if (i0 < n16) v0 = src[i0];
+    if (i1 < n16) v1 = src[i1];
+    if (i2 < n16) v2 = src[i2];
+    if (i3 < n16) v3 = src[i3];
+    if (i0 < n16) dst[i0] = v0;
+    if (i1 < n16) dst[i1] = v1;
+    if (i2 < n16) dst[i2] = v2;
+    if (i3 < n16) dst[i3] = v3;
+    for (int i = tid + 1024; i < n16; i += 256) dst[i] = src[i];
     cplx<R>* tw = reinterpret_cast<cplx<R>*>(smem);
     cplx<R>* w5 = tw + 256;
     R* dct = reinterpret_cast<R*>(w5 + 130);
     R* mw = dct + n_mfcc * n_filt;
-    size_t off = (size_t)((unsigned char*)(mw + g.mel_nnz) - smem);
+    size_t off = (size_t)((unsigned char*)(mw + 2 * kMelSteps * 16) - smem);
     off = (off + 15) & ~(size_t)15;
-    int* ms = reinterpret_cast<int*>(smem + off);
-    int* mo = ms + n_filt;
-    off += ((size_t)(2 * n_filt + 1) * sizeof(int) + 15) & ~(size_t)15;
-    R* scratch = reinterpret_cast<R*>(smem + off);
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int i = tid; i < 256; i += nt) tw[i] = g.tw256[i];
-    for (int i = tid; i < 129; i += nt) w5[i] = g.w512[i];
-    for (int i = tid; i < n_mfcc * n_filt; i += nt) dct[i] = g.dct[i];
-    for (int i = tid; i < g.mel_nnz; i += nt) mw[i] = g.mel_w[i];
-    for (int i = tid; i < n_filt; i += nt) ms[i] = g.mel_start[i];
-    for (int i = tid; i <= n_filt; i += nt) mo[i] = g.mel_off[i];
-    t.tw256 = tw; t.w512 = w5; t.dct = dct; t.mel_w = mw; t.mel_start = ms; t.mel_off = mo;
-    __syncthreads();
-    return scratch;
+    int* fl = reinterpret_cast<int*>(smem + off);
+    t.tw256 = tw; t.w512 = w5; t.dct = dct; t.mel_w = mw; t.mel_flush = fl; t.mel_pstart = fl + kMelSteps * 16;
+    return reinterpret_cast<R*>(smem + g.blob_bytes);
 }
 
 // One frame on one 16-lane group.  `load(c, xr, xi)` returns samples 32c+2r and 32c+2r+1 of the
-// frame (already scaled to [-1,1), zero beyond frame_len).  Returns coefficient r in lane r
-// (lanes >= n_mfcc return 0).  S: this group's LDS scratch (kGroupScratch reals).
+// frame (already scaled to [-1,1), zero beyond frame_len; typically from registers loaded earlier).
+// Returns coefficient r in lane r (lanes >= n_mfcc return 0).  S: this group's LDS scratch.
 template <class R, class Load>
 __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_filt, int n_mfcc, Load load) {
     using K = RealK<R>;
     R re[16], im[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) load(c, re[c], im[c]);
+    PE_T(2);
 
     // pass 1: lane r transforms z[16c + r] over c -> Y_r[k1]; twiddle by W256^(r k1)
     fft16(re, im);
@@ -181,6 +182,7 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
         re[k1] = a * w.x - b * w.y;
         im[k1] = a * w.y + b * w.x;
     }
+    PE_T(3);
     // 16x16 transpose through LDS (row stride 17 reals: conflict-free both ways), re then im
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) S[k1 * kTrStride + r] = re[k1];
@@ -195,8 +197,10 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
     for (int c = 0; c < 16; ++c) im[c] = S[r * kTrStride + c];
     group_sync();
 
+    PE_T(4);
     // pass 2: lane k1 (= r) transforms over the former lane index -> Z[k1 + 16 k2] in element k2
     fft16(re, im);
+    PE_T(5);
 
     // real-FFT split needs Z[256 - p]: it lives in lane (16 - r) & 15, upper half of its registers
 #pragma unroll
@@ -215,6 +219,7 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
     if (r == 0) { qre[0] = re[0]; qim[0] = im[0]; }
     group_sync();
 
+    PE_T(6);
     // X[p] = E + W512^p O, X[256-p] = conj(E - W512^p O);  power = |X|^2 / 512
     R psum = R(0);
 #pragma unroll
@@ -228,37 +233,86 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
         const R x1r = er + tr, x1i = ei + ti, x2r = er - tr, x2i = ei - ti;
         const R p1 = (x1r * x1r + x1i * x1i) * K::INV_FFT;
         const R p2 = (x2r * x2r + x2i * x2i) * K::INV_FFT;
-        S[p] = p1;
-        S[256 - p] = p2;
+        const int pm = 256 - p;
+        S[p + (p >> 4)] = p1;
+        S[pm + (pm >> 4)] = p2;
         psum += p1 + p2;
     }
     if (r == 0) {
         const R p128 = (re[8] * re[8] + im[8] * im[8]) * K::INV_FFT;
-        S[128] = p128;
+        S[128 + 8] = p128;
         psum += p128;
     }
 #pragma unroll
     for (int o = 8; o >= 1; o >>= 1) psum += __shfl_xor(psum, o, 16);
     group_sync();
 
-    // sparse triangular mel filters, then log(clip)
-    R* LM = S + 16 * kTrStride;
+    PE_T(7);
+    // Sparse mel filterbank.  Every bin feeds at most two (neighbouring, triangular) filters, so the
+    // pass runs over BINS: lane r walks bins 16r .. 16r+16 (stride-17 layout: no bank conflicts),
+    // keeps one running sum per "stream" (1st / 2nd filter of the bin) and drops it into a partial
+    // slot whenever the table says the filter under that stream changes.  Slots are numbered filter
+    // by filter, so the second pass adds a contiguous range in a fixed order.
+    R* LM = S + kPowerPad;
+    R* PART = LM + kMaxFilt;
+    {
+        R acc0 = R(0), acc1 = R(0);
+#pragma unroll
+        for (int i = 0; i < kMelSteps; ++i) {
+            const R pw = S[kTrStride * r + i + (i >> 4)];      // padded index of bin 16 r + i
+            acc0 = real_fma(t.mel_w[i * 16 + r], pw, acc0);
+            acc1 = real_fma(t.mel_w[(kMelSteps + i) * 16 + r], pw, acc1);
+            // no branch: a step that ends no run stores to the spare slot and keeps its sum
+            const int fl = t.mel_flush[i * 16 + r];
+            const int s0 = fl & 0xffff, s1 = (fl >> 16) & 0xffff;
+            PART[s0 != 0xffff ? s0 : kMaxMelParts - 1] = acc0;
+            PART[s1 != 0xffff ? s1 : kMaxMelParts - 1] = acc1;
+            acc0 = s0 != 0xffff ? R(0) : acc0;
+            acc1 = s1 != 0xffff ? R(0) : acc1;
+        }
+    }
+    group_sync();
     for (int f = r; f < n_filt; f += 16) {
-        const int start = t.mel_start[f], o0 = t.mel_off[f], len = t.mel_off[f + 1] - o0;
+        const int p0 = t.mel_pstart[f], np = t.mel_pstart[f + 1] - p0;
         R acc = R(0);
-        for (int i = 0; i < len; ++i) acc = real_fma(t.mel_w[o0 + i], S[start + i], acc);
+        for (int i0 = 0; i0 < np; i0 += 4) {
+            R v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (i0 + u < np) ? PART[p0 + i0 + u] : R(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u];
+        }
+        LM[f] = acc;
+    }
+    PE_T(18);
+    for (int f = r; f < n_filt; f += 16) {
+        const R acc = LM[f];
         LM[f] = real_log(acc > K::EPS ? acc : K::EPS);
     }
     group_sync();
 
+    PE_T(8);
     // DCT-II (ortho) rows 0..n_mfcc-1; row 0 replaced by log total power
     R coeff = R(0);
     if (r < n_mfcc) {
         const R* drow = t.dct + r * n_filt;
-        for (int jf = 0; jf < n_filt; ++jf) coeff = real_fma(drow[jf], LM[jf], coeff);
+        for (int j0 = 0; j0 < n_filt; j0 += 4) {
+            R dv[4], lv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jf = j0 + u;
+                const int jc = jf < n_filt ? jf : n_filt - 1;
+                dv[u] = drow[jc];
+                lv[u] = LM[jc];
+                if (jf >= n_filt) dv[u] = R(0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) coeff = real_fma(dv[u], lv[u], coeff);
+        }
         if (r == 0) coeff = real_log(psum > K::EPS ? psum : K::EPS);
     }
     group_sync();
+    PE_T(9);
     return coeff;
 }
 
@@ -285,72 +339,117 @@ struct PcmView {
 // One workgroup (256 threads) = one tile of 16 streams.  Reads the stream state of this update
 // (st_*), writes the state after it (st_*_next): the two may alias only when no other role reads
 // the old state concurrently.
+//
+// Latency plan (this stage is a dependent chain per workgroup, so global-memory round trips are
+// what is worth hiding): counters -> PCM of the first frame and of the leftover are requested
+// before the 12 KB table image is copied to LDS; the next frame's PCM is requested while the
+// current frame is transformed.
 template <class R>
 __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, const int tile, unsigned char* smem) {
     using K = RealK<R>;
     const StreamGeom& geo = a.geo;
-    LdsTab<R> tab;
-    R* scratch = lds_setup<R>(smem, a.tab, geo.n_filt, geo.n_mfcc, tab);
-
+    PE_T(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, r = lane & 15;
     const int j = wave * 4 + grp;                           // stream within the tile
     const long long s = (long long)tile * kTileStreams + j;
-    if (s >= geo.n_streams) return;
-    R* S = scratch + (wave * 4 + grp) * kGroupScratch;
+    const bool active = s < geo.n_streams;
+    const long long sc = active ? s : 0;                    // padded lanes shadow stream 0 (loads only)
 
-    const int q = a.st_q[s];
-    const uint32_t kc = a.st_kc[s];
-    uint32_t ke = a.st_ke[s];
     const int C = a.chunk, hop = geo.hop, flen = geo.frame_len;
+    const int q = a.st_q[sc];
+    const uint32_t kc = a.st_kc[sc];
+    uint32_t ke = a.st_ke[sc];
+    // Touch this stream's chunk (one dword per 128-byte line) and carry while the counters are on
+    // their way: the counter-dependent sample loads below then merge with / hit these lines instead
+    // of starting their own HBM round trip.  The values are never used.
+    {
+        const int16_t* row0 = a.pcm + (size_t)sc * C;
+        const int16_t* car0 = a.carry + (size_t)sc * kCarryCap;
+        for (int line = r * 64; line < C; line += 16 * 64) (void)*reinterpret_cast<const volatile int16_t*>(row0 + line);
+        if (r < 8) (void)*reinterpret_cast<const volatile int16_t*>(car0 + r * 64);
+    }
     const int avail = q + C;                                 // virtual samples now available
-    const int nnew = avail >= flen ? 1 + (avail - flen) / hop : 0;
+    const int nnew = (active && avail >= flen) ? 1 + (avail - flen) / hop : 0;
+    const int qn = avail - nnew * hop;                       // leftover after this update (< flen)
 
     PcmView pv;
-    pv.row = a.pcm + (size_t)s * C;
-    pv.car = a.carry + (size_t)s * kCarryCap;
+    pv.row = a.pcm + (size_t)sc * C;
+    pv.car = a.carry + (size_t)sc * kCarryCap;
     pv.q = q;
     pv.pairs = a.pcm_pairs_ok && ((q & 1) == 0);
 
+    // samples [vb, vb + limit) of the virtual stream as int16 pairs, 32c + 2r per lane
+    auto fetch = [&](int vb, int limit, int (&dst)[16]) {
+        if (pv.pairs && ((vb | limit) & 1) == 0) {
+            // aligned case: sixteen unconditional dword loads (addresses clamped, results masked)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int n = 32 * c + 2 * r;
+                const int v = vb + (n < limit ? n : 0);
+                const int16_t* p = (v < q) ? (pv.car + v) : (pv.row + (v - q));
+                const int val = *reinterpret_cast<const int*>(p);
+                dst[c] = n < limit ? val : 0;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int n = 32 * c + 2 * r;
+                dst[c] = (n < limit) ? pv.pair(vb + n, n + 1 < limit) : 0;
+            }
+        }
+    };
+    int cur[16], left[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { cur[c] = 0; left[c] = 0; }
     const int slots = geo.ring_slots;
+    // frames that would be overwritten before anyone reads them (huge chunks) are skipped
+    const int f_first = nnew > slots ? nnew - slots : 0;
+    if (nnew > 0) fetch(f_first * hop, flen, cur);
+    if (active && qn > 0) fetch(nnew * hop, qn, left);       // new leftover, read before any carry store
+
+    LdsTab<R> tab;
+    R* scratch = lds_setup<R>(smem, a.tab, geo.n_filt, geo.n_mfcc, tab);
+    __syncthreads();
+    PE_T(1);
+    if (!active) return;
+    R* S = scratch + (wave * 4 + grp) * kGroupScratch;
     float* ring_rows = a.ring + ((size_t)tile * slots * kTileStreams + j) * kRowFloats;
 
-    for (int f = 0; f < nnew; ++f) {
-        if (nnew - f > slots) continue;                      // would be overwritten before anyone reads it
-        const int vb = f * hop;
+    float last_row = 0.0f;                                   // the final frame's ring store is issued
+    int last_slot = -1;                                      // after the carry stores (see below)
+    for (int f = f_first; f < nnew; ++f) {
         auto load = [&](int c, R& xr, R& xi) {
-            const int n = 32 * c + 2 * r;
-            int pr = 0;
-            if (n < flen) pr = pv.pair(vb + n, n + 1 < flen);
-            xr = (R)(int)(short)(pr & 0xffff) * K::INV_I16;
-            xi = (R)(pr >> 16) * K::INV_I16;
+            xr = (R)(int)(short)(cur[c] & 0xffff) * K::INV_I16;
+            xi = (R)(cur[c] >> 16) * K::INV_I16;
         };
         const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load);
         const uint32_t k = kc + (uint32_t)f;
         const int slot = (int)(k & (uint32_t)(slots - 1));
-        ring_rows[(size_t)slot * kTileStreams * kRowFloats + r] = (r < geo.n_mfcc) ? (float)coeff : 0.0f;
+        const float row = (r < geo.n_mfcc) ? (float)coeff : 0.0f;
+        if (f + 1 < nnew) {
+            ring_rows[(size_t)slot * kTileStreams * kRowFloats + r] = row;
+            fetch((f + 1) * hop, flen, cur);                 // L2-resident: the whole chunk was touched
+        } else {
+            last_row = row;
+            last_slot = slot;
+        }
     }
 
-    // leftover: virtual samples [nnew*hop, avail) become the new carry (< frame_len of them)
-    const int qn = avail - nnew * hop;
+    PE_T(10);
+    // leftover: virtual samples [nnew*hop, avail) become the new carry
     if (qn > 0) {
-        const int vs = nnew * hop;
         int16_t* carw = a.carry + (size_t)s * kCarryCap;
-        int buf[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int n = 32 * c + 2 * r;
-            buf[c] = (n < qn) ? pv.pair(vs + n, n + 1 < qn) : 0;
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every read of the old carry has landed
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int n = 32 * c + 2 * r;
-            if (n + 1 < qn) *reinterpret_cast<int*>(carw + n) = buf[c];
-            else if (n < qn) carw[n] = (int16_t)(buf[c] & 0xffff);
+            if (n + 1 < qn) *reinterpret_cast<int*>(carw + n) = left[c];
+            else if (n < qn) carw[n] = (int16_t)(left[c] & 0xffff);
         }
     }
+    if (last_slot >= 0) ring_rows[(size_t)last_slot * kTileStreams * kRowFloats + r] = last_row;
     if (r == 0) {
         const uint32_t kcn = kc + (uint32_t)nnew;
         // frame k becomes visible once a whole window [k*hop, k*hop + window) has arrived:
@@ -361,6 +460,7 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
         a.st_kc_next[s] = kcn;
         a.st_ke_next[s] = ke;
     }
+    PE_T(11);
 }
 
 // ---- stateless whole-buffer form (vectorize_raw) ----------------------------------------------
@@ -369,6 +469,7 @@ __device__ __forceinline__ void mfcc_offline_block(const MfccOfflineArgs<R>& a, 
     const StreamGeom& geo = a.geo;
     LdsTab<R> tab;
     R* scratch = lds_setup<R>(smem, a.tab, geo.n_filt, geo.n_mfcc, tab);
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, r = lane & 15;
     const long long fr = (long long)blockIdx.x * 16 + wave * 4 + grp;

@@ -13,22 +13,46 @@ constexpr int kCarryCap = 512;      // int16 samples of leftover PCM kept per st
 constexpr int kNfft = 512;          // the only FFT size with a kernel
 constexpr int kBins = kNfft / 2 + 1;
 constexpr int kMaxFilt = 64;
-constexpr int kMaxMelNnz = 1024;
 
 template <class R> struct cplx { R x, y; };
+
+constexpr int kTrStride = 17;                       // padded row of the 16x16 LDS transpose
+constexpr int kPowerPad = 16 * kTrStride + 2;       // power spectrum, bin b at b + (b >> 4)
+constexpr int kMelSteps = 17;                       // bins per lane in the mel pass: 16 r .. 16 r + 16
+constexpr int kMaxMelParts = 128;                   // partial filter sums per frame
+constexpr int kGroupScratch = kPowerPad + kMaxFilt + kMaxMelParts;   // reals of LDS per 16-lane group
+
+// The constant tables live in ONE device blob laid out exactly as they sit in LDS:
+//   [tw256: 256 cplx][w512: 130 cplx][dct: n_mfcc*n_filt R][mel_w: 2*17*16 R][pad16]
+//   [mel_flush: 17*16 int][mel_pstart: n_filt+1 int][pad16]          (engine.hip: build_tables)
+__host__ __device__ inline size_t table_blob_bytes(int real_size, int n_filt, int n_mfcc) {
+    size_t b = 0;
+    b += 256 * 2 * (size_t)real_size;
+    b += 130 * 2 * (size_t)real_size;
+    b += (size_t)n_mfcc * n_filt * real_size;
+    b += (size_t)2 * kMelSteps * 16 * real_size;
+    b = (b + 15) & ~(size_t)15;
+    b += ((size_t)(kMelSteps * 16 + n_filt + 1) * sizeof(int) + 15) & ~(size_t)15;
+    return b;
+}
+
+__host__ __device__ inline size_t lds_layout_bytes(int real_size, int n_filt, int n_mfcc) {
+    return table_blob_bytes(real_size, n_filt, n_mfcc) + (size_t)16 * kGroupScratch * real_size;
+}
 
 // ---------------------------------------------------------------------------------------
 // MFCC front end (vectorization.py:36-39 -> sonopy.mfcc_spec), streaming form
 // ---------------------------------------------------------------------------------------
 template <class R>
 struct MfccTables {
-    const cplx<R>* tw256;   // [16 k1][16 r]  exp(-2 pi i r k1 / 256)
-    const cplx<R>* w512;    // [129]          exp(-2 pi i p / 512)
-    const R* mel_w;         // [nnz]   filter weights, filter-major, zero weights trimmed
-    const int* mel_start;   // [n_filt] first bin of each filter's support
-    const int* mel_off;     // [n_filt+1] offsets into mel_w
-    const R* dct;           // [n_mfcc][n_filt]  DCT-II, norm='ortho'
-    int mel_nnz;
+    // one device blob laid out exactly as the tables sit in LDS (table_blob_bytes above):
+    //   tw256 [16 k1][16 r] exp(-2 pi i r k1 / 256) | w512 [130] exp(-2 pi i p / 512) |
+    //   dct [n_mfcc][n_filt] (DCT-II ortho) |
+    //   mel_w [2 streams][17 steps][16 lanes]: weight of bin 16 r + i in its 1st / 2nd filter |
+    //   mel_flush [17][16]: lo/hi 16 bits = partial-sum slot to write after that step (0xffff: none) |
+    //   mel_pstart [n_filt+1]: partial-sum slots of filter f are [pstart[f], pstart[f+1])
+    const void* blob;
+    int blob_bytes;
 };
 
 struct StreamGeom {
@@ -100,6 +124,7 @@ struct GruArgs {
     // ... or an explicit [n][T][F] float32 batch (Runner.predict)
     const float* feats;
     float* out;             // [n_streams]
+    int waves_per_tile;     // 1: one wave per tile (gru_tile);  4: four waves share a tile (gru_tile_mw)
 };
 
 struct GatherArgs {         // ring -> [n][T][F] time-ordered features (update_vectors result)
@@ -126,7 +151,6 @@ hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const GruArgs& g, h
 hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const GruArgs& g, hipStream_t s);
 hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, hipStream_t s);
 hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, hipStream_t s);
-size_t mfcc_lds_bytes(int real_size, int n_filt, int n_mfcc, int mel_nnz);
 hipError_t launch_gru_small(const GruArgs& a, bool from_ring, hipStream_t s);   // units <= 32
 int gru_small_regs(int units);                  // R = ceil(units/4)
 int gru_small_tiles(int units);                 // NT = ceil(3R/4)

@@ -172,6 +172,27 @@ def test_fused_launch_equals_two_dependent_launches(stock_weights):
         assert np.array_equal(a.engine.get_vectors(), b.engine.get_vectors())
 
 
+def test_gru_kernel_shapes_agree_bitwise(stock_weights):
+    """pe_set_gru_waves: one wave per tile vs four waves sharing a tile issue the same MFMAs in the
+    same order per output element, so they must agree bit for bit (fused and unfused)."""
+    from mycroft_precise_amd.network_runner import BatchedListener
+    n, n_up = 50, 40
+    pcm = _stream_batch(['tone_noise'] * (n - 3) + ['zeros', 'square', 'quiet'], n_up)
+    engines = []
+    for fused in (True, False):
+        for waves in (1, 4):
+            b = BatchedListener(stock_weights, n)
+            b.engine.set_fused(fused)
+            b.engine.set_gru_waves(waves)
+            engines.append(b)
+    for u in range(n_up):
+        outs = [b.update_raw(pcm[u]) for b in engines]
+        for o in outs[1:]:
+            assert np.array_equal(o, outs[0]), u
+    with pytest.raises(ValueError):
+        engines[0].engine.set_gru_waves(3)
+
+
 def test_update_vectors_and_masked_clear_desynchronise_streams(stock_weights):
     """pe_clear(mask) restarts some streams mid-way: afterwards streams of one tile sit at
     different positions of their feature rings; each must still match its own oracle."""
