@@ -196,6 +196,19 @@ def main():
     fused_ms, _ = timed_pass(True)              # the launch the timed region used: MFCC || GRU roles
     mfcc_ms, gru_ms = timed_pass(False)         # the two roles as separate dependent launches
 
+    def pmc_traffic(kernel):
+        """HBM bytes per launch from the committed rocprofv3 PMC summary (bench.py cannot collect PMC
+        counters itself); None when the profile is missing or was taken at another batch size."""
+        try:
+            with open(os.path.join(REPO, 'profiles', 'pmc_latest.json')) as f:
+                pmc = json.load(f)
+            if pmc.get('streams') != B:
+                return None
+            k = pmc[kernel]
+            return (k['fetch_kb'] + k['write_kb']) * 1024.0
+        except (OSError, KeyError, ValueError):
+            return None
+
     if rank == 0:
         value = n_global * steps / elapsed
         def tflops(ms):
@@ -219,19 +232,21 @@ def main():
             'realtime_streams': value / REALTIME_WINDOWS_PER_S,
             'outputs_finite': finite,
             # dominant kernel of the timed region: the fused launch (GRU role is its long pole)
-            'roofline': {'kernel': 'fused_update_kernel<%s,5>' % mfcc_name, 'bound': 'mfma',
+            'roofline': {'kernel': 'fused_update_kernel<%s,5,true>' % mfcc_name, 'bound': 'mfma',
                          'achieved': tflops(fused_ms), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': tflops(fused_ms) / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                         'frac': tflops(fused_ms) / MFMA_F32_PEAK_TFLOPS,
+                         'traffic': pmc_traffic('fused_update_kernel'), 'traffic_unit': 'bytes/launch (PMC, profiles/pmc_latest.json)',
                          'avg_launch_ms': fused_ms,
                          'algorithmic': '%d flop/window x %d windows/launch' % (GRU_FLOP_PER_WINDOW, B)},
             # the two roles launched separately (pe_set_fused(0)), for the per-stage picture
-            'roofline_gru': {'kernel': 'gru_small_kernel<5>', 'bound': 'mfma', 'achieved': tflops(gru_ms),
+            'roofline_gru': {'kernel': 'gru_mw_kernel<5>', 'bound': 'mfma', 'achieved': tflops(gru_ms),
                              'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                             'frac': tflops(gru_ms) / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                             'frac': tflops(gru_ms) / MFMA_F32_PEAK_TFLOPS, 'traffic': pmc_traffic('gru_mw_kernel'),
                              'avg_launch_ms': gru_ms},
             'roofline_mfcc': {'kernel': 'mfcc_stream_kernel<%s>' % mfcc_name, 'bound': 'hbm',
                               'achieved': gbs(mfcc_ms), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                              'frac': gbs(mfcc_ms) / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': mfcc_ms,
+                              'frac': gbs(mfcc_ms) / HBM_PEAK_GBS, 'traffic': pmc_traffic('mfcc_stream_kernel'),
+                              'avg_launch_ms': mfcc_ms,
                               'algorithmic': '%.1f B/window x %d windows/launch' % (MFCC_BYTES_PER_WINDOW, B)},
         }
         if cpu is not None:
