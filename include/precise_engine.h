@@ -120,6 +120,15 @@ int pe_predict_device(pe_engine* e, const float* feats_dev, int32_t n, float* ou
 int pe_vectorize_raw(pe_engine* e, const double* audio_host, int64_t n_samples,
                      double* feats_out_host, int64_t max_frames, int64_t* n_frames_out);
 
+/* The reference's batched offline evaluation (precise/scripts/simulate.py:92-104, also
+ * annoyance_estimator.py:114-130): MFCC of one whole recording, one network input per hop_frames
+ * (= chunk_size // hop_samples) frames -- windows ending at frame i for i in range(n_features,
+ * n_frames, hop_frames) -- all predicted in one batch.  out[n_windows] raw outputs; nothing of the
+ * [n_windows][T][F] batch is materialised: the network reads overlapping windows of one row
+ * sequence.  Stateless (the engine's streams are untouched). */
+int pe_evaluate(pe_engine* e, const double* audio_host, int64_t n_samples, int32_t hop_frames,
+                float* out_host, int64_t max_windows, int64_t* n_windows_out);
+
 /* Introspection used by tests and the bench. */
 typedef struct pe_info {
     int32_t n_streams, n_features, n_mfcc, units, n_layers, ring_slots, carry_capacity;

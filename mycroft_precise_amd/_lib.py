@@ -58,6 +58,8 @@ EXPORTS = {
     'pe_predict_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'pe_vectorize_raw': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                    C.POINTER(C.c_int64)]),
+    'pe_evaluate': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
+                              C.POINTER(C.c_int64)]),
     'pe_get_info': (C.c_int, [C.c_void_p, C.POINTER(PeInfo)]),
     'pe_get_stream_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pe_set_fused': (C.c_int, [C.c_void_p, C.c_int32]),
@@ -232,6 +234,19 @@ class HipEngine:
         n = C.c_int64(0)
         self._check(self._lib.pe_vectorize_raw(self._h, audio.ctypes.data if audio.size else None, audio.size,
                                                out.ctypes.data if max_frames else None, max_frames, C.byref(n)))
+        return out[:n.value]
+
+    def evaluate(self, audio, hop_frames: int) -> np.ndarray:
+        """Whole recording (float64 audio) -> raw outputs [n_windows, 1] of the windows ending at frames
+        range(T, n_frames, hop_frames): simulate.py:92-104 in one call."""
+        audio = np.ascontiguousarray(audio, dtype=np.float64).reshape(-1)
+        win, hop = self._win_hop
+        n_frames = 1 + (audio.size - win) // hop if audio.size >= win else 0
+        n_win = max(0, -(-(n_frames - self.n_features) // int(hop_frames))) if n_frames > self.n_features else 0
+        out = np.empty((n_win, 1), dtype=np.float32)
+        n = C.c_int64(0)
+        self._check(self._lib.pe_evaluate(self._h, audio.ctypes.data if audio.size else None, audio.size,
+                                          int(hop_frames), out.ctypes.data if n_win else None, n_win, C.byref(n)))
         return out[:n.value]
 
     def clear(self, mask=None):

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -308,7 +309,7 @@ GruArgs gru_args(const pe_engine* e) {
     a.chunk = 0;
     a.window = e->prm.window_samples; a.hop = e->prm.hop_samples;
     a.frame_len = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
-    a.feats = nullptr; a.out = nullptr;
+    a.feats = nullptr; a.out = nullptr; a.row_stride = 0;
     a.waves_per_tile = e->gru_waves ? e->gru_waves : (e->n_tiles <= 1024 ? 4 : 1);
     return a;
 }
@@ -316,7 +317,7 @@ GruArgs gru_args(const pe_engine* e) {
 int launch_gru_ring(pe_engine* e, float* out_dev, hipStream_t s) {
     GruArgs a = gru_args(e);
     a.out = out_dev;
-    PE_HIP(e, launch_gru_small(a, true, s));
+    PE_HIP(e, launch_gru_small(a, 1, s));
     return PE_OK;
 }
 
@@ -535,7 +536,7 @@ int pe_predict_device(pe_engine* e, const float* feats_dev, int32_t n, float* ou
     a.waves_per_tile = 1;
     a.feats = feats_dev;
     a.out = out_dev;
-    PE_HIP(e, launch_gru_small(a, false, static_cast<hipStream_t>(stream)));
+    PE_HIP(e, launch_gru_small(a, 0, static_cast<hipStream_t>(stream)));
     return PE_OK;
 }
 
@@ -570,13 +571,51 @@ int pe_vectorize_raw(pe_engine* e, const double* audio_host, int64_t n_samples, 
     if ((rc = ensure(e, e->st_mfcc, fb))) return rc;
     PE_HIP(e, hipMemcpy(e->st_audio.p, audio_host, ab, hipMemcpyHostToDevice));
     if (e->prm.mfcc_precision == 0) {
-        MfccOfflineArgs<double> a{geom(e), tables<double>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, static_cast<double*>(e->st_mfcc.p)};
+        MfccOfflineArgs<double> a{geom(e), tables<double>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, static_cast<double*>(e->st_mfcc.p), nullptr};
         PE_HIP(e, launch_mfcc_offline_f64(a, nullptr));
     } else {
-        MfccOfflineArgs<float> a{geom(e), tables<float>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, static_cast<double*>(e->st_mfcc.p)};
+        MfccOfflineArgs<float> a{geom(e), tables<float>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, static_cast<double*>(e->st_mfcc.p), nullptr};
         PE_HIP(e, launch_mfcc_offline_f32(a, nullptr));
     }
     PE_HIP(e, hipMemcpy(feats_out_host, e->st_mfcc.p, fb, hipMemcpyDeviceToHost));
+    return PE_OK;
+}
+
+int pe_evaluate(pe_engine* e, const double* audio_host, int64_t n_samples, int32_t hop_frames, float* out_host,
+                int64_t max_windows, int64_t* n_windows_out) {
+    if (!e || !n_windows_out) return fail(e, PE_ERR_INVALID, "null argument to pe_evaluate");
+    if (hop_frames < 1) return fail(e, PE_ERR_INVALID, "hop_frames must be >= 1 (chunk_size // hop_samples)");
+    if (n_samples < 0 || (n_samples > 0 && !audio_host)) return fail(e, PE_ERR_INVALID, "bad audio buffer");
+    const int64_t win = e->prm.window_samples, hop = e->prm.hop_samples, T = e->prm.n_features;
+    const int64_t n_frames = n_samples >= win ? 1 + (n_samples - win) / hop : 0;
+    // simulate.py:96-99: windows end at frame i for i in range(T, n_frames, hop_frames)
+    const int64_t n_windows = n_frames > T ? (n_frames - T + hop_frames - 1) / hop_frames : 0;
+    *n_windows_out = n_windows;
+    if (n_windows == 0) return PE_OK;
+    if (!out_host || max_windows < n_windows) return fail(e, PE_ERR_INVALID, "output holds %lld windows, need %lld", (long long)max_windows, (long long)n_windows);
+    if (n_windows > 0x7fffffff) return fail(e, PE_ERR_INVALID, "too many windows");
+    PE_HIP(e, hipSetDevice(e->device));
+    int rc;
+    const size_t ab = (size_t)n_samples * sizeof(double), rb = (size_t)n_frames * kRowFloats * sizeof(float);
+    if ((rc = ensure(e, e->st_audio, ab))) return rc;
+    if ((rc = ensure(e, e->st_feats, rb))) return rc;
+    if ((rc = ensure(e, e->st_out, (size_t)n_windows * sizeof(float)))) return rc;
+    PE_HIP(e, hipMemcpy(e->st_audio.p, audio_host, ab, hipMemcpyHostToDevice));
+    if (e->prm.mfcc_precision == 0) {
+        MfccOfflineArgs<double> a{geom(e), tables<double>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, nullptr, static_cast<float*>(e->st_feats.p)};
+        PE_HIP(e, launch_mfcc_offline_f64(a, nullptr));
+    } else {
+        MfccOfflineArgs<float> a{geom(e), tables<float>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, nullptr, static_cast<float*>(e->st_feats.p)};
+        PE_HIP(e, launch_mfcc_offline_f32(a, nullptr));
+    }
+    GruArgs g = gru_args(e);
+    g.n_streams = (int)n_windows;
+    g.feats = static_cast<const float*>(e->st_feats.p);
+    g.row_stride = hop_frames;
+    g.out = static_cast<float*>(e->st_out.p);
+    g.waves_per_tile = 1;
+    PE_HIP(e, launch_gru_small(g, 2, nullptr));
+    PE_HIP(e, hipMemcpy(out_host, e->st_out.p, (size_t)n_windows * sizeof(float), hipMemcpyDeviceToHost));
     return PE_OK;
 }
 

@@ -49,9 +49,18 @@ template <int R> struct GruShape {
     static constexpr int NP2 = NT - P2_BEGIN;
 };
 
+// Where a wave's timestep inputs come from.
+enum GruInput {
+    kFeats = 0,     // explicit [n][T][F] float32 batch                       (Runner.predict)
+    kRing = 1,      // the streaming feature ring + per-stream frame counters (Listener.update)
+    kRows = 2       // one long [n_frames][16] float32 feature sequence, window w = rows
+                    // [w*stride, w*stride + T)                               (simulate.py:92-104)
+};
+
 // One wave = one tile of 16 streams, whole window, weights resident in registers.
-template <int R, bool FROM_RING>
+template <int R, int MODE>
 __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const int lane) {
+    constexpr bool FROM_RING = MODE == kRing;
     using G = GruShape<R>;
     const int g = lane >> 4, j = lane & 15;
     const long long stream = (long long)tile * kTileStreams + j;
@@ -98,6 +107,9 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
         }
         first = ke - (uint32_t)T;
         xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats + 4 * g;
+    } else if (MODE == kRows) {
+        const long long w = valid ? stream : 0;               // padded lanes shadow window 0
+        xbase = a.feats + ((size_t)w * a.row_stride) * kRowFloats + 4 * g;
     } else {
         xbase = a.feats + (size_t)stream * T * a.n_in;
     }
@@ -108,6 +120,10 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
             const int tc = t < T ? t : T - 1;
             const uint32_t slot = (first + (uint32_t)tc) & mask;
             return *reinterpret_cast<const f32x4*>(xbase + (size_t)slot * kTileStreams * kRowFloats);
+        }
+        if (MODE == kRows) {
+            const int tc = t < T ? t : T - 1;
+            return *reinterpret_cast<const f32x4*>(xbase + (size_t)tc * kRowFloats);
         }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (!valid || t >= T) return v;

@@ -6,10 +6,11 @@
 namespace pe {
 
 // ---- MFCC, streaming: one workgroup per 16-stream tile ---------------------------------------
+// Grid = n_tiles * nsel workgroups; workgroup b serves tile b / nsel, frame subset b % nsel.
 template <class R>
-__global__ __launch_bounds__(256) void mfcc_stream_kernel(const MfccStreamArgs<R> a) {
+__global__ __launch_bounds__(256) void mfcc_stream_kernel(const MfccStreamArgs<R> a, const int nsel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    mfcc_stream_tile<R>(a, blockIdx.x, smem);
+    mfcc_stream_tile<R>(a, blockIdx.x / nsel, smem, blockIdx.x % nsel, nsel);
 }
 
 template <class R>
@@ -19,9 +20,9 @@ __global__ __launch_bounds__(256) void mfcc_offline_kernel(const MfccOfflineArgs
 }
 
 // ---- GRU: one wave per 16-stream tile ----------------------------------------------------------
-template <int R, bool FROM_RING>
+template <int R, int MODE>
 __global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
-    gru_tile<R, FROM_RING>(a, blockIdx.x, threadIdx.x);
+    gru_tile<R, MODE>(a, blockIdx.x, threadIdx.x);
 }
 
 // ---- GRU: four waves per 16-stream tile (few tiles: fills all four SIMDs of a CU) -----------------
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void gru_mw_kernel(const GruArgs a) {
 // share the tile (gru_tile_mw); MW = false: four tiles per GRU workgroup, one wave each.
 template <class R, int RG, bool MW>
 __global__ __launch_bounds__(256) void fused_update_kernel(const MfccStreamArgs<R> m, const GruArgs g,
-                                                           const int n_gru_blocks, const int n_tiles) {
+                                                           const int n_gru_blocks, const int n_tiles, const int nsel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
     if (b < n_gru_blocks) {
@@ -48,18 +49,28 @@ __global__ __launch_bounds__(256) void fused_update_kernel(const MfccStreamArgs<
             gru_tile_mw<RG>(g, b, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
         } else {
             const int tile = b * 4 + wave;
-            if (tile < n_tiles) gru_tile<RG, true>(g, tile, threadIdx.x & 63);
+            if (tile < n_tiles) gru_tile<RG, kRing>(g, tile, threadIdx.x & 63);
         }
     } else {
-        mfcc_stream_tile<R>(m, b - n_gru_blocks, smem);
+        const int mb = b - n_gru_blocks;
+        mfcc_stream_tile<R>(m, mb / nsel, smem, mb % nsel, nsel);
     }
 }
+
+// Workgroups per tile for the MFCC role: while the machine is not full (<= 512 tiles), give every
+// frame an update can complete per stream its own workgroup (at most 4).
+// Workgroups per tile for the MFCC role.  Splitting the frames of one update over several
+// workgroups was measured (4096 streams, MI355X): 2 per tile makes the fused launch 31.6 us instead
+// of 22.9 us -- every workgroup of the launch reserves the 73 KB LDS image, so the third workgroup
+// per CU has to wait -- hence 1.  The kernels keep the (fsel, nsel) parameters for larger-chunk use.
+static int frame_split(const StreamGeom&, int, int) { return 1; }
 
 template <class R>
 static hipError_t launch_stream(const MfccStreamArgs<R>& a, hipStream_t s) {
     const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
     const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc);
-    hipLaunchKernelGGL(mfcc_stream_kernel<R>, dim3(tiles), dim3(256), lds, s, a);
+    const int nsel = frame_split(a.geo, a.chunk, tiles);
+    hipLaunchKernelGGL(mfcc_stream_kernel<R>, dim3(tiles * nsel), dim3(256), lds, s, a, nsel);
     return hipGetLastError();
 }
 
@@ -81,16 +92,17 @@ int gru_small_regs(int units) { return (units + 3) / 4; }
 int gru_small_tiles(int units) { return (3 * gru_small_regs(units) + 3) / 4; }
 
 template <int R>
-static hipError_t launch_r(const GruArgs& a, bool from_ring, hipStream_t s) {
+static hipError_t launch_r(const GruArgs& a, int mode, hipStream_t s) {
     const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
     if (tiles == 0) return hipSuccess;
-    if (from_ring && a.waves_per_tile == 4) hipLaunchKernelGGL((gru_mw_kernel<R>), dim3(tiles), dim3(256), 0, s, a);
-    else if (from_ring) hipLaunchKernelGGL((gru_small_kernel<R, true>), dim3(tiles), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((gru_small_kernel<R, false>), dim3(tiles), dim3(64), 0, s, a);
+    if (mode == kRing && a.waves_per_tile == 4) hipLaunchKernelGGL((gru_mw_kernel<R>), dim3(tiles), dim3(256), 0, s, a);
+    else if (mode == kRing) hipLaunchKernelGGL((gru_small_kernel<R, kRing>), dim3(tiles), dim3(64), 0, s, a);
+    else if (mode == kRows) hipLaunchKernelGGL((gru_small_kernel<R, kRows>), dim3(tiles), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((gru_small_kernel<R, kFeats>), dim3(tiles), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_gru_small(const GruArgs& a, bool from_ring, hipStream_t s) {
+hipError_t launch_gru_small(const GruArgs& a, int from_ring, hipStream_t s) {
     switch (gru_small_regs(a.units)) {
         case 1: return launch_r<1>(a, from_ring, s);
         case 2: return launch_r<2>(a, from_ring, s);
@@ -108,11 +120,12 @@ template <class R, int RG>
 static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const GruArgs& g, hipStream_t s) {
     const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
     const size_t lds = lds_layout_bytes(sizeof(R), m.geo.n_filt, m.geo.n_mfcc);
+    const int nsel = frame_split(m.geo, m.chunk, tiles);
     if (g.waves_per_tile == 4) {
-        hipLaunchKernelGGL((fused_update_kernel<R, RG, true>), dim3(tiles + tiles), dim3(256), lds, s, m, g, tiles, tiles);
+        hipLaunchKernelGGL((fused_update_kernel<R, RG, true>), dim3(tiles + tiles * nsel), dim3(256), lds, s, m, g, tiles, tiles, nsel);
     } else {
         const int gru_blocks = (tiles + 3) / 4;
-        hipLaunchKernelGGL((fused_update_kernel<R, RG, false>), dim3(gru_blocks + tiles), dim3(256), lds, s, m, g, gru_blocks, tiles);
+        hipLaunchKernelGGL((fused_update_kernel<R, RG, false>), dim3(gru_blocks + tiles * nsel), dim3(256), lds, s, m, g, gru_blocks, tiles, nsel);
     }
     return hipGetLastError();
 }

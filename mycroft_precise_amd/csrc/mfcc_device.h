@@ -174,7 +174,10 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
     PE_T(2);
 
     // pass 1: lane r transforms z[16c + r] over c -> Y_r[k1]; twiddle by W256^(r k1)
+#ifndef PE_ABL_FFT
     fft16(re, im);
+#endif
+#ifndef PE_ABL_TWIDDLE
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) {
         const cplx<R> w = t.tw256[k1 * 16 + r];
@@ -182,8 +185,10 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
         re[k1] = a * w.x - b * w.y;
         im[k1] = a * w.y + b * w.x;
     }
+#endif
     PE_T(3);
     // 16x16 transpose through LDS (row stride 17 reals: conflict-free both ways), re then im
+#ifndef PE_ABL_TRANSPOSE
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) S[k1 * kTrStride + r] = re[k1];
     group_sync();
@@ -196,16 +201,21 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
 #pragma unroll
     for (int c = 0; c < 16; ++c) im[c] = S[r * kTrStride + c];
     group_sync();
+#endif
 
     PE_T(4);
     // pass 2: lane k1 (= r) transforms over the former lane index -> Z[k1 + 16 k2] in element k2
+#ifndef PE_ABL_FFT
     fft16(re, im);
+#endif
     PE_T(5);
 
     // real-FFT split needs Z[256 - p]: it lives in lane (16 - r) & 15, upper half of its registers
+#ifndef PE_ABL_EXCHANGE
 #pragma unroll
     for (int u = 0; u < 8; ++u) { S[u * 16 + r] = re[8 + u]; S[128 + u * 16 + r] = im[8 + u]; }
     group_sync();
+#endif
     const int pl = (16 - r) & 15;
     R qre[8], qim[8];
 #pragma unroll
@@ -213,8 +223,12 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
         // r != 0: partner element 15 - m -> upper index 7 - m;  r == 0: element 16 - m -> 8 - m (m >= 1)
         int u = (r == 0) ? (8 - m) : (7 - m);
         u = (u > 7) ? 7 : u;                      // r == 0, m == 0 handled below (own Z[0])
+#ifndef PE_ABL_EXCHANGE
         qre[m] = S[u * 16 + pl];
         qim[m] = S[128 + u * 16 + pl];
+#else
+        qre[m] = re[u + 8] + (R)pl; qim[m] = im[u + 8];
+#endif
     }
     if (r == 0) { qre[0] = re[0]; qim[0] = im[0]; }
     group_sync();
@@ -231,8 +245,12 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
         const cplx<R> w = t.w512[p];
         const R tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
         const R x1r = er + tr, x1i = ei + ti, x2r = er - tr, x2i = ei - ti;
+#ifndef PE_ABL_POWER
         const R p1 = (x1r * x1r + x1i * x1i) * K::INV_FFT;
         const R p2 = (x2r * x2r + x2i * x2i) * K::INV_FFT;
+#else
+        const R p1 = a + c + w.x, p2 = b + d;
+#endif
         const int pm = 256 - p;
         S[p + (p >> 4)] = p1;
         S[pm + (pm >> 4)] = p2;
@@ -255,6 +273,7 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
     // by filter, so the second pass adds a contiguous range in a fixed order.
     R* LM = S + kPowerPad;
     R* PART = LM + kMaxFilt;
+#ifndef PE_ABL_MEL
     {
         R acc0 = R(0), acc1 = R(0);
 #pragma unroll
@@ -271,6 +290,9 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
             acc1 = s1 != 0xffff ? R(0) : acc1;
         }
     }
+#else
+    PART[r] = S[r];
+#endif
     group_sync();
     for (int f = r; f < n_filt; f += 16) {
         const int p0 = t.mel_pstart[f], np = t.mel_pstart[f + 1] - p0;
@@ -287,7 +309,11 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
     PE_T(18);
     for (int f = r; f < n_filt; f += 16) {
         const R acc = LM[f];
+#ifndef PE_ABL_LOG
         LM[f] = real_log(acc > K::EPS ? acc : K::EPS);
+#else
+        LM[f] = acc + K::EPS;
+#endif
     }
     group_sync();
 
@@ -296,6 +322,9 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
     R coeff = R(0);
     if (r < n_mfcc) {
         const R* drow = t.dct + r * n_filt;
+#ifdef PE_ABL_DCT
+        coeff = LM[r] + drow[0];
+#else
         for (int j0 = 0; j0 < n_filt; j0 += 4) {
             R dv[4], lv[4];
 #pragma unroll
@@ -309,6 +338,7 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
 #pragma unroll
             for (int u = 0; u < 4; ++u) coeff = real_fma(dv[u], lv[u], coeff);
         }
+#endif
         if (r == 0) coeff = real_log(psum > K::EPS ? psum : K::EPS);
     }
     group_sync();
@@ -344,8 +374,12 @@ struct PcmView {
 // what is worth hiding): counters -> PCM of the first frame and of the leftover are requested
 // before the 12 KB table image is copied to LDS; the next frame's PCM is requested while the
 // current frame is transformed.
+// fsel / nsel: the new frames of a tile may be split over nsel workgroups (workgroup fsel takes
+// frames fsel, fsel + nsel, ...), so an update that completes two frames per stream is not twice
+// as long as one that completes one; only workgroup 0 moves the leftover and the counters.
 template <class R>
-__device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, const int tile, unsigned char* smem) {
+__device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, const int tile, unsigned char* smem,
+                                                 const int fsel = 0, const int nsel = 1) {
     using K = RealK<R>;
     const StreamGeom& geo = a.geo;
     PE_T(0);
@@ -366,8 +400,10 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
     {
         const int16_t* row0 = a.pcm + (size_t)sc * C;
         const int16_t* car0 = a.carry + (size_t)sc * kCarryCap;
+#ifndef PE_ABL_TOUCH
         for (int line = r * 64; line < C; line += 16 * 64) (void)*reinterpret_cast<const volatile int16_t*>(row0 + line);
         if (r < 8) (void)*reinterpret_cast<const volatile int16_t*>(car0 + r * 64);
+#endif
     }
     const int avail = q + C;                                 // virtual samples now available
     const int nnew = (active && avail >= flen) ? 1 + (avail - flen) / hop : 0;
@@ -404,12 +440,24 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
     for (int c = 0; c < 16; ++c) { cur[c] = 0; left[c] = 0; }
     const int slots = geo.ring_slots;
     // frames that would be overwritten before anyone reads them (huge chunks) are skipped
-    const int f_first = nnew > slots ? nnew - slots : 0;
-    if (nnew > 0) fetch(f_first * hop, flen, cur);
-    if (active && qn > 0) fetch(nnew * hop, qn, left);       // new leftover, read before any carry store
+    const int f_first = (nnew > slots ? nnew - slots : 0) + fsel;
+    const bool owner = fsel == 0;                            // moves the leftover and the counters
+#ifndef PE_ABL_PCM
+    if (f_first < nnew) fetch(f_first * hop, flen, cur);
+    if (owner && active && qn > 0) fetch(nnew * hop, qn, left);   // read before any carry store
+#else
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { cur[c] = q + c * 977 + r; left[c] = c; }
+#endif
 
     LdsTab<R> tab;
+#ifdef PE_ABL_TABLES
+    MfccTables<R> none = a.tab;
+    none.blob_bytes = 0;
+    R* scratch = lds_setup<R>(smem, none, geo.n_filt, geo.n_mfcc, tab) + a.tab.blob_bytes / sizeof(R);
+#else
     R* scratch = lds_setup<R>(smem, a.tab, geo.n_filt, geo.n_mfcc, tab);
+#endif
     __syncthreads();
     PE_T(1);
     if (!active) return;
@@ -418,7 +466,7 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
 
     float last_row = 0.0f;                                   // the final frame's ring store is issued
     int last_slot = -1;                                      // after the carry stores (see below)
-    for (int f = f_first; f < nnew; ++f) {
+    for (int f = f_first; f < nnew; f += nsel) {
         auto load = [&](int c, R& xr, R& xi) {
             xr = (R)(int)(short)(cur[c] & 0xffff) * K::INV_I16;
             xi = (R)(cur[c] >> 16) * K::INV_I16;
@@ -427,9 +475,9 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
         const uint32_t k = kc + (uint32_t)f;
         const int slot = (int)(k & (uint32_t)(slots - 1));
         const float row = (r < geo.n_mfcc) ? (float)coeff : 0.0f;
-        if (f + 1 < nnew) {
+        if (f + nsel < nnew) {
             ring_rows[(size_t)slot * kTileStreams * kRowFloats + r] = row;
-            fetch((f + 1) * hop, flen, cur);                 // L2-resident: the whole chunk was touched
+            fetch((f + nsel) * hop, flen, cur);              // L2-resident: the whole chunk was touched
         } else {
             last_row = row;
             last_slot = slot;
@@ -438,7 +486,7 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
 
     PE_T(10);
     // leftover: virtual samples [nnew*hop, avail) become the new carry
-    if (qn > 0) {
+    if (owner && qn > 0) {
         int16_t* carw = a.carry + (size_t)s * kCarryCap;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every read of the old carry has landed
         __builtin_amdgcn_wave_barrier();
@@ -450,7 +498,7 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
         }
     }
     if (last_slot >= 0) ring_rows[(size_t)last_slot * kTileStreams * kRowFloats + r] = last_row;
-    if (r == 0) {
+    if (owner && r == 0) {
         const uint32_t kcn = kc + (uint32_t)nnew;
         // frame k becomes visible once a whole window [k*hop, k*hop + window) has arrived:
         // Listener.update_vectors only vectorizes when len(window_audio) >= window_samples
@@ -483,7 +531,8 @@ __device__ __forceinline__ void mfcc_offline_block(const MfccOfflineArgs<R>& a, 
         xi = (n + 1 < flen) ? (R)x[n + 1] : R(0);
     };
     const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load);
-    if (r < geo.n_mfcc) a.out[fr * geo.n_mfcc + r] = (double)coeff;
+    if (a.out && r < geo.n_mfcc) a.out[fr * geo.n_mfcc + r] = (double)coeff;
+    if (a.out_rows) a.out_rows[fr * kRowFloats + r] = (r < geo.n_mfcc) ? (float)coeff : 0.0f;
 }
 
 }  // namespace pe

@@ -93,7 +93,8 @@ struct MfccOfflineArgs {
     const double* audio;    // [n_samples] float64 samples
     long long n_samples;
     long long n_frames;
-    double* out;            // [n_frames][n_mfcc]
+    double* out;            // [n_frames][n_mfcc] float64, may be null
+    float* out_rows;        // [n_frames][16] float32 rows (coefficients + zero padding), may be null
 };
 
 // ---------------------------------------------------------------------------------------
@@ -121,8 +122,10 @@ struct GruArgs {
     const int32_t* st_q;
     const uint32_t* st_kc;
     int chunk, window, hop, frame_len;
-    // ... or an explicit [n][T][F] float32 batch (Runner.predict)
+    // ... or an explicit [n][T][F] float32 batch (Runner.predict), or -- row_stride > 0 -- one
+    // [n_frames][16] float32 row sequence from which window w takes rows [w*row_stride, +T)
     const float* feats;
+    int row_stride;
     float* out;             // [n_streams]
     int waves_per_tile;     // 1: one wave per tile (gru_tile);  4: four waves share a tile (gru_tile_mw)
 };
@@ -151,7 +154,7 @@ hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const GruArgs& g, h
 hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const GruArgs& g, hipStream_t s);
 hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, hipStream_t s);
 hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, hipStream_t s);
-hipError_t launch_gru_small(const GruArgs& a, bool from_ring, hipStream_t s);   // units <= 32
+hipError_t launch_gru_small(const GruArgs& a, int input_mode, hipStream_t s);   // units <= 32; 0 feats, 1 ring, 2 rows
 int gru_small_regs(int units);                  // R = ceil(units/4)
 int gru_small_tiles(int units);                 // NT = ceil(3R/4)
 hipError_t launch_gather(const GatherArgs& a, hipStream_t s);

@@ -10,7 +10,8 @@ so this module defines the weights as plain arrays in Keras layout:
     {'gru': [(kernel[F,3H], recurrent_kernel[H,3H], bias[3H]), ...],   gate order z | r | h
      'dense_kernel': [H,1], 'dense_bias': [1]}
 
-stored as ``<model>.npz`` next to the usual ``<model>.npz.params`` JSON.
+stored as ``<model>.npz`` next to the usual ``<model>.npz.params`` JSON, or read straight from the
+reference's frozen-graph ``<model>.pb`` (``pb_model.py``: a protobuf wire reader, no TensorFlow).
 """
 import numpy as np
 
@@ -44,10 +45,13 @@ def save_weights(model_name: str, weights: dict):
 
 
 def load_weights(model_name: str) -> dict:
-    if model_name.endswith('.pb') or model_name.endswith('.net'):
+    if model_name.endswith('.pb'):
+        from .pb_model import weights_from_pb
+        return weights_from_pb(model_name)
+    if model_name.endswith('.net'):
         raise NotImplementedError(
-            'importing %s needs the frozen-GraphDef / HDF5 reader, which is not built yet; '
-            'convert the weights to .npz (mycroft_precise_amd.model.save_weights)' % model_name)
+            'importing %s needs an HDF5 reader (no h5py on the target); freeze it with precise-convert '
+            'to .pb, or export the arrays to .npz (mycroft_precise_amd.model.save_weights)' % model_name)
     with np.load(model_name, allow_pickle=False) as z:
         n = int(z['n_layers'])
         layers = [(z['kernel_%d' % i], z['recurrent_kernel_%d' % i], z['bias_%d' % i]) for i in range(n)]

@@ -64,6 +64,15 @@ class HipRunner(Runner):
     def run(self, inp: np.ndarray) -> float:
         return self.predict(np.asarray(inp)[np.newaxis])[0][0]
 
+    def evaluate(self, audio: np.ndarray, chunk_size: int = 4096) -> np.ndarray:
+        """The reference's offline batch evaluation (precise/scripts/simulate.py:92-104) in one device
+        call: MFCC of the whole recording, one prediction every ``chunk_size // hop_samples`` frames
+        over the sliding ``n_features``-frame window.  -> raw outputs [N, 1]."""
+        hops = int(chunk_size) // pr.hop_samples
+        if hops < 1:
+            raise ValueError('chunk_size must be at least hop_samples (%d)' % pr.hop_samples)
+        return self.engine.evaluate(audio, hops)
+
 
 def _placeholder_weights(n_in):
     return {'gru': [(np.zeros((n_in, 3), np.float32), np.zeros((1, 3), np.float32), np.zeros(3, np.float32))],

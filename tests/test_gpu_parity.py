@@ -253,6 +253,49 @@ def test_runner_predict_matches_oracle_ragged_and_empty(stock_weights):
     assert np.array_equal(runner.predict(big), keras_gru.predict(big, stock_weights))
 
 
+def test_offline_batch_evaluation_matches_simulate_semantics(stock_weights):
+    """HipRunner.evaluate == simulate.py:92-104 restated with the oracle: vectorize_raw(whole file),
+    windows mfccs[i-T:i] for i in range(T, len, chunk//hop), one predict over the batch."""
+    from mycroft_precise_amd.network_runner import HipRunner
+    from oracle import sonopy_restated as so
+    runner = HipRunner(weights=stock_weights)
+    for n, chunk in ((16000 * 6, 4096), (50000, 1024), (16000 * 2, 800), (24000, 4096), (1000, 4096)):
+        audio = synth.stream_pcm(21, n).astype(np.float32) / np.float32(32768.0)
+        got = runner.evaluate(audio, chunk)
+        mf = so.mfcc_spec(audio.astype(np.float64), 16000, (1600, 800), num_filt=20, fft_size=512, num_coeffs=13)
+        idx = range(29, len(mf), chunk // 800)
+        if len(mf) <= 29:
+            assert got.shape == (0, 1)
+            continue
+        want = keras_gru.predict(np.stack([mf[i - 29:i] for i in idx]), stock_weights)
+        assert got.shape == want.shape and np.abs(got - want).max() <= GUARD_RAW, (n, chunk)
+    with pytest.raises(ValueError):
+        runner.evaluate(np.zeros(32000), 100)
+
+
+def test_listener_runs_a_frozen_pb_model(tmp_path, stock_weights):
+    """The reference's own container: Listener('<model>.pb') finds the runner by extension
+    (network_runner.py:110-119) and reads weights + <model>.pb.params without TensorFlow."""
+    import json
+    from mycroft_precise_amd import pb_model
+    from mycroft_precise_amd.network_runner import Listener
+    path = str(tmp_path / 'hey-synthetic.pb')
+    pb_model.write_frozen_pb(path, stock_weights)
+    saved = dict(P.pr.__dict__)
+    try:
+        with open(path + '.params', 'w') as f:
+            json.dump(dict(saved, threshold_center=0.25), f)
+        g = golden('listener_chunk2048.npz')
+        lis = Listener(path, 2048)
+        assert lis.threshold_decoder.center == 0.25
+        data = g['pcm'][2].tobytes()
+        raws = [lis.update_raw(data[off:off + 2048]) for off in range(0, len(data), 2048)]
+        assert np.abs(np.array(raws) - g['raw'][2]).max() <= GUARD_RAW
+    finally:
+        P.pr.__dict__.clear()
+        P.pr.__dict__.update(saved)
+
+
 @pytest.mark.parametrize('units', [1, 4, 7, 16, 20, 24, 32])
 def test_other_gru_widths(units):
     """Every instantiation of the register-resident GRU kernel (R = ceil(units/4) = 1..8)."""

@@ -258,3 +258,62 @@ def test_find_runner_extension_dispatch():
     assert Listener.find_runner('model.pb') is HipRunner
     with pytest.raises(ValueError):
         Listener.find_runner('model.txt')
+
+
+# ---- frozen-graph .pb model files (convert.py:59-81) --------------------------------------------
+def test_pb_roundtrip_and_load_weights(tmp_path, stock_weights):
+    from mycroft_precise_amd import pb_model
+    from mycroft_precise_amd.model import load_weights, save_weights
+    path = str(tmp_path / 'hey.pb')
+    pb_model.write_frozen_pb(path, stock_weights)
+    consts = pb_model.read_const_tensors(path)
+    assert sorted(consts) == ['dense_1/bias', 'dense_1/kernel', 'net/bias', 'net/kernel', 'net/recurrent_kernel']
+    w = load_weights(path)
+    for a, b in zip(w['gru'][0], stock_weights['gru'][0]):
+        assert a.dtype == np.float32 and np.array_equal(a, b)
+    assert np.array_equal(w['dense_kernel'], stock_weights['dense_kernel'])
+    assert np.array_equal(w['dense_bias'], stock_weights['dense_bias'])
+    # .npz container round trip
+    npz = str(tmp_path / 'hey.npz')
+    save_weights(npz, stock_weights)
+    w2 = load_weights(npz)
+    assert np.array_equal(w2['gru'][0][1], stock_weights['gru'][0][1])
+    with pytest.raises(NotImplementedError):
+        load_weights(str(tmp_path / 'model.net'))
+
+
+def test_pb_reader_handles_tf_encodings(tmp_path):
+    """float_val (packed and single-value splat) instead of tensor_content, 'import/' prefixes,
+    non-float and non-Const nodes in between: what TensorFlow's own writer may emit."""
+    from mycroft_precise_amd import pb_model as pm
+    rng = np.random.default_rng(3)
+    k = rng.normal(size=(13, 12)).astype(np.float32)
+    rk = rng.normal(size=(4, 12)).astype(np.float32)
+
+    def const(name, tensor_payload):
+        return pm._node(name, 'Const', attrs=[pm._attr('dtype', pm._enc_int(6, 1)),
+                                              pm._attr('value', pm._enc_field(8, tensor_payload))])
+
+    def shape(dims):
+        return pm._enc_field(2, b''.join(pm._enc_field(2, pm._enc_int(1, d)) for d in dims))
+
+    packed = pm._enc_int(1, 1) + shape(rk.shape) + pm._enc_field(5, rk.astype('<f4').tobytes())
+    splat = pm._enc_int(1, 1) + shape((12,)) + pm._enc_varint((5 << 3) | 5) + np.float32(0.25).tobytes()
+    int_tensor = pm._enc_int(1, 3) + shape((2,)) + pm._enc_field(4, np.array([1, 2], '<i4').tobytes())
+    graph = (pm._node('import/net_input', 'Placeholder')
+             + const('import/net/kernel', pm._tensor_proto(k))
+             + const('import/net/recurrent_kernel', packed)
+             + const('import/net/bias', splat)
+             + const('import/net/while/maximum_iterations', int_tensor)
+             + const('import/dense_7/kernel', pm._tensor_proto(np.ones((4, 1), np.float32)))
+             + const('import/dense_7/bias', pm._tensor_proto(np.array([0.5], np.float32)))
+             + pm._node('import/net_output', 'Identity', inputs=['import/dense_7/Sigmoid']))
+    path = str(tmp_path / 'tf.pb')
+    open(path, 'wb').write(graph)
+    w = pm.weights_from_pb(path)
+    (gk, grk, gb), = w['gru']
+    assert np.array_equal(gk, k) and np.array_equal(grk, rk) and np.array_equal(gb, np.full(12, 0.25, np.float32))
+    assert w['dense_kernel'].shape == (4, 1) and float(w['dense_bias'][0]) == 0.5
+    open(path, 'wb').write(pm._node('x', 'Placeholder'))
+    with pytest.raises(ValueError):
+        pm.weights_from_pb(path)

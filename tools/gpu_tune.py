@@ -47,9 +47,9 @@ def bench_cfg(B, fused, waves, prec='f64', steps=200):
 
 print('%-8s %-6s %-6s %-5s | %10s %10s %10s | %12s' % ('B', 'fused', 'waves', 'prec', 'wall us', 'ev1 us', 'ev2 us', 'Mwin/s'))
 for B in (4096,):
-    for prec in ('f64',) if B != 4096 else ('f64', 'f32'):
+    for prec in ('f64',):
         for fused in (True, False):
-            for waves in (1, 4):
+            for waves in (4,):
                 if B == 65536 and prec == 'f32' and not fused:
                     continue
                 wall, e1, e2 = bench_cfg(B, fused, waves, prec)
