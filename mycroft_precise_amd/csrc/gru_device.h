@@ -320,4 +320,142 @@ __device__ __forceinline__ void gru_tile_mw(const GruArgs& a, const int tile, co
     }
 }
 
+// ---- four waves per tile, stock width (17 <= H <= 20, R = 5) ----------------------------------------
+// Same split as gru_tile_mw -- tile 0 = {z0..z3}, tile 1 = {z4, r0, r1, r2}, tile 2 = {r3, r4 | c0, c1},
+// tile 3 = {c2, c3, c4} -- with the input projections moved off the critical path: waves 0/1 compute
+// theirs while waves 2/3 run phase 2; wave 3, idle during phase 1, computes its own AND tile 2's and
+// hands the latter to wave 2 through LDS.  What stays serial per timestep is two 5-MFMA chains and
+// two LDS hand-offs.
+__device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, const int wave, const int lane,
+                                             float* S /* [15][64] gate slots + [64][4] tile-2 projection */) {
+    constexpr int R = 5;
+    float* X2 = S + 3 * R * 64;
+    const int g = lane >> 4, j = lane & 15;
+    const long long stream = (long long)tile * kTileStreams + j;
+    const bool valid = stream < a.n_streams;
+    const int T = a.n_features;
+
+    float wx[4], wx2[4], wrA[R], wrB[R], wd[R];
+    f32x4 bias, bias2;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        wx[kk] = a.wx[(wave * 4 + kk) * 64 + lane];
+        wx2[kk] = a.wx[(2 * 4 + kk) * 64 + lane];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bias[q] = a.bias[(wave * 4 + q) * 64 + lane];
+        bias2[q] = a.bias[(2 * 4 + q) * 64 + lane];
+    }
+#pragma unroll
+    for (int rho = 0; rho < R; ++rho) {
+        wrA[rho] = a.wr1[(wave * R + rho) * 64 + lane];      // phase-1 rows of this wave's tile (zero for tile 3)
+        wrB[rho] = a.wr2[(wave * R + rho) * 64 + lane];      // phase-2 rows (zero for tiles 0, 1)
+        wd[rho] = a.wd[rho * 64 + lane];
+    }
+
+    uint32_t ke = a.st_ke[stream];                 // counters exist for padded streams too
+    if (a.predict_ke) {
+        const int q = a.st_q[stream];
+        const uint32_t kc = a.st_kc[stream];
+        const int avail = q + a.chunk;
+        const int nnew = avail >= a.frame_len ? 1 + (avail - a.frame_len) / a.hop : 0;
+        const int qn = avail - nnew * a.hop;
+        const int m = qn + a.hop * (int)(kc + (uint32_t)nnew - ke);
+        if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
+    }
+    const uint32_t first = ke - (uint32_t)T;
+    const uint32_t mask = (uint32_t)(a.ring_slots - 1);
+    const float* xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats + 4 * g;
+    auto load_x = [&](int t) -> f32x4 {
+        const int tc = t < T ? t : T - 1;
+        const uint32_t slot = (first + (uint32_t)tc) & mask;
+        return *reinterpret_cast<const f32x4*>(xbase + (size_t)slot * kTileStreams * kRowFloats);
+    };
+    auto xproj = [&](const float (&w)[4], const f32x4& b, const f32x4& x) -> f32x4 {
+        f32x4 acc = mfma(w[0], x[0], b);
+#pragma unroll
+        for (int kk = 1; kk < 4; ++kk) acc = mfma(w[kk], x[kk], acc);
+        return acc;
+    };
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    float* Sl = S + lane;
+
+    float h[R], z[R];
+#pragma unroll
+    for (int rho = 0; rho < R; ++rho) { h[rho] = 0.f; z[rho] = 0.f; }
+    f32x4 accx = xproj(wx, bias, load_x(0));       // this wave's tile, timestep 0
+    f32x4 x1 = load_x(1);
+
+    for (int t = 0; t < T; ++t) {
+        if (wave == 3) {
+            // phase 1 of the others: projections of timestep t+1 for tile 3 (own) and tile 2 (wave 2's)
+            const f32x4 an = xproj(wx, bias, x1);
+            const f32x4 a2 = xproj(wx2, bias2, x1);
+            *reinterpret_cast<f32x4*>(X2 + lane * 4) = a2;
+            x1 = load_x(t + 2);
+            lds_barrier();                                           // A
+            float rr[R];
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) { z[rho] = Sl[rho * 64]; rr[rho] = Sl[(R + rho) * 64]; }
+            f32x4 acc = accx;
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) acc = mfma(wrB[rho], rr[rho] * h[rho], acc);
+            Sl[12 * 64] = acc[0]; Sl[13 * 64] = acc[1]; Sl[14 * 64] = acc[2];
+            lds_barrier();                                           // B
+            accx = an;
+        } else if (wave == 2) {
+            f32x4 acc = accx;
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) acc = mfma(wrA[rho], h[rho], acc);
+            Sl[8 * 64] = hard_sigmoid(acc[0]); Sl[9 * 64] = hard_sigmoid(acc[1]);
+            lds_barrier();                                           // A
+            float rr[R];
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) { z[rho] = Sl[rho * 64]; rr[rho] = Sl[(R + rho) * 64]; }
+            const f32x4 an = *reinterpret_cast<const f32x4*>(X2 + lane * 4);
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) acc = mfma(wrB[rho], rr[rho] * h[rho], acc);
+            Sl[10 * 64] = acc[2]; Sl[11 * 64] = acc[3];
+            lds_barrier();                                           // B
+            accx = an;
+        } else {
+            f32x4 acc = accx;
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) acc = mfma(wrA[rho], h[rho], acc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Sl[(4 * wave + q) * 64] = hard_sigmoid(acc[q]);
+            lds_barrier();                                           // A
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) z[rho] = Sl[rho * 64];
+            accx = xproj(wx, bias, x1);                              // phase 2 of the others
+            x1 = load_x(t + 2);
+            lds_barrier();                                           // B
+        }
+        float hh[R];
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) hh[rho] = Sl[(2 * R + rho) * 64];
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) h[rho] = z[rho] * h[rho] + (1.0f - z[rho]) * hh[rho];
+    }
+
+    if (wave == 0) {
+        float part = 0.f;
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) part = fmaf(h[rho], wd[rho], part);
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (valid && g == 0) a.out[stream] = 1.0f / (1.0f + expf(-(part + a.dense_bias)));
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void gru_tile_mw_any(const GruArgs& a, const int tile, const int wave, const int lane, float* S) {
+    if constexpr (R == 5) gru_tile_mw5(a, tile, wave, lane, S);
+    else gru_tile_mw<R>(a, tile, wave, lane, S);
+}
+
 }  // namespace pe

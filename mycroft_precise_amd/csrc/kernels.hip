@@ -28,9 +28,9 @@ __global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
 // ---- GRU: four waves per 16-stream tile (few tiles: fills all four SIMDs of a CU) -----------------
 template <int R>
 __global__ __launch_bounds__(256) void gru_mw_kernel(const GruArgs a) {
-    __shared__ float S[3 * R * 64];
+    __shared__ __attribute__((aligned(16))) float S[3 * R * 64 + 256];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    gru_tile_mw<R>(a, blockIdx.x, wave, threadIdx.x & 63, S);
+    gru_tile_mw_any<R>(a, blockIdx.x, wave, threadIdx.x & 63, S);
 }
 
 // ---- fused update: GRU role || MFCC role in ONE launch ------------------------------------------
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void fused_update_kernel(const MfccStreamArgs<
     if (b < n_gru_blocks) {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         if (MW) {
-            gru_tile_mw<RG>(g, b, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
+            gru_tile_mw_any<RG>(g, b, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
         } else {
             const int tile = b * 4 + wave;
             if (tile < n_tiles) gru_tile<RG, kRing>(g, tile, threadIdx.x & 63);
