@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PE_ABI_VERSION 1
+#define PE_ABI_VERSION 2
 
 typedef enum pe_status {
     PE_OK = 0,
@@ -51,6 +51,9 @@ typedef struct pe_params {
     int32_t use_delta;       /* 0      (1 is PE_ERR_UNSUPPORTED for now)     params.py:143 */
     int32_t mfcc_precision;  /* 0 = float64 front end (what the reference computes in,
                                 network_runner.py:102,137);  1 = float32 front end        */
+    int32_t gru_precision;   /* 0 = float32 matrix cores (reference precision, tol 1e-4);
+                                1 = bf16 operands / float32 accumulate (BASELINE configs[4],
+                                tol 1e-2)                                                    */
 } pe_params;
 
 /* One Keras GRU layer (precise/model.py:77-81), Keras weight layout, gate order z|r|h. */
@@ -132,7 +135,7 @@ int pe_evaluate(pe_engine* e, const double* audio_host, int64_t n_samples, int32
 /* Introspection used by tests and the bench. */
 typedef struct pe_info {
     int32_t n_streams, n_features, n_mfcc, units, n_layers, ring_slots, carry_capacity;
-    int32_t mfcc_precision;
+    int32_t mfcc_precision, gru_precision;
     int64_t device_bytes;            /* HBM held by this engine                                */
 } pe_info;
 int pe_get_info(const pe_engine* e, pe_info* out);

@@ -13,13 +13,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libprecise_engine.so')
 
 PE_OK, PE_ERR_INVALID, PE_ERR_HIP, PE_ERR_UNSUPPORTED, PE_ERR_NOMEM, PE_ERR_EOF = range(6)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class PeParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'sample_rate', 'window_samples', 'hop_samples', 'n_fft', 'n_filt', 'n_mfcc', 'n_features',
-        'use_delta', 'mfcc_precision')]
+        'use_delta', 'mfcc_precision', 'gru_precision')]
 
 
 class PeGruLayer(C.Structure):
@@ -36,7 +36,7 @@ class PeWeights(C.Structure):
 class PeInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'n_streams', 'n_features', 'n_mfcc', 'units', 'n_layers', 'ring_slots', 'carry_capacity',
-        'mfcc_precision')] + [('device_bytes', C.c_int64)]
+        'mfcc_precision', 'gru_precision')] + [('device_bytes', C.c_int64)]
 
 
 EXPORTS = {
@@ -131,7 +131,8 @@ class HipEngine:
     ``network_runner.py``.
     """
 
-    def __init__(self, params, weights, n_streams=1, device=0, mfcc_precision='f64', mel_filters=None):
+    def __init__(self, params, weights, n_streams=1, device=0, mfcc_precision='f64', mel_filters=None,
+                 gru_precision='f32'):
         from .vectorization import mel_filterbank
         self._lib = load()
         self._h = C.c_void_p()
@@ -140,7 +141,8 @@ class HipEngine:
         self.n_mfcc = int(params.n_mfcc)
         prec = {'f64': 0, 'f32': 1}[mfcc_precision]
         p = PeParams(params.sample_rate, params.window_samples, params.hop_samples, params.n_fft,
-                     params.n_filt, params.n_mfcc, params.n_features, int(bool(params.use_delta)), prec)
+                     params.n_filt, params.n_mfcc, params.n_features, int(bool(params.use_delta)), prec,
+                     {'f32': 0, 'bf16': 1}[gru_precision])
         if mel_filters is None:
             mel_filters = mel_filterbank(params.sample_rate, params.n_filt, params.n_fft // 2 + 1)
         mel = np.ascontiguousarray(mel_filters, dtype=np.float64)

@@ -53,6 +53,8 @@ struct pe_engine {
     int table_blob_bytes = 0;
     // packed network
     float* wx = nullptr; float* wr1 = nullptr; float* wr2 = nullptr; float* bias = nullptr; float* wd = nullptr;
+    // bf16-operand network (pe_params.gru_precision = 1)
+    uint16_t* wx_bf16 = nullptr; uint16_t* wr_bf16 = nullptr; float* bias_bf16 = nullptr; float* wd_bf16 = nullptr;
     // staging for the host entry points (grown on demand)
     DeviceBuf st_pcm, st_out, st_feats, st_mask, st_audio, st_mfcc;
     // timing
@@ -250,6 +252,53 @@ int pack_gru_weights(pe_engine* e, const pe_gru_layer& L, const float* dense_ker
     return PE_OK;
 }
 
+// bf16 network operands (gru_bf16_device.h): unit u = 8 g + i; tile (gate, t): row 4 gout + q <-> unit
+// 8 gout + 4 t + q; A operand of lane (row i, k-group g) = 8 consecutive k (features / source units).
+uint16_t to_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);     // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                                 // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+
+int pack_gru_weights_bf16(pe_engine* e, const pe_gru_layer& L, const float* dense_kernel) {
+    const int H = L.units, F = L.n_in;
+    std::vector<uint16_t> wx((size_t)6 * 64 * 8, 0), wr((size_t)6 * 64 * 8, 0);
+    std::vector<float> bias((size_t)6 * 4 * 64, 0.f), wd((size_t)8 * 64, 0.f);
+    for (int tl = 0; tl < 6; ++tl) {
+        const int gate = tl >> 1, t = tl & 1;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, g = lane >> 4;
+            const int gout = i >> 2, reg = i & 3;
+            const int u = 8 * gout + 4 * t + reg;                    // A row i of this tile
+            if (u < H) {
+                const int col = gate * H + u;
+                for (int ek = 0; ek < 8; ++ek) {
+                    const int k = 8 * g + ek;
+                    if (k < F) wx[((size_t)tl * 64 + lane) * 8 + ek] = to_bf16(L.kernel[(size_t)k * 3 * H + col]);
+                    if (k < H) wr[((size_t)tl * 64 + lane) * 8 + ek] = to_bf16(L.recurrent_kernel[(size_t)k * 3 * H + col]);
+                }
+            }
+            for (int q = 0; q < 4; ++q) {                            // C rows 4 g + q of this lane
+                const int ub = 8 * g + 4 * t + q;
+                if (ub < H) bias[((size_t)tl * 4 + q) * 64 + lane] = L.bias[gate * H + ub];
+            }
+        }
+    }
+    for (int i = 0; i < 8; ++i)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int u = 8 * (lane >> 4) + i;
+            if (u < H) wd[(size_t)i * 64 + lane] = dense_kernel[u];
+        }
+    int rc;
+    if ((rc = dev_upload(e, &e->wx_bf16, wx))) return rc;
+    if ((rc = dev_upload(e, &e->wr_bf16, wr))) return rc;
+    if ((rc = dev_upload(e, &e->bias_bf16, bias))) return rc;
+    if ((rc = dev_upload(e, &e->wd_bf16, wd))) return rc;
+    return PE_OK;
+}
+
 StreamGeom geom(const pe_engine* e) {
     StreamGeom g;
     g.n_streams = e->n_streams;
@@ -309,6 +358,8 @@ GruArgs gru_args(const pe_engine* e) {
     a.chunk = 0;
     a.window = e->prm.window_samples; a.hop = e->prm.hop_samples;
     a.frame_len = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
+    a.bf16 = e->prm.gru_precision == 1;
+    a.wx_bf16 = e->wx_bf16; a.wr_bf16 = e->wr_bf16; a.bias_bf16 = e->bias_bf16; a.wd_bf16 = e->wd_bf16;
     a.feats = nullptr; a.out = nullptr; a.row_stride = 0;
     a.waves_per_tile = e->gru_waves ? e->gru_waves : (e->n_tiles <= 1024 ? 4 : 1);
     return a;
@@ -385,6 +436,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         return fail(nullptr, PE_ERR_INVALID, "window/hop/n_features must be positive");
     if (p->use_delta) return fail(nullptr, PE_ERR_UNSUPPORTED, "use_delta=True has no kernel yet");
     if (p->mfcc_precision != 0 && p->mfcc_precision != 1) return fail(nullptr, PE_ERR_INVALID, "mfcc_precision must be 0 (f64) or 1 (f32)");
+    if (p->gru_precision != 0 && p->gru_precision != 1) return fail(nullptr, PE_ERR_INVALID, "gru_precision must be 0 (f32) or 1 (bf16 operands)");
     if (w->n_layers != 1 || !w->layers) return fail(nullptr, PE_ERR_UNSUPPORTED, "only single-layer GRU networks have a kernel (got %d layers)", w->n_layers);
     const pe_gru_layer& L = w->layers[0];
     if (L.units < 1 || L.units > 32) return fail(nullptr, PE_ERR_UNSUPPORTED, "register-resident GRU kernel needs 1 <= units <= 32 (got %d)", L.units);
@@ -421,6 +473,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         rc = (p->mfcc_precision == 0) ? build_tables<double>(e, mel_filters) : build_tables<float>(e, mel_filters);
         if (rc) break;
         if ((rc = pack_gru_weights(e, L, w->dense_kernel))) break;
+        if (p->gru_precision == 1 && (rc = pack_gru_weights_bf16(e, L, w->dense_kernel))) break;
         for (auto& ev : e->ev)
             if (hipEventCreate(&ev) != hipSuccess) { rc = fail(e, PE_ERR_HIP, "hipEventCreate failed"); break; }
         if (rc) break;
@@ -629,6 +682,7 @@ int pe_get_info(const pe_engine* e, pe_info* out) {
     out->ring_slots = e->ring_slots;
     out->carry_capacity = kCarryCap;
     out->mfcc_precision = e->prm.mfcc_precision;
+    out->gru_precision = e->prm.gru_precision;
     out->device_bytes = e->device_bytes;
     return PE_OK;
 }

@@ -1,0 +1,134 @@
+// bf16-operand GRU + Dense forward (BASELINE.json configs[4]: "bf16 MFCC+GRU ... tol 1e-2"), gfx950.
+//
+// Same network and recurrence as gru_device.h (model.py:76-82), but the gate matmuls run on
+// v_mfma_f32_16x16x32_bf16: weights, features and the hidden state are rounded to bf16 as MFMA
+// operands, accumulation, gate non-linearities and the state update stay float32.  K = 32 swallows
+// the whole contraction (13 features / <= 32 hidden units) in ONE MFMA per output tile, so a
+// timestep is 6 (input) + 4 (z, r) + 2 (candidate) MFMAs of ~17 cycles instead of 41 of 32 -- one
+// wave per 16-stream tile, no LDS, no cross-wave hand-off.
+//
+// Layout: hidden unit u = 8 g + i lives in lane group g = lane >> 4, register i (0..7).  Output tile
+// (gate, t) holds rows 4 g + q  <->  unit 8 g + 4 t + q, so a lane's eight z / r / candidate values of
+// the two tiles of a gate are exactly its eight units, and bf16(h) packed from those registers IS the
+// B operand of the next step (B: lane (g, j) supplies k = 8 g .. 8 g + 7 for stream j).
+#pragma once
+#include "gru_device.h"
+
+namespace pe {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mfma_bf16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 pack_bf16(const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
+    return o;
+}
+
+// MODE as in gru_device.h (kFeats / kRing / kRows).  Tiles: 0,1 = z, 2,3 = r, 4,5 = candidate.
+template <int MODE>
+__device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, const int lane) {
+    const int g = lane >> 4, j = lane & 15;
+    const long long stream = (long long)tile * kTileStreams + j;
+    const bool valid = stream < a.n_streams;
+    const int T = a.n_features;
+
+    // resident operands: 6 + 6 tiles x 4 VGPRs of bf16 weights, 6 x 4 biases, 8 dense weights
+    bf16x8 wx[6], wr[6];
+    f32x4 bias[6];
+    float wd[8];
+    const uint4* wxs = reinterpret_cast<const uint4*>(a.wx_bf16);
+    const uint4* wrs = reinterpret_cast<const uint4*>(a.wr_bf16);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const uint4 u = wxs[t * 64 + lane], v = wrs[t * 64 + lane];
+        wx[t] = __builtin_bit_cast(bf16x8, u);
+        wr[t] = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias[t][q] = a.bias_bf16[(t * 4 + q) * 64 + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wd[i] = a.wd_bf16[i * 64 + lane];
+
+    const float* xbase = nullptr;
+    uint32_t first = 0;
+    const uint32_t mask = (uint32_t)(a.ring_slots - 1);
+    if (MODE == kRing) {
+        uint32_t ke = a.st_ke[stream];               // counters exist for padded streams too
+        if (a.predict_ke) {
+            const int q = a.st_q[stream];
+            const uint32_t kc = a.st_kc[stream];
+            const int avail = q + a.chunk;
+            const int nnew = avail >= a.frame_len ? 1 + (avail - a.frame_len) / a.hop : 0;
+            const int qn = avail - nnew * a.hop;
+            const int m = qn + a.hop * (int)(kc + (uint32_t)nnew - ke);
+            if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
+        }
+        first = ke - (uint32_t)T;
+        xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats;
+    } else if (MODE == kRows) {
+        const long long w = valid ? stream : 0;
+        xbase = a.feats + ((size_t)w * a.row_stride) * kRowFloats;
+    } else {
+        xbase = a.feats + (size_t)(valid ? stream : 0) * T * a.n_in;
+    }
+    // lane group g supplies features 8 g .. 8 g + 7 (a ring row has 16 floats: groups 2, 3 supply zeros)
+    auto load_x = [&](int t) -> bf16x8 {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        const int tc = t < T ? t : T - 1;
+        if (MODE == kFeats) {
+            const float* p = xbase + (size_t)tc * a.n_in;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (valid && 8 * g + i < a.n_in) v[i] = p[8 * g + i];
+        } else if (g < 2) {
+            const float* p = (MODE == kRing)
+                ? xbase + (size_t)((first + (uint32_t)tc) & mask) * kTileStreams * kRowFloats + 8 * g
+                : xbase + (size_t)tc * kRowFloats + 8 * g;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = lo[i]; v[4 + i] = hi[i]; }
+        }
+        return pack_bf16(v);
+    };
+
+    float h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = 0.f;
+    bf16x8 x = load_x(0);
+    for (int t = 0; t < T; ++t) {
+        const bf16x8 xn = load_x(t + 1);
+        f32x4 acc[6];
+#pragma unroll
+        for (int tl = 0; tl < 6; ++tl) acc[tl] = mfma_bf16(wx[tl], x, bias[tl]);
+        const bf16x8 hb = pack_bf16(h);
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) acc[tl] = mfma_bf16(wr[tl], hb, acc[tl]);
+        float z[8], rh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            z[i] = hard_sigmoid(acc[i >> 2][i & 3]);
+            rh[i] = hard_sigmoid(acc[2 + (i >> 2)][i & 3]) * h[i];
+        }
+        const bf16x8 rhb = pack_bf16(rh);
+#pragma unroll
+        for (int tl = 4; tl < 6; ++tl) acc[tl] = mfma_bf16(wr[tl], rhb, acc[tl]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = z[i] * h[i] + (1.0f - z[i]) * acc[4 + (i >> 2)][i & 3];
+        x = xn;
+    }
+
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part = fmaf(h[i], wd[i], part);
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    if (valid && g == 0) a.out[stream] = 1.0f / (1.0f + expf(-(part + a.dense_bias)));
+}
+
+}  // namespace pe

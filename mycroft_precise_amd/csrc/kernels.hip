@@ -2,6 +2,7 @@
 // in mfcc_device.h (MFCC front end) and gru_device.h (GRU + Dense on the f32 matrix cores).
 #include "mfcc_device.h"
 #include "gru_device.h"
+#include "gru_bf16_device.h"
 
 namespace pe {
 
@@ -23,6 +24,26 @@ __global__ __launch_bounds__(256) void mfcc_offline_kernel(const MfccOfflineArgs
 template <int R, int MODE>
 __global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
     gru_tile<R, MODE>(a, blockIdx.x, threadIdx.x);
+}
+
+// ---- GRU, bf16 operands: one wave per 16-stream tile --------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(64) void gru_bf16_kernel(const GruArgs a) {
+    gru_tile_bf16<MODE>(a, blockIdx.x, threadIdx.x);
+}
+
+// fused update with the bf16 network role (four tiles per GRU workgroup, one wave each)
+template <class R>
+__global__ __launch_bounds__(256) void fused_update_bf16_kernel(const MfccStreamArgs<R> m, const GruArgs g,
+                                                                const int n_gru_blocks, const int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    if (b < n_gru_blocks) {
+        const int tile = b * 4 + (threadIdx.x >> 6);
+        if (tile < n_tiles) gru_tile_bf16<kRing>(g, tile, threadIdx.x & 63);
+    } else {
+        mfcc_stream_tile<R>(m, b - n_gru_blocks, smem);
+    }
 }
 
 // ---- GRU: four waves per 16-stream tile (few tiles: fills all four SIMDs of a CU) -----------------
@@ -103,6 +124,14 @@ static hipError_t launch_r(const GruArgs& a, int mode, hipStream_t s) {
 }
 
 hipError_t launch_gru_small(const GruArgs& a, int from_ring, hipStream_t s) {
+    if (a.bf16) {
+        const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
+        if (tiles == 0) return hipSuccess;
+        if (from_ring == kRing) hipLaunchKernelGGL((gru_bf16_kernel<kRing>), dim3(tiles), dim3(64), 0, s, a);
+        else if (from_ring == kRows) hipLaunchKernelGGL((gru_bf16_kernel<kRows>), dim3(tiles), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((gru_bf16_kernel<kFeats>), dim3(tiles), dim3(64), 0, s, a);
+        return hipGetLastError();
+    }
     switch (gru_small_regs(a.units)) {
         case 1: return launch_r<1>(a, from_ring, s);
         case 2: return launch_r<2>(a, from_ring, s);
@@ -132,6 +161,13 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const GruArgs& g, 
 
 template <class R>
 static hipError_t launch_fused(const MfccStreamArgs<R>& m, const GruArgs& g, hipStream_t s) {
+    if (g.bf16) {
+        const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
+        const int gru_blocks = (tiles + 3) / 4;
+        const size_t lds = lds_layout_bytes(sizeof(R), m.geo.n_filt, m.geo.n_mfcc);
+        hipLaunchKernelGGL((fused_update_bf16_kernel<R>), dim3(gru_blocks + tiles), dim3(256), lds, s, m, g, gru_blocks, tiles);
+        return hipGetLastError();
+    }
     switch (gru_small_regs(g.units)) {
         case 1: return launch_fused_rg<R, 1>(m, g, s);
         case 2: return launch_fused_rg<R, 2>(m, g, s);

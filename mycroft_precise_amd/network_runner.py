@@ -167,7 +167,8 @@ class BatchedListener:
     of bytes objects) and returns one prediction per stream.  Stream state never leaves HBM.
     """
 
-    def __init__(self, model, n_streams: int, device: int = 0, mfcc_precision: str = 'f64', params=None):
+    def __init__(self, model, n_streams: int, device: int = 0, mfcc_precision: str = 'f64', params=None,
+                 gru_precision: str = 'f32'):
         if isinstance(model, str):
             self.pr = inject_params(model).copy()
             weights = load_weights(model)
@@ -177,7 +178,7 @@ class BatchedListener:
         self.n_streams = int(n_streams)
         self.weights = weights
         self.engine = HipEngine(self.pr, weights, n_streams=self.n_streams, device=device,
-                                mfcc_precision=mfcc_precision)
+                                mfcc_precision=mfcc_precision, gru_precision=gru_precision)
         self.threshold_decoder = ThresholdDecoder(self.pr.threshold_config, self.pr.threshold_center)
 
     def _pcm(self, chunks) -> np.ndarray:

@@ -39,9 +39,9 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_struct_layouts_match_header():
-    assert ctypes.sizeof(_lib.PeParams) == 9 * 4
+    assert ctypes.sizeof(_lib.PeParams) == 10 * 4
     assert ctypes.sizeof(_lib.PeGruLayer) == 8 + 3 * ctypes.sizeof(ctypes.c_void_p)
-    assert ctypes.sizeof(_lib.PeInfo) == 8 * 4 + 8
+    assert ctypes.sizeof(_lib.PeInfo) == 9 * 4 + 4 + 8
 
 
 def test_create_argument_validation_without_gpu():

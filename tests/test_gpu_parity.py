@@ -330,6 +330,51 @@ def test_other_listener_params_overlapping_windows():
     eng.close()
 
 
+# ---- BASELINE configs[4]: bf16 operands, tolerance 1e-2 -------------------------------------------------
+TOL_BF16 = 1e-2
+
+
+@pytest.mark.parametrize('mfcc', ['f32', 'f64'])
+def test_bf16_network_within_1e2_of_oracle(stock_weights, mfcc):
+    """gru_precision='bf16': weights / features / hidden state rounded to bf16 as MFMA operands, float32
+    accumulate; streaming, predict and offline evaluation against the float32 oracle, tol 1e-2."""
+    from mycroft_precise_amd.network_runner import BatchedListener
+    from mycroft_precise_amd._lib import HipEngine
+    kinds = (['tone_noise'] * 40) + ['zeros', 'square', 'quiet']
+    n_up = 40
+    pcm = _stream_batch(kinds, n_up)
+    hip = BatchedListener(stock_weights, len(kinds), mfcc_precision=mfcc, gru_precision='bf16')
+    ref = ol.BatchedOracle(stock_weights, len(kinds))
+    worst = 0.0
+    for u in range(n_up):
+        raw = hip.update_raw(pcm[u])
+        want = ref.update_raw(pcm[u])
+        worst = max(worst, float(np.abs(raw - want).max()))
+    assert worst <= TOL_BF16, worst
+    assert worst > 1e-6          # it really is the reduced-precision path
+    # fused == unfused bitwise also for this kernel
+    a = BatchedListener(stock_weights, 33, mfcc_precision=mfcc, gru_precision='bf16')
+    b = BatchedListener(stock_weights, 33, mfcc_precision=mfcc, gru_precision='bf16')
+    b.engine.set_fused(False)
+    for u in range(12):
+        assert np.array_equal(a.update_raw(pcm[u][:33]), b.update_raw(pcm[u][:33]))
+    eng = HipEngine(P.pr, stock_weights, n_streams=1, gru_precision='bf16')
+    x = np.random.default_rng(8).normal(0, 2, (70, 29, 13)).astype(np.float32)
+    assert np.abs(eng.predict(x) - keras_gru.predict(x, stock_weights)).max() <= TOL_BF16
+    assert eng.info().gru_precision == 1
+    eng.close()
+
+
+@pytest.mark.parametrize('units', [8, 20, 32])
+def test_bf16_network_other_widths(units):
+    from mycroft_precise_amd._lib import HipEngine
+    w = synth.make_weights(units=(units,), seed=300 + units)
+    eng = HipEngine(P.pr, w, n_streams=1, gru_precision='bf16')
+    x = np.random.default_rng(units).normal(0, 2, (40, 29, 13)).astype(np.float32)
+    assert np.abs(eng.predict(x) - keras_gru.predict(x, w)).max() <= TOL_BF16
+    eng.close()
+
+
 # ---- full-size properties (BASELINE configs[1]: 4096 streams on one GPU) ----------------------------
 def test_full_batch_4096_streams_properties(stock_weights):
     from mycroft_precise_amd.network_runner import BatchedListener

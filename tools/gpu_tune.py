@@ -19,8 +19,8 @@ w = synth.make_weights()
 dev = torch.device('cuda', 0)
 
 
-def bench_cfg(B, fused, waves, prec='f64', steps=200):
-    eng = _lib.HipEngine(pr, w, n_streams=B, mfcc_precision=prec)
+def bench_cfg(B, fused, waves, prec='f64', steps=200, gru='f32'):
+    eng = _lib.HipEngine(pr, w, n_streams=B, mfcc_precision=prec, gru_precision=gru)
     eng.set_fused(fused)
     eng.set_gru_waves(waves)
     n_res = 64
@@ -54,6 +54,12 @@ for B in (4096,):
                     continue
                 wall, e1, e2 = bench_cfg(B, fused, waves, prec)
                 print('%-8d %-6s %-6d %-5s | %10.2f %10.2f %10.2f | %12.1f' % (B, fused, waves, prec, wall, e1, e2, B / wall), flush=True)
+
+for B in (4096, 65536):
+    for prec in ('f32', 'f64'):
+        for fused in (True, False):
+            wall, e1, e2 = bench_cfg(B, fused, 1, prec, gru='bf16')
+            print('%-8d %-6s %-6s %-5s | %10.2f %10.2f %10.2f | %12.1f' % (B, fused, 'bf16', prec, wall, e1, e2, B / wall), flush=True)
 
 # ---- MFCC section timers (debug library) ---------------------------------------------------------
 dbg = os.path.join(REPO, 'mycroft_precise_amd', 'csrc', 'build', 'libprecise_engine_dbg.so')
