@@ -48,7 +48,8 @@ typedef struct pe_params {
     int32_t n_filt;          /* 20     mel filters, <= 64                    params.py:142 */
     int32_t n_mfcc;          /* 13     coefficients kept, <= 16              params.py:142 */
     int32_t n_features;      /* 29     T, timesteps per network input        params.py:79  */
-    int32_t use_delta;       /* 0      (1 is PE_ERR_UNSUPPORTED for now)     params.py:143 */
+    int32_t use_delta;       /* 0      1: network inputs are [x_t, x_t - x_(t-1)]
+                                       (vectorization.py:53-59), layer n_in = 2 n_mfcc   params.py:143 */
     int32_t mfcc_precision;  /* 0 = float64 front end (what the reference computes in,
                                 network_runner.py:102,137);  1 = float32 front end        */
     int32_t gru_precision;   /* 0 = float32 matrix cores (reference precision, tol 1e-4);
@@ -112,7 +113,8 @@ int pe_get_vectors(pe_engine* e, float* feats_out_host);
 /* Run the network on the current feature windows without consuming audio. */
 int pe_run_device(pe_engine* e, float* raw_out_dev, void* hip_stream);
 
-/* Runner.predict (network_runner.py:35-38): feats[n][n_features][n_mfcc] float32 -> out[n]. */
+/* Runner.predict (network_runner.py:35-38): feats[n][n_features][feature_size] float32 -> out[n]
+ * (feature_size = n_mfcc, or 2 n_mfcc with use_delta: the batch then carries its delta columns). */
 int pe_predict(pe_engine* e, const float* feats_host, int32_t n, float* out_host);
 int pe_predict_device(pe_engine* e, const float* feats_dev, int32_t n, float* out_dev,
                       void* hip_stream);

@@ -139,6 +139,7 @@ class HipEngine:
         self.n_streams = int(n_streams)
         self.n_features = int(params.n_features)
         self.n_mfcc = int(params.n_mfcc)
+        self.feature_size = int(params.n_mfcc) * (2 if params.use_delta else 1)
         prec = {'f64': 0, 'f32': 1}[mfcc_precision]
         p = PeParams(params.sample_rate, params.window_samples, params.hop_samples, params.n_fft,
                      params.n_filt, params.n_mfcc, params.n_features, int(bool(params.use_delta)), prec,
@@ -221,8 +222,8 @@ class HipEngine:
 
     def predict(self, feats) -> np.ndarray:
         feats = np.ascontiguousarray(feats, dtype=np.float32)
-        if feats.ndim != 3 or feats.shape[1:] != (self.n_features, self.n_mfcc):
-            raise ValueError('inputs must be [N, %d, %d], got %r' % (self.n_features, self.n_mfcc, feats.shape))
+        if feats.ndim != 3 or feats.shape[1:] != (self.n_features, self.feature_size):
+            raise ValueError('inputs must be [N, %d, %d], got %r' % (self.n_features, self.feature_size, feats.shape))
         out = np.empty((feats.shape[0], 1), dtype=np.float32)
         self._check(self._lib.pe_predict(self._h, feats.ctypes.data, feats.shape[0], out.ctypes.data))
         return out

@@ -52,6 +52,7 @@ struct pe_engine {
     unsigned char* table_blob = nullptr;
     int table_blob_bytes = 0;
     // packed network
+    float* wxd = nullptr;
     float* wx = nullptr; float* wr1 = nullptr; float* wr2 = nullptr; float* bias = nullptr; float* wd = nullptr;
     // bf16-operand network (pe_params.gru_precision = 1)
     uint16_t* wx_bf16 = nullptr; uint16_t* wr_bf16 = nullptr; float* bias_bf16 = nullptr; float* wd_bf16 = nullptr;
@@ -207,9 +208,10 @@ int build_tables(pe_engine* e, const double* mel_filters) {
 
 // Arrange the Keras matrices as MFMA A-operands (see the layout comment in gru_kernels.hip).
 int pack_gru_weights(pe_engine* e, const pe_gru_layer& L, const float* dense_kernel) {
-    const int H = L.units, F = L.n_in;
+    const int H = L.units, F = e->n_in;          // F = base features; with use_delta the kernel has 2F rows
+    const bool delta = e->prm.use_delta != 0;
     const int R = gru_small_regs(H), NT = gru_small_tiles(H);
-    std::vector<float> wx((size_t)NT * 4 * 64, 0.f), wr1((size_t)NT * R * 64, 0.f), wr2((size_t)NT * R * 64, 0.f);
+    std::vector<float> wx((size_t)NT * 4 * 64, 0.f), wxd((size_t)NT * 4 * 64, 0.f), wr1((size_t)NT * R * 64, 0.f), wr2((size_t)NT * R * 64, 0.f);
     std::vector<float> bias((size_t)NT * 4 * 64, 0.f), wd((size_t)R * 64, 0.f);
     for (int tile = 0; tile < NT; ++tile)
         for (int lane = 0; lane < 64; ++lane) {
@@ -223,6 +225,7 @@ int pack_gru_weights(pe_engine* e, const pe_gru_layer& L, const float* dense_ker
                     for (int kk = 0; kk < 4; ++kk) {
                         const int phi = 4 * g + kk;
                         if (phi < F) wx[((size_t)tile * 4 + kk) * 64 + lane] = L.kernel[(size_t)phi * 3 * H + col];
+                        if (phi < F && delta) wxd[((size_t)tile * 4 + kk) * 64 + lane] = L.kernel[(size_t)(F + phi) * 3 * H + col];
                     }
                     for (int rs = 0; rs < R; ++rs) {
                         const int usrc = 4 * rs + g;
@@ -245,6 +248,7 @@ int pack_gru_weights(pe_engine* e, const pe_gru_layer& L, const float* dense_ker
         }
     int rc;
     if ((rc = dev_upload(e, &e->wx, wx))) return rc;
+    if ((rc = dev_upload(e, &e->wxd, wxd))) return rc;
     if ((rc = dev_upload(e, &e->wr1, wr1))) return rc;
     if ((rc = dev_upload(e, &e->wr2, wr2))) return rc;
     if ((rc = dev_upload(e, &e->bias, bias))) return rc;
@@ -350,6 +354,7 @@ GruArgs gru_args(const pe_engine* e) {
     a.n_features = e->prm.n_features;
     a.n_in = e->n_in;
     a.units = e->units;
+    a.wxd = e->wxd; a.use_delta = e->prm.use_delta;
     a.wx = e->wx; a.wr1 = e->wr1; a.wr2 = e->wr2; a.bias = e->bias; a.wd = e->wd;
     a.dense_bias = e->dense_bias;
     a.ring = e->ring; a.st_ke = e->st_ke[e->cur]; a.ring_slots = e->ring_slots;
@@ -362,6 +367,7 @@ GruArgs gru_args(const pe_engine* e) {
     a.wx_bf16 = e->wx_bf16; a.wr_bf16 = e->wr_bf16; a.bias_bf16 = e->bias_bf16; a.wd_bf16 = e->wd_bf16;
     a.feats = nullptr; a.out = nullptr; a.row_stride = 0;
     a.waves_per_tile = e->gru_waves ? e->gru_waves : (e->n_tiles <= 1024 ? 4 : 1);
+    if (e->prm.use_delta) a.waves_per_tile = 1;          // only the one-wave kernel carries the delta inputs
     return a;
 }
 
@@ -434,13 +440,14 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         return fail(nullptr, PE_ERR_UNSUPPORTED, "need 1 <= n_mfcc <= n_filt <= 64 (got n_filt=%d n_mfcc=%d)", p->n_filt, p->n_mfcc);
     if (p->hop_samples < 1 || p->window_samples < 1 || p->n_features < 1)
         return fail(nullptr, PE_ERR_INVALID, "window/hop/n_features must be positive");
-    if (p->use_delta) return fail(nullptr, PE_ERR_UNSUPPORTED, "use_delta=True has no kernel yet");
+    if (p->use_delta && p->gru_precision != 0) return fail(nullptr, PE_ERR_UNSUPPORTED, "use_delta has no bf16 kernel");
     if (p->mfcc_precision != 0 && p->mfcc_precision != 1) return fail(nullptr, PE_ERR_INVALID, "mfcc_precision must be 0 (f64) or 1 (f32)");
     if (p->gru_precision != 0 && p->gru_precision != 1) return fail(nullptr, PE_ERR_INVALID, "gru_precision must be 0 (f32) or 1 (bf16 operands)");
     if (w->n_layers != 1 || !w->layers) return fail(nullptr, PE_ERR_UNSUPPORTED, "only single-layer GRU networks have a kernel (got %d layers)", w->n_layers);
     const pe_gru_layer& L = w->layers[0];
     if (L.units < 1 || L.units > 32) return fail(nullptr, PE_ERR_UNSUPPORTED, "register-resident GRU kernel needs 1 <= units <= 32 (got %d)", L.units);
-    if (L.n_in != p->n_mfcc) return fail(nullptr, PE_ERR_INVALID, "layer n_in=%d does not match n_mfcc=%d", L.n_in, p->n_mfcc);
+    const int feature_size = p->use_delta ? 2 * p->n_mfcc : p->n_mfcc;          // params.py:99-109
+    if (L.n_in != feature_size) return fail(nullptr, PE_ERR_INVALID, "layer n_in=%d does not match feature_size=%d", L.n_in, feature_size);
     if (!L.kernel || !L.recurrent_kernel || !L.bias || !w->dense_kernel) return fail(nullptr, PE_ERR_INVALID, "null weight pointer");
 
     hipError_t herr = hipSetDevice(device);
@@ -452,7 +459,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     e->n_streams = n_streams;
     e->n_tiles = (n_streams + kTileStreams - 1) / kTileStreams;
     e->n_padded = e->n_tiles * kTileStreams;
-    e->units = L.units; e->n_in = L.n_in; e->n_layers = 1;
+    e->units = L.units; e->n_in = p->n_mfcc; e->n_layers = 1;
     e->dense_bias = w->dense_bias;
     const int flen = p->window_samples < kNfft ? p->window_samples : kNfft;
     // frames computed (first flen samples arrived) but not yet emitted (whole window arrived):
@@ -599,7 +606,7 @@ int pe_predict(pe_engine* e, const float* feats_host, int32_t n, float* out_host
     if (n == 0) return PE_OK;
     PE_HIP(e, hipSetDevice(e->device));
     int rc;
-    const size_t fb = (size_t)n * e->prm.n_features * e->n_in * sizeof(float);
+    const size_t fb = (size_t)n * e->prm.n_features * (e->prm.use_delta ? 2 * e->n_in : e->n_in) * sizeof(float);
     if ((rc = ensure(e, e->st_feats, fb))) return rc;
     if ((rc = ensure(e, e->st_out, (size_t)n * sizeof(float)))) return rc;
     PE_HIP(e, hipMemcpy(e->st_feats.p, feats_host, fb, hipMemcpyHostToDevice));

@@ -68,12 +68,16 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
     const int T = a.n_features;
 
     // ---- resident operands ------------------------------------------------------------
-    float wx[G::NT][4], wr1[G::P1_END][R], wr2[G::NP2][R], wd[R];
+    float wx[G::NT][4], wxd[G::NT][4], wr1[G::P1_END][R], wr2[G::NP2][R], wd[R];
     f32x4 bias[G::NT];
+    const bool delta = a.use_delta != 0;      // add_deltas (vectorization.py:53-59): F more inputs = x_t - x_(t-1)
 #pragma unroll
     for (int t = 0; t < G::NT; ++t) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) wx[t][kk] = a.wx[(t * 4 + kk) * 64 + lane];
+        for (int kk = 0; kk < 4; ++kk) {
+            wx[t][kk] = a.wx[(t * 4 + kk) * 64 + lane];
+            wxd[t][kk] = delta ? a.wxd[(t * 4 + kk) * 64 + lane] : 0.f;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) bias[t][q] = a.bias[(t * 4 + q) * 64 + lane];
     }
@@ -111,8 +115,9 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
         const long long w = valid ? stream : 0;               // padded lanes shadow window 0
         xbase = a.feats + ((size_t)w * a.row_stride) * kRowFloats + 4 * g;
     } else {
-        xbase = a.feats + (size_t)stream * T * a.n_in;
+        xbase = a.feats + (size_t)stream * T * (delta ? 2 * a.n_in : a.n_in);
     }
+    const int frow = delta ? 2 * a.n_in : a.n_in;         // floats per timestep of an explicit batch
     auto load_x = [&](int t) -> f32x4 {
         if (FROM_RING) {
             // no branch: rows of padded streams exist (zeroed), t is clamped to the last row, so the
@@ -127,7 +132,16 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
         }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (!valid || t >= T) return v;
-        const float* p = xbase + (size_t)t * a.n_in + 4 * g;
+        const float* p = xbase + (size_t)t * frow + 4 * g;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) v[kk] = (4 * g + kk < a.n_in) ? p[kk] : 0.f;
+        return v;
+    };
+    // explicit batches carry their delta columns (Runner.predict receives add_deltas output)
+    auto load_d = [&](int t) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!valid || t >= T) return v;
+        const float* p = xbase + (size_t)t * frow + a.n_in + 4 * g;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) v[kk] = (4 * g + kk < a.n_in) ? p[kk] : 0.f;
         return v;
@@ -138,6 +152,7 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
     for (int rho = 0; rho < R; ++rho) h[rho] = 0.f;
 
     f32x4 x = load_x(0);
+    f32x4 xprev = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < T; ++t) {
         const f32x4 xn = load_x(t + 1);      // prefetch next timestep's features
         f32x4 acc[G::NT];
@@ -147,6 +162,16 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
             acc[tl] = mfma(wx[tl][0], x[0], bias[tl]);
 #pragma unroll
             for (int kk = 1; kk < 4; ++kk) acc[tl] = mfma(wx[tl][kk], x[kk], acc[tl]);
+        }
+        if (delta) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == kFeats) d = load_d(t);
+            else if (t > 0) d = x - xprev;
+#pragma unroll
+            for (int tl = 0; tl < G::NT; ++tl)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc[tl] = mfma(wxd[tl][kk], d[kk], acc[tl]);
+            xprev = x;
         }
         // phase 1: + h . U for the z / r rows
 #pragma unroll

@@ -107,6 +107,8 @@ struct GruArgs {
     int units;              // H
     // packed MFMA A-operands, one float per lane (see pack_gru_weights in engine.hip)
     const float* wx;        // [NT][4][64]      input kernel, k-step kk <-> feature 4g+kk
+    const float* wxd;       // [NT][4][64]      input kernel rows of the delta features (use_delta)
+    int use_delta;          // inputs are [x_t, x_t - x_(t-1)] (first timestep's delta is 0); n_in stays F
     const float* wr1;       // [NT][R][64]      recurrent kernel rows of z/r slots (phase 1)
     const float* wr2;       // [NT][R][64]      recurrent kernel rows of candidate slots (phase 2)
     const float* bias;      // [NT][4][64]      accumulator init per output register

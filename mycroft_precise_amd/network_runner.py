@@ -144,7 +144,7 @@ class Listener:
 
     def update_raw(self, stream) -> float:
         """``update`` without the ThresholdDecoder: the raw network output."""
-        if self._fused and not self.pr.use_delta:
+        if self._fused:
             pcm = self._read(stream)
             if pcm.size == 0:
                 raise EOFError

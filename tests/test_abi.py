@@ -57,7 +57,7 @@ def test_create_argument_validation_without_gpu():
         _lib.HipEngine(bad, w, n_streams=1, mel_filters=np.zeros((20, 129)))
     delta = pr.copy()
     delta.__dict__['use_delta'] = True
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                 # use_delta needs a layer with 2 * n_mfcc inputs
         _lib.HipEngine(delta, w, n_streams=1)
     wide = synth.make_weights(units=(256,))
     with pytest.raises(NotImplementedError):

@@ -330,6 +330,53 @@ def test_other_listener_params_overlapping_windows():
     eng.close()
 
 
+def test_use_delta_matches_reference_semantics(tmp_path):
+    """ListenerParams.use_delta (params.py:143, vectorization.py:53-59, network_runner.py:150-151): the
+    network sees [x_t, x_t - x_(t-1)] with a zero first delta; streaming (fused and unfused), the
+    drop-in Listener on a model whose .params says use_delta, and Runner.predict on explicit batches."""
+    import json
+    from mycroft_precise_amd._lib import HipEngine
+    from mycroft_precise_amd.model import save_weights
+    from mycroft_precise_amd.network_runner import Listener
+    w = synth.make_weights(n_in=26, units=(20,), seed=77)
+    opr = ol.Params(use_delta=True)
+    hpr = P.pr.copy()
+    hpr.__dict__['use_delta'] = True
+    assert hpr.feature_size == 26
+    n, n_up = 19, 40
+    pcm = _stream_batch(['tone_noise'] * (n - 2) + ['quiet', 'square'], n_up)
+    refs = [ol.OracleListener(w, opr) for _ in range(n)]
+    engines = [HipEngine(hpr, w, n_streams=n), HipEngine(hpr, w, n_streams=n)]
+    engines[1].set_fused(False)
+    for u in range(n_up):
+        want = np.array([r.update_raw(pcm[u, j].tobytes()) for j, r in enumerate(refs)])
+        for eng in engines:
+            assert np.abs(eng.update(pcm[u]) - want).max() <= GUARD_RAW, u
+    # explicit batch with its delta columns
+    x = np.stack([ol.add_deltas(r.mfccs) for r in refs]).astype(np.float32)
+    assert x.shape == (n, 29, 26)
+    assert np.abs(engines[0].predict(x) - keras_gru.predict(x, w)).max() <= GUARD_RAW
+    for eng in engines:
+        eng.close()
+    # drop-in Listener: model file + .params with use_delta
+    saved = dict(P.pr.__dict__)
+    try:
+        path = str(tmp_path / 'delta.npz')
+        save_weights(path, w)
+        with open(path + '.params', 'w') as f:
+            json.dump(dict(saved, use_delta=True), f)
+        lis = Listener(path, 2048)
+        assert lis.pr.use_delta is True
+        ref = ol.OracleListener(w, opr)
+        data = synth.stream_pcm(3, 40 * 1024).tobytes()
+        for off in range(0, len(data), 2048):
+            assert abs(lis.update_raw(data[off:off + 2048]) - ref.update_raw(data[off:off + 2048])) <= GUARD_RAW
+        assert lis.mfccs.shape == (29, 13)
+    finally:
+        P.pr.__dict__.clear()
+        P.pr.__dict__.update(saved)
+
+
 # ---- BASELINE configs[4]: bf16 operands, tolerance 1e-2 -------------------------------------------------
 TOL_BF16 = 1e-2
 
