@@ -134,6 +134,18 @@ int pe_vectorize_raw(pe_engine* e, const double* audio_host, int64_t n_samples,
 int pe_evaluate(pe_engine* e, const double* audio_host, int64_t n_samples, int32_t hop_frames,
                 float* out_host, int64_t max_windows, int64_t* n_windows_out);
 
+/* ThresholdDecoder.decode (threshold_decoder.py:45-57) and TriggerDetector.update
+ * (runner/precise_runner/runner.py:127-142) for every stream, on the device.
+ * pe_set_decoder: cd = the decoder's cumulative table (np.cumsum of the summed normal pdfs,
+ * threshold_decoder.py:42,68-70), min_out / out_range / center as the Python object holds them.
+ * pe_set_trigger: (re)arms one TriggerDetector per stream (chunk_size in BYTES as in runner.py:122).
+ * pe_decode*: raw[n_streams] float32 -> conf[n_streams] float64 (may be NULL) and, when a trigger is
+ * set, fired[n_streams] (1 = this prediction caused an activation; may be NULL). */
+int pe_set_decoder(pe_engine* e, const double* cd, int32_t cd_len, int32_t min_out, int32_t out_range, double center);
+int pe_set_trigger(pe_engine* e, int32_t chunk_size_bytes, double sensitivity, int32_t trigger_level);
+int pe_decode_device(pe_engine* e, const float* raw_dev, double* conf_out_dev, unsigned char* fired_out_dev, void* hip_stream);
+int pe_decode(pe_engine* e, const float* raw_host, double* conf_out_host, unsigned char* fired_out_host);
+
 /* Introspection used by tests and the bench. */
 typedef struct pe_info {
     int32_t n_streams, n_features, n_mfcc, units, n_layers, ring_slots, carry_capacity;

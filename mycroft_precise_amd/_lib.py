@@ -60,6 +60,10 @@ EXPORTS = {
                                    C.POINTER(C.c_int64)]),
     'pe_evaluate': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
                               C.POINTER(C.c_int64)]),
+    'pe_set_decoder': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
+    'pe_set_trigger': (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32]),
+    'pe_decode_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pe_decode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pe_get_info': (C.c_int, [C.c_void_p, C.POINTER(PeInfo)]),
     'pe_get_stream_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pe_set_fused': (C.c_int, [C.c_void_p, C.c_int32]),
@@ -251,6 +255,25 @@ class HipEngine:
         self._check(self._lib.pe_evaluate(self._h, audio.ctypes.data if audio.size else None, audio.size,
                                           int(hop_frames), out.ctypes.data if n_win else None, n_win, C.byref(n)))
         return out[:n.value]
+
+    def set_decoder(self, decoder):
+        """Upload a ThresholdDecoder (its cumulative table and scalars) for pe_decode*."""
+        cd = np.ascontiguousarray(decoder.cd, dtype=np.float64)
+        self._check(self._lib.pe_set_decoder(self._h, cd.ctypes.data if cd.size else None, cd.size,
+                                             int(decoder.min_out), int(decoder.out_range), float(decoder.center)))
+
+    def set_trigger(self, chunk_size: int, sensitivity: float = 0.5, trigger_level: int = 3):
+        self._check(self._lib.pe_set_trigger(self._h, int(chunk_size), float(sensitivity), int(trigger_level)))
+
+    def decode(self, raw, want_fired=False):
+        """raw float32 [n_streams] -> decoded confidences float64 [n_streams] (, fired bool [n_streams])."""
+        raw = np.ascontiguousarray(raw, dtype=np.float32).reshape(-1)
+        if raw.size != self.n_streams:
+            raise ValueError('expected %d raw outputs' % self.n_streams)
+        conf = np.empty(self.n_streams, dtype=np.float64)
+        fired = np.zeros(self.n_streams, dtype=np.uint8)
+        self._check(self._lib.pe_decode(self._h, raw.ctypes.data, conf.ctypes.data, fired.ctypes.data))
+        return (conf, fired.astype(bool)) if want_fired else conf
 
     def clear(self, mask=None):
         if mask is None:

@@ -56,8 +56,11 @@ struct pe_engine {
     float* wx = nullptr; float* wr1 = nullptr; float* wr2 = nullptr; float* bias = nullptr; float* wd = nullptr;
     // bf16-operand network (pe_params.gru_precision = 1)
     uint16_t* wx_bf16 = nullptr; uint16_t* wr_bf16 = nullptr; float* bias_bf16 = nullptr; float* wd_bf16 = nullptr;
+    // on-device ThresholdDecoder / TriggerDetector (pe_set_decoder / pe_set_trigger)
+    double* cd = nullptr; int cd_len = 0, dec_min_out = 0, dec_out_range = 0; double dec_center = 0.5;
+    int32_t* activation = nullptr; double trig_threshold = 0.5; int trig_level = 3, trig_rearm = -8; bool trig_on = false;
     // staging for the host entry points (grown on demand)
-    DeviceBuf st_pcm, st_out, st_feats, st_mask, st_audio, st_mfcc;
+    DeviceBuf st_pcm, st_out, st_feats, st_mask, st_audio, st_mfcc, st_conf, st_fired;
     // timing
     bool timing = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -503,7 +506,7 @@ int pe_destroy(pe_engine* e) {
     if (!e) return PE_OK;
     (void)hipSetDevice(e->device);
     for (void* p : e->allocs) (void)hipFree(p);
-    for (DeviceBuf* b : {&e->st_pcm, &e->st_out, &e->st_feats, &e->st_mask, &e->st_audio, &e->st_mfcc})
+    for (DeviceBuf* b : {&e->st_pcm, &e->st_out, &e->st_feats, &e->st_mask, &e->st_audio, &e->st_mfcc, &e->st_conf, &e->st_fired})
         if (b->p) (void)hipFree(b->p);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     delete e;
@@ -520,7 +523,7 @@ int pe_clear(pe_engine* e, const uint8_t* mask_host) {
         PE_HIP(e, hipMemcpy(e->st_mask.p, mask_host, (size_t)e->n_streams, hipMemcpyHostToDevice));
         mask_dev = static_cast<const uint8_t*>(e->st_mask.p);
     }
-    ClearArgs a{e->n_padded, e->ring_slots, mask_dev, e->st_q[e->cur], e->st_kc[e->cur], e->st_ke[e->cur], e->ring};
+    ClearArgs a{e->n_padded, e->ring_slots, mask_dev, e->st_q[e->cur], e->st_kc[e->cur], e->st_ke[e->cur], e->ring, e->activation};
     if (mask_dev) a.n_streams = e->n_streams;
     PE_HIP(e, launch_clear(a, nullptr));
     PE_HIP(e, hipStreamSynchronize(nullptr));
@@ -676,6 +679,66 @@ int pe_evaluate(pe_engine* e, const double* audio_host, int64_t n_samples, int32
     g.waves_per_tile = 1;
     PE_HIP(e, launch_gru_small(g, 2, nullptr));
     PE_HIP(e, hipMemcpy(out_host, e->st_out.p, (size_t)n_windows * sizeof(float), hipMemcpyDeviceToHost));
+    return PE_OK;
+}
+
+int pe_set_decoder(pe_engine* e, const double* cd, int32_t cd_len, int32_t min_out, int32_t out_range, double center) {
+    if (!e || cd_len < 0 || (cd_len > 0 && !cd)) return fail(e, PE_ERR_INVALID, "bad decoder table");
+    if (out_range != 0 && cd_len < 1) return fail(e, PE_ERR_INVALID, "decoder needs a non-empty table when out_range != 0");
+    PE_HIP(e, hipSetDevice(e->device));
+    std::vector<double> host(cd, cd + cd_len);
+    int rc = dev_upload(e, &e->cd, host);
+    if (rc) return rc;
+    e->cd_len = cd_len; e->dec_min_out = min_out; e->dec_out_range = out_range; e->dec_center = center;
+    return PE_OK;
+}
+
+int pe_set_trigger(pe_engine* e, int32_t chunk_size_bytes, double sensitivity, int32_t trigger_level) {
+    if (!e || chunk_size_bytes <= 0) return fail(e, PE_ERR_INVALID, "bad trigger parameters");
+    PE_HIP(e, hipSetDevice(e->device));
+    if (!e->activation) {
+        int rc = dev_alloc(e, &e->activation, (size_t)e->n_padded);
+        if (rc) return rc;
+    }
+    PE_HIP(e, hipMemset(e->activation, 0, (size_t)e->n_padded * sizeof(int32_t)));
+    e->trig_threshold = 1.0 - sensitivity;
+    e->trig_level = trigger_level;
+    const int n = 8 * 2048;                                // -(8 * 2048) // chunk_size, floor division
+    e->trig_rearm = -((n + chunk_size_bytes - 1) / chunk_size_bytes);
+    e->trig_on = true;
+    return PE_OK;
+}
+
+int pe_decode_device(pe_engine* e, const float* raw_dev, double* conf_out_dev, unsigned char* fired_out_dev, void* stream) {
+    if (!e || !raw_dev) return fail(e, PE_ERR_INVALID, "null argument to pe_decode_device");
+    if (!e->cd && e->dec_out_range != 0) return fail(e, PE_ERR_INVALID, "pe_set_decoder has not been called");
+    if (!e->cd_len && !e->cd) return fail(e, PE_ERR_INVALID, "pe_set_decoder has not been called");
+    DecodeArgs a{};
+    a.n_streams = e->n_streams; a.raw = raw_dev; a.cd = e->cd; a.cd_len = e->cd_len;
+    a.min_out = e->dec_min_out; a.out_range = e->dec_out_range; a.center = e->dec_center;
+    a.conf_out = conf_out_dev;
+    a.activation = e->trig_on ? e->activation : nullptr;
+    a.fired_out = fired_out_dev;
+    a.threshold = e->trig_threshold; a.trigger_level = e->trig_level; a.rearm = e->trig_rearm;
+    PE_HIP(e, launch_decode(a, static_cast<hipStream_t>(stream)));
+    return PE_OK;
+}
+
+int pe_decode(pe_engine* e, const float* raw_host, double* conf_out_host, unsigned char* fired_out_host) {
+    if (!e || !raw_host) return fail(e, PE_ERR_INVALID, "null argument to pe_decode");
+    PE_HIP(e, hipSetDevice(e->device));
+    int rc;
+    const size_t n = (size_t)e->n_streams;
+    if ((rc = ensure(e, e->st_out, n * sizeof(float)))) return rc;
+    if ((rc = ensure(e, e->st_conf, n * sizeof(double)))) return rc;
+    if ((rc = ensure(e, e->st_fired, n))) return rc;
+    PE_HIP(e, hipMemcpy(e->st_out.p, raw_host, n * sizeof(float), hipMemcpyHostToDevice));
+    PE_HIP(e, hipMemset(e->st_fired.p, 0, n));
+    if ((rc = pe_decode_device(e, static_cast<const float*>(e->st_out.p), static_cast<double*>(e->st_conf.p),
+                               static_cast<unsigned char*>(e->st_fired.p), nullptr))) return rc;
+    if (conf_out_host) PE_HIP(e, hipMemcpy(conf_out_host, e->st_conf.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (fired_out_host) PE_HIP(e, hipMemcpy(fired_out_host, e->st_fired.p, n, hipMemcpyDeviceToHost));
+    if (!conf_out_host && !fired_out_host) PE_HIP(e, hipStreamSynchronize(nullptr));
     return PE_OK;
 }
 

@@ -150,7 +150,25 @@ struct ClearArgs {
     const uint8_t* mask;
     int32_t* st_q; uint32_t* st_kc; uint32_t* st_ke;
     float* ring;
+    int32_t* activation;    // per-stream trigger state, may be null
 };
+
+// ThresholdDecoder.decode + TriggerDetector.update for every stream (threshold_decoder.py:45-57,
+// runner/precise_runner/runner.py:127-142)
+struct DecodeArgs {
+    int n_streams;
+    const float* raw;           // [n] raw network outputs
+    const double* cd;           // cumulative distribution LUT
+    int cd_len, min_out, out_range;
+    double center;
+    double* conf_out;           // [n] decoded confidence, may be null
+    // trigger (enabled when activation != null)
+    int32_t* activation;        // [n] per-stream TriggerDetector.activation
+    unsigned char* fired_out;   // [n] 1 where this update caused an activation, may be null
+    double threshold;           // 1 - sensitivity
+    int trigger_level, rearm;   // rearm = -(8 * 2048) // chunk_size
+};
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t s);
 
 // launchers implemented in kernels.hip
 hipError_t launch_mfcc_stream_f64(const MfccStreamArgs<double>& a, hipStream_t s);

@@ -180,6 +180,14 @@ class BatchedListener:
         self.engine = HipEngine(self.pr, weights, n_streams=self.n_streams, device=device,
                                 mfcc_precision=mfcc_precision, gru_precision=gru_precision)
         self.threshold_decoder = ThresholdDecoder(self.pr.threshold_config, self.pr.threshold_center)
+        self.engine.set_decoder(self.threshold_decoder)
+        self._trigger = False
+
+    def set_trigger(self, chunk_size: int = 2048, sensitivity: float = 0.5, trigger_level: int = 3):
+        """One TriggerDetector (runner/precise_runner/runner.py:115-142) per stream, on the device;
+        ``chunk_size`` in bytes as in the reference."""
+        self.engine.set_trigger(chunk_size, sensitivity, trigger_level)
+        self._trigger = True
 
     def _pcm(self, chunks) -> np.ndarray:
         if isinstance(chunks, np.ndarray):
@@ -207,5 +215,11 @@ class BatchedListener:
         return self.engine.update(self._pcm(chunks))
 
     def update(self, chunks) -> np.ndarray:
-        """-> decoded confidences float64 [n_streams]"""
-        return self.threshold_decoder.decode_many(self.update_raw(chunks))
+        """-> decoded confidences float64 [n_streams] (ThresholdDecoder.decode on the device)"""
+        return self.engine.decode(self.update_raw(chunks))
+
+    def update_detect(self, chunks):
+        """-> (confidences float64 [n_streams], activations bool [n_streams]); needs set_trigger()."""
+        if not self._trigger:
+            raise RuntimeError('call set_trigger() first')
+        return self.engine.decode(self.update_raw(chunks), want_fired=True)

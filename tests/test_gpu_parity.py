@@ -330,6 +330,61 @@ def test_other_listener_params_overlapping_windows():
     eng.close()
 
 
+def test_device_threshold_decoder_and_trigger(stock_weights):
+    """ThresholdDecoder.decode and TriggerDetector.update for every stream on the device vs the
+    reference-pinned fixtures / host classes (decode is a step function: one LUT bin of tolerance;
+    the trigger must be exact given the same confidences)."""
+    from mycroft_precise_amd._lib import HipEngine
+    from mycroft_precise_amd.network_runner import BatchedListener
+    from mycroft_precise_amd.runner import TriggerDetector
+    from mycroft_precise_amd.threshold_decoder import ThresholdDecoder
+    g = golden('threshold_decoder.npz')
+    for name in ('default', 'two', 'narrow'):
+        dec = ThresholdDecoder([tuple(r) for r in g['cfg_' + name]], float(g['center_' + name]))
+        grid = g['grid'].astype(np.float32)
+        eng = HipEngine(P.pr, stock_weights, n_streams=grid.size)
+        eng.set_decoder(dec)
+        got = eng.decode(grid)
+        want = np.array([dec.decode(float(v)) for v in grid])
+        assert np.abs(got - want).max() <= TOL_DECODE, name
+        assert np.mean(got == want) > 0.9, name
+        eng.close()
+    # streaming: decode + trigger on the device == host decode + host TriggerDetector per stream
+    n, n_up = 40, 60
+    pcm = _stream_batch(['tone_noise'] * n, n_up)
+    hip = BatchedListener(stock_weights, n)
+    hip.set_trigger(2048, sensitivity=0.45, trigger_level=2)
+    dets = [TriggerDetector(2048, 0.45, 2) for _ in range(n)]
+    n_fired = 0
+    for u in range(n_up):
+        if u == 30:
+            mask = np.zeros(n, np.uint8); mask[::3] = 1
+            hip.clear(mask)
+            for j in np.nonzero(mask)[0]:
+                dets[j] = TriggerDetector(2048, 0.45, 2)
+        conf, fired = hip.update_detect(pcm[u])
+        want_fired = np.array([d.update(float(c)) for d, c in zip(dets, conf)])
+        assert np.array_equal(fired, want_fired), u
+        n_fired += int(fired.sum())
+    # crafted raw outputs (bursts near 1 between lulls) so that activations and re-arming do happen
+    rng = np.random.default_rng(11)
+    for chunk_size, sens, level in ((2048, 0.5, 3), (1024, 0.8, 1), (8192, 0.2, 0)):
+        hip.set_trigger(chunk_size, sens, level)
+        dets = [TriggerDetector(chunk_size, sens, level) for _ in range(n)]
+        total = 0
+        for u in range(120):
+            burst = (np.sin((np.arange(n) * 0.7 + u) / 5.0) > 0.2)
+            raw = np.clip(np.where(burst, 1 - 1e-4 * rng.random(n), 1e-3 * rng.random(n)), 1e-7, 1 - 1e-7).astype(np.float32)
+            conf, fired = hip.engine.decode(raw, want_fired=True)
+            want = np.array([d.update(float(c)) for d, c in zip(dets, conf)])
+            assert np.array_equal(fired, want), (chunk_size, u)
+            total += int(fired.sum())
+        assert total > 0, chunk_size
+    plain = BatchedListener(stock_weights, n)
+    with pytest.raises(RuntimeError):
+        plain.update_detect(pcm[0])
+
+
 def test_use_delta_matches_reference_semantics(tmp_path):
     """ListenerParams.use_delta (params.py:143, vectorization.py:53-59, network_runner.py:150-151): the
     network sees [x_t, x_t - x_(t-1)] with a zero first delta; streaming (fused and unfused), the
