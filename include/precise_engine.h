@@ -60,7 +60,8 @@ typedef struct pe_params {
 /* One Keras GRU layer (precise/model.py:77-81), Keras weight layout, gate order z|r|h. */
 typedef struct pe_gru_layer {
     int32_t n_in;                    /* F (13) for layer 0, units of the previous layer after */
-    int32_t units;                   /* H (20)                                                */
+    int32_t units;                   /* H (20): 1..32 register-resident kernels; 64..256 (multiples of
+                                        64) the streamed-weight kernel                            */
     const float* kernel;             /* [n_in][3*units] row-major                              */
     const float* recurrent_kernel;   /* [units][3*units]                                       */
     const float* bias;               /* [3*units]                                              */
@@ -68,7 +69,8 @@ typedef struct pe_gru_layer {
 
 /* Sequential([GRU..., Dense(1, sigmoid)])   (precise/model.py:76-82) */
 typedef struct pe_weights {
-    int32_t n_layers;                /* 1 in the reference                                     */
+    int32_t n_layers;                /* 1 in the reference; 2 = GRU(H, return_sequences) -> GRU(H) with
+                                        equal widths H in {64,128,192,256} (BASELINE configs[3])  */
     const pe_gru_layer* layers;
     const float* dense_kernel;       /* [units_last]                                           */
     float dense_bias;

@@ -54,6 +54,11 @@ struct pe_engine {
     // packed network
     float* wxd = nullptr;
     float* wx = nullptr; float* wr1 = nullptr; float* wr2 = nullptr; float* bias = nullptr; float* wd = nullptr;
+    // wide / stacked network (units 64..256, 1-2 layers): weight streams in MFMA A-operand order
+    bool wide = false;
+    float* wide_buf[2][6] = {{nullptr}};     // per layer: wx1, wr1, wx2, wr2, b1, b2
+    int wide_kx4[2] = {1, 1};
+    float* wide_wd = nullptr;
     // bf16-operand network (pe_params.gru_precision = 1)
     uint16_t* wx_bf16 = nullptr; uint16_t* wr_bf16 = nullptr; float* bias_bf16 = nullptr; float* wd_bf16 = nullptr;
     // on-device ThresholdDecoder / TriggerDetector (pe_set_decoder / pe_set_trigger)
@@ -306,6 +311,57 @@ int pack_gru_weights_bf16(pe_engine* e, const pe_gru_layer& L, const float* dens
     return PE_OK;
 }
 
+// Wide / stacked network (gru_wide_device.h): wave w owns output tiles tau = w TPW + t of every gate;
+// row i of a tile <-> unit 16 tau + 4 (i & 3) + (i >> 2); k-step rho, k-slot gk <-> source unit 4 rho + gk
+// (layer 0 input: k-step kk <-> feature 4 gk + kk).  Streams: [wave][k-group][tile][lane] float4.
+int pack_gru_weights_wide(pe_engine* e, const pe_weights* w) {
+    const int H = w->layers[0].units, TPW = H / 64, H16 = H / 16;
+    for (int l = 0; l < w->n_layers; ++l) {
+        const pe_gru_layer& L = w->layers[l];
+        const int kx4 = l == 0 ? 1 : H16;
+        const int F = L.n_in;
+        e->wide_kx4[l] = kx4;
+        auto in_weight = [&](int rho, int gk, int col) -> float {      // input part, k-step rho, k-slot gk
+            if (l == 0) { const int phi = 4 * gk + rho; return phi < F ? L.kernel[(size_t)phi * 3 * H + col] : 0.f; }
+            return L.kernel[(size_t)(4 * rho + gk) * 3 * H + col];
+        };
+        for (int phase = 0; phase < 2; ++phase) {
+            const int NT = phase == 0 ? 2 * TPW : TPW;
+            std::vector<float> wx((size_t)4 * kx4 * NT * 64 * 4, 0.f), wr((size_t)4 * H16 * NT * 64 * 4, 0.f);
+            std::vector<float> bias((size_t)4 * NT * 4 * 64, 0.f);
+            for (int wv = 0; wv < 4; ++wv)
+                for (int tl = 0; tl < NT; ++tl) {
+                    const int gate = phase == 0 ? (tl < TPW ? 0 : 1) : 2;
+                    const int tau = wv * TPW + (tl % TPW);
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i = lane & 15, gk = lane >> 4;
+                        const int col = gate * H + 16 * tau + 4 * (i & 3) + (i >> 2);
+                        for (int r4 = 0; r4 < kx4; ++r4)
+                            for (int q = 0; q < 4; ++q)
+                                wx[((((size_t)wv * kx4 + r4) * NT + tl) * 64 + lane) * 4 + q] = in_weight(4 * r4 + q, gk, col);
+                        for (int r4 = 0; r4 < H16; ++r4)
+                            for (int q = 0; q < 4; ++q)
+                                wr[((((size_t)wv * H16 + r4) * NT + tl) * 64 + lane) * 4 + q] =
+                                    L.recurrent_kernel[(size_t)(4 * (4 * r4 + q) + gk) * 3 * H + col];
+                        for (int q = 0; q < 4; ++q)      // C operand: this lane's output rows 4 gk + q
+                            bias[(((size_t)wv * NT + tl) * 4 + q) * 64 + lane] = L.bias[gate * H + 16 * tau + 4 * q + gk];
+                    }
+                }
+            int rc;
+            if ((rc = dev_upload(e, &e->wide_buf[l][phase == 0 ? 0 : 2], wx))) return rc;
+            if ((rc = dev_upload(e, &e->wide_buf[l][phase == 0 ? 1 : 3], wr))) return rc;
+            if ((rc = dev_upload(e, &e->wide_buf[l][phase == 0 ? 4 : 5], bias))) return rc;
+        }
+    }
+    std::vector<float> wd((size_t)4 * TPW * 4 * 64, 0.f);
+    for (int wv = 0; wv < 4; ++wv)
+        for (int tp = 0; tp < TPW; ++tp)
+            for (int q = 0; q < 4; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    wd[(((size_t)wv * TPW + tp) * 4 + q) * 64 + lane] = w->dense_kernel[16 * (wv * TPW + tp) + 4 * q + (lane >> 4)];
+    return dev_upload(e, &e->wide_wd, wd);
+}
+
 StreamGeom geom(const pe_engine* e) {
     StreamGeom g;
     g.n_streams = e->n_streams;
@@ -374,10 +430,34 @@ GruArgs gru_args(const pe_engine* e) {
     return a;
 }
 
+// Network launch for any input mode (0 explicit batch, 1 ring, 2 row sequence)
+int launch_network(pe_engine* e, const GruArgs& g, int mode, hipStream_t s) {
+    if (e->wide) {
+        WideArgs wa{};
+        wa.base = g;
+        wa.n_layers = e->n_layers;
+        wa.units = e->units;
+        wa.wd = e->wide_wd;
+        for (int l = 0; l < e->n_layers; ++l) {
+            wa.layer[l].wx1 = reinterpret_cast<const float4*>(e->wide_buf[l][0]);
+            wa.layer[l].wr1 = reinterpret_cast<const float4*>(e->wide_buf[l][1]);
+            wa.layer[l].wx2 = reinterpret_cast<const float4*>(e->wide_buf[l][2]);
+            wa.layer[l].wr2 = reinterpret_cast<const float4*>(e->wide_buf[l][3]);
+            wa.layer[l].b1 = e->wide_buf[l][4];
+            wa.layer[l].b2 = e->wide_buf[l][5];
+            wa.layer[l].kx4 = e->wide_kx4[l];
+        }
+        PE_HIP(e, launch_gru_wide(wa, mode, s));
+        return PE_OK;
+    }
+    PE_HIP(e, launch_gru_small(g, mode, s));
+    return PE_OK;
+}
+
 int launch_gru_ring(pe_engine* e, float* out_dev, hipStream_t s) {
     GruArgs a = gru_args(e);
     a.out = out_dev;
-    PE_HIP(e, launch_gru_small(a, 1, s));
+    return launch_network(e, a, 1, s);
     return PE_OK;
 }
 
@@ -392,7 +472,7 @@ int check_chunk(pe_engine* e, const void* pcm, int chunk) {
 // update (it needs window - frame_len more samples), so the network does not depend on it.
 bool can_fuse(const pe_engine* e, int chunk) {
     const int flen = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
-    return e->fused && chunk <= e->prm.window_samples - flen;
+    return e->fused && !e->wide && chunk <= e->prm.window_samples - flen;
 }
 
 int do_update(pe_engine* e, const int16_t* pcm_dev, int chunk, float* raw_out_dev, float* feats_out_dev,
@@ -446,9 +526,20 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     if (p->use_delta && p->gru_precision != 0) return fail(nullptr, PE_ERR_UNSUPPORTED, "use_delta has no bf16 kernel");
     if (p->mfcc_precision != 0 && p->mfcc_precision != 1) return fail(nullptr, PE_ERR_INVALID, "mfcc_precision must be 0 (f64) or 1 (f32)");
     if (p->gru_precision != 0 && p->gru_precision != 1) return fail(nullptr, PE_ERR_INVALID, "gru_precision must be 0 (f32) or 1 (bf16 operands)");
-    if (w->n_layers != 1 || !w->layers) return fail(nullptr, PE_ERR_UNSUPPORTED, "only single-layer GRU networks have a kernel (got %d layers)", w->n_layers);
+    if (w->n_layers < 1 || w->n_layers > 2 || !w->layers) return fail(nullptr, PE_ERR_UNSUPPORTED, "networks of 1 or 2 GRU layers have kernels (got %d layers)", w->n_layers);
     const pe_gru_layer& L = w->layers[0];
-    if (L.units < 1 || L.units > 32) return fail(nullptr, PE_ERR_UNSUPPORTED, "register-resident GRU kernel needs 1 <= units <= 32 (got %d)", L.units);
+    const bool wide = w->n_layers == 2 || L.units > 32;
+    if (!wide && L.units < 1) return fail(nullptr, PE_ERR_INVALID, "units must be positive");
+    if (wide) {
+        if (L.units % 64 != 0 || L.units < 64 || L.units > 256)
+            return fail(nullptr, PE_ERR_UNSUPPORTED, "the streamed-weight GRU kernel needs units in {64, 128, 192, 256} (got %d); the register-resident one units <= 32 and one layer", L.units);
+        if (p->use_delta || p->gru_precision != 0) return fail(nullptr, PE_ERR_UNSUPPORTED, "use_delta / bf16 have no wide-GRU kernel");
+        if (w->n_layers == 2) {
+            const pe_gru_layer& L2 = w->layers[1];
+            if (L2.units != L.units || L2.n_in != L.units) return fail(nullptr, PE_ERR_UNSUPPORTED, "stacked layers must have equal widths (layer 2: n_in=%d units=%d)", L2.n_in, L2.units);
+            if (!L2.kernel || !L2.recurrent_kernel || !L2.bias) return fail(nullptr, PE_ERR_INVALID, "null weight pointer");
+        }
+    }
     const int feature_size = p->use_delta ? 2 * p->n_mfcc : p->n_mfcc;          // params.py:99-109
     if (L.n_in != feature_size) return fail(nullptr, PE_ERR_INVALID, "layer n_in=%d does not match feature_size=%d", L.n_in, feature_size);
     if (!L.kernel || !L.recurrent_kernel || !L.bias || !w->dense_kernel) return fail(nullptr, PE_ERR_INVALID, "null weight pointer");
@@ -462,7 +553,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     e->n_streams = n_streams;
     e->n_tiles = (n_streams + kTileStreams - 1) / kTileStreams;
     e->n_padded = e->n_tiles * kTileStreams;
-    e->units = L.units; e->n_in = p->n_mfcc; e->n_layers = 1;
+    e->units = L.units; e->n_in = p->n_mfcc; e->n_layers = w->n_layers; e->wide = wide;
     e->dense_bias = w->dense_bias;
     const int flen = p->window_samples < kNfft ? p->window_samples : kNfft;
     // frames computed (first flen samples arrived) but not yet emitted (whole window arrived):
@@ -482,7 +573,8 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         if ((rc = dev_alloc(e, &e->ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kRowFloats))) break;
         rc = (p->mfcc_precision == 0) ? build_tables<double>(e, mel_filters) : build_tables<float>(e, mel_filters);
         if (rc) break;
-        if ((rc = pack_gru_weights(e, L, w->dense_kernel))) break;
+        if (wide) { if ((rc = pack_gru_weights_wide(e, w))) break; }
+        else if ((rc = pack_gru_weights(e, L, w->dense_kernel))) break;
         if (p->gru_precision == 1 && (rc = pack_gru_weights_bf16(e, L, w->dense_kernel))) break;
         for (auto& ev : e->ev)
             if (hipEventCreate(&ev) != hipSuccess) { rc = fail(e, PE_ERR_HIP, "hipEventCreate failed"); break; }
@@ -599,7 +691,7 @@ int pe_predict_device(pe_engine* e, const float* feats_dev, int32_t n, float* ou
     a.waves_per_tile = 1;
     a.feats = feats_dev;
     a.out = out_dev;
-    PE_HIP(e, launch_gru_small(a, 0, static_cast<hipStream_t>(stream)));
+    { int nrc = launch_network(e, a, 0, static_cast<hipStream_t>(stream)); if (nrc) return nrc; }
     return PE_OK;
 }
 
@@ -677,7 +769,7 @@ int pe_evaluate(pe_engine* e, const double* audio_host, int64_t n_samples, int32
     g.row_stride = hop_frames;
     g.out = static_cast<float*>(e->st_out.p);
     g.waves_per_tile = 1;
-    PE_HIP(e, launch_gru_small(g, 2, nullptr));
+    if ((rc = launch_network(e, g, 2, nullptr))) return rc;
     PE_HIP(e, hipMemcpy(out_host, e->st_out.p, (size_t)n_windows * sizeof(float), hipMemcpyDeviceToHost));
     return PE_OK;
 }

@@ -3,6 +3,7 @@
 #include "mfcc_device.h"
 #include "gru_device.h"
 #include "gru_bf16_device.h"
+#include "gru_wide_device.h"
 
 namespace pe {
 
@@ -24,6 +25,35 @@ __global__ __launch_bounds__(256) void mfcc_offline_kernel(const MfccOfflineArgs
 template <int R, int MODE>
 __global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
     gru_tile<R, MODE>(a, blockIdx.x, threadIdx.x);
+}
+
+// ---- wide / stacked GRU: one workgroup per 16-stream tile, weights streamed from L2 -------------------
+template <int TPW, int MODE>
+__global__ __launch_bounds__(256) void gru_wide_kernel(const WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    gru_wide_tile<TPW, MODE>(a, blockIdx.x, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
+}
+
+template <int TPW>
+static hipError_t launch_wide_t(const WideArgs& a, int mode, hipStream_t s) {
+    const int tiles = (a.base.n_streams + kTileStreams - 1) / kTileStreams;
+    if (tiles == 0) return hipSuccess;
+    const size_t lds = (size_t)4 * (64 * TPW / 16) * 256 * sizeof(float);      // 2 layers x {h, r*h}
+    if (mode == kRing) hipLaunchKernelGGL((gru_wide_kernel<TPW, kRing>), dim3(tiles), dim3(256), lds, s, a);
+    else if (mode == kRows) hipLaunchKernelGGL((gru_wide_kernel<TPW, kRows>), dim3(tiles), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((gru_wide_kernel<TPW, kFeats>), dim3(tiles), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gru_wide(const WideArgs& a, int mode, hipStream_t s) {
+    switch (a.units / 64) {
+        case 1: return launch_wide_t<1>(a, mode, s);
+        case 2: return launch_wide_t<2>(a, mode, s);
+        case 3: return launch_wide_t<3>(a, mode, s);
+        case 4: return launch_wide_t<4>(a, mode, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 // ---- GRU, bf16 operands: one wave per 16-stream tile --------------------------------------------------

@@ -138,6 +138,24 @@ struct GruArgs {
     int waves_per_tile;     // 1: one wave per tile (gru_tile);  4: four waves share a tile (gru_tile_mw)
 };
 
+struct WideLayerArgs {
+    const float4* wx1;      // phase 1, input part     [wave][kx4][2 TPW][64] float4
+    const float4* wr1;      // phase 1, recurrent part [wave][H/16][2 TPW][64] float4
+    const float4* wx2;      // phase 2, input part     [wave][kx4][TPW][64] float4
+    const float4* wr2;      // phase 2, recurrent part [wave][H/16][TPW][64] float4
+    const float* b1;        // [wave][2 TPW][4][64]
+    const float* b2;        // [wave][TPW][4][64]
+    int kx4;                // k-groups of the input part: 1 for layer 0 (<= 16 features), H/16 above
+};
+
+struct WideArgs {
+    GruArgs base;          // streams, T, ring / feats / rows addressing, predict_ke, out
+    WideLayerArgs layer[2];
+    int n_layers;
+    int units;              // H
+    const float* wd;        // [wave][TPW][4][64]
+};
+
 struct GatherArgs {         // ring -> [n][T][F] time-ordered features (update_vectors result)
     int n_streams, n_features, n_mfcc, ring_slots;
     const float* ring;
@@ -183,6 +201,7 @@ hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, hipStream_t 
 hipError_t launch_gru_small(const GruArgs& a, int input_mode, hipStream_t s);   // units <= 32; 0 feats, 1 ring, 2 rows
 int gru_small_regs(int units);                  // R = ceil(units/4)
 int gru_small_tiles(int units);                 // NT = ceil(3R/4)
+hipError_t launch_gru_wide(const WideArgs& a, int input_mode, hipStream_t s);      // units 64..256, 1-2 layers
 hipError_t launch_gather(const GatherArgs& a, hipStream_t s);
 hipError_t launch_clear(const ClearArgs& a, hipStream_t s);
 

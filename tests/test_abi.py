@@ -59,9 +59,12 @@ def test_create_argument_validation_without_gpu():
     delta.__dict__['use_delta'] = True
     with pytest.raises(ValueError):                 # use_delta needs a layer with 2 * n_mfcc inputs
         _lib.HipEngine(delta, w, n_streams=1)
-    wide = synth.make_weights(units=(256,))
+    odd = synth.make_weights(units=(100,))               # neither <= 32 nor a multiple of 64
     with pytest.raises(NotImplementedError):
-        _lib.HipEngine(pr, wide, n_streams=1)
+        _lib.HipEngine(pr, odd, n_streams=1)
+    uneven = synth.make_weights(units=(128, 64))
+    with pytest.raises(NotImplementedError):
+        _lib.HipEngine(pr, uneven, n_streams=1)
 
 
 @pytest.mark.skipif(os.path.exists('/dev/kfd'), reason='a GPU is present')

@@ -432,6 +432,47 @@ def test_use_delta_matches_reference_semantics(tmp_path):
         P.pr.__dict__.update(saved)
 
 
+# ---- BASELINE configs[3]: wide / stacked GRU (streamed-weight kernel) ------------------------------------
+@pytest.mark.parametrize('units', [(256, 256), (64,), (128, 128), (192,), (256,)])
+def test_wide_gru_predict_matches_oracle(units):
+    from mycroft_precise_amd._lib import HipEngine
+    w = synth.make_weights(units=units, seed=500 + sum(units))
+    eng = HipEngine(P.pr, w, n_streams=1)
+    rng = np.random.default_rng(len(units))
+    for n in (1, 17, 70):
+        x = rng.normal(0, 2, (n, 29, 13)).astype(np.float32)
+        got, want = eng.predict(x), keras_gru.predict(x, w)
+        assert got.shape == want.shape and np.abs(got - want).max() <= GUARD_RAW, (units, n)
+    eng.close()
+
+
+def test_wide_gru_streaming_and_offline_match_oracle():
+    """configs[3] (256 x 2 layers) behind the same streaming front end: BatchedListener updates, masked
+    clear, and the offline evaluator."""
+    from mycroft_precise_amd.network_runner import BatchedListener, HipRunner
+    from oracle import sonopy_restated as so
+    w = synth.make_weights(units=(256, 256), seed=5)
+    n, n_up = 21, 36
+    pcm = _stream_batch(['tone_noise'] * (n - 3) + ['zeros', 'square', 'quiet'], n_up)
+    hip = BatchedListener(w, n)
+    refs = [ol.OracleListener(w) for _ in range(n)]
+    for u in range(n_up):
+        if u == 20:
+            mask = np.zeros(n, np.uint8); mask[::4] = 1
+            hip.clear(mask)
+            for j in np.nonzero(mask)[0]:
+                refs[j].clear()
+        raw = hip.update_raw(pcm[u])
+        want = np.array([r.update_raw(pcm[u, j].tobytes()) for j, r in enumerate(refs)])
+        assert np.abs(raw - want).max() <= GUARD_RAW, u
+    runner = HipRunner(weights=w)
+    audio = synth.stream_pcm(9, 16000 * 4).astype(np.float32) / np.float32(32768.0)
+    got = runner.evaluate(audio, 2048)
+    mf = so.mfcc_spec(audio.astype(np.float64), 16000, (1600, 800))
+    want = keras_gru.predict(np.stack([mf[i - 29:i] for i in range(29, len(mf), 2)]), w)
+    assert got.shape == want.shape and np.abs(got - want).max() <= GUARD_RAW
+
+
 # ---- BASELINE configs[4]: bf16 operands, tolerance 1e-2 -------------------------------------------------
 TOL_BF16 = 1e-2
 
