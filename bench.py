@@ -114,6 +114,7 @@ def main():
     ap.add_argument('--mfcc-precision', choices=['f64', 'f32'], default='f64')
     ap.add_argument('--gru-precision', choices=['f32', 'bf16'], default='f32',
                     help="bf16 = BASELINE configs[4] arithmetic (bf16 MFMA operands, tol 1e-2); not the headline")
+    ap.add_argument('--units', default='20', help="GRU widths, e.g. 20 (stock, default) or 256,256 (BASELINE configs[3])")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--resident-updates', type=int, default=256,
                     help='distinct PCM chunks kept in HBM per stream (reused cyclically beyond that)')
@@ -139,7 +140,10 @@ def main():
     steps, warmup = args.steps, args.warmup
     n_res = min(args.resident_updates, warmup + steps)
 
-    weights = synth.make_weights()
+    units = tuple(int(u) for u in args.units.split(','))
+    weights = synth.make_weights(units=units)
+    stock = units == (20,)
+    flop_per_window = 2 * sum(29 * 3 * h * (f + h) for f, h in zip((13,) + units[:-1], units)) + 2 * units[-1]
     engine = HipEngine(pr, weights, n_streams=B, device=local_rank, mfcc_precision=args.mfcc_precision,
                        gru_precision=args.gru_precision)
     pcm = synth_pcm_device(n_res, B, rank * B, device)
@@ -210,7 +214,7 @@ def main():
         ev1.synchronize()
         return ev0.elapsed_time(ev1) / n
 
-    fused_ms = bracket_pass(min(steps, 200))
+    fused_ms = bracket_pass(min(steps, 200))          # wide networks: MFCC launch + network launch per update
     # the two roles as separate dependent launches, one HIP event pair per kernel (engine-side events,
     # same stream); each figure carries the event overhead
     mfcc_ms, gru_ms = timed_pass(False)
@@ -231,7 +235,7 @@ def main():
     if rank == 0:
         value = n_global * steps / elapsed
         def tflops(ms):
-            return GRU_FLOP_PER_WINDOW * B / (ms * 1e-3) / 1e12
+            return flop_per_window * B / (ms * 1e-3) / 1e12
 
         def gbs(ms):
             return MFCC_BYTES_PER_WINDOW * B / (ms * 1e-3) / 1e9
@@ -240,16 +244,20 @@ def main():
         mfma_peak = MFMA_F32_PEAK_TFLOPS if args.gru_precision == 'f32' else MFMA_BF16_PEAK_TFLOPS
         fused_name = ('fused_update_kernel<%s,5,true>' if args.gru_precision == 'f32' else 'fused_update_bf16_kernel<%s>') % mfcc_name
         gru_name = 'gru_mw_kernel<5>' if args.gru_precision == 'f32' else 'gru_bf16_kernel<1>'
+        if not stock:
+            fused_name = 'mfcc_stream_kernel<%s> + gru_wide_kernel<%d,1>' % (mfcc_name, units[0] // 64)
+            gru_name = 'gru_wide_kernel<%d,1>' % (units[0] // 64)
         line = {
             'metric': METRIC, 'value': value, 'unit': 'windows/s',
             'n_gpus': world, 'steps': steps, 'warmup': warmup,
             'ms_per_step': 1e3 * elapsed / steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.gru_precision, 'data': 'synthetic',
-            'config': {'workload': 'stock GRU (default ListenerParams) fp32, batch=%d synthetic 16 kHz '
-                                   'streams per MI355X, one 1024-sample chunk per stream per step' % B,
+            'config': {'workload': '%s GRU (default ListenerParams) %s, batch=%d synthetic 16 kHz '
+                                   'streams per MI355X, one 1024-sample chunk per stream per step'
+                                   % ('stock' if stock else 'wide %s' % 'x'.join(map(str, units)), args.gru_precision, B),
                        'streams_per_gpu': B, 'global_streams': n_global, 'chunk_samples': CHUNK,
-                       'gru': 'H=20, T=29, F=13, ' + ('f32 MFMA 16x16x4' if args.gru_precision == 'f32' else 'bf16 MFMA 16x16x32, f32 accumulate'),
+                       'gru': 'H=%s, T=29, F=13, ' % args.units + ('f32 MFMA 16x16x4' if args.gru_precision == 'f32' else 'bf16 MFMA 16x16x32, f32 accumulate'),
                        'mfcc_dtype': args.mfcc_precision,
                        'parallelism': 'streams sharded over %d rank(s), final all-gather of probabilities' % world},
             'realtime_streams': value / REALTIME_WINDOWS_PER_S,
@@ -258,13 +266,13 @@ def main():
             'roofline': {'kernel': fused_name, 'bound': 'mfma',
                          'achieved': tflops(fused_ms), 'peak': mfma_peak, 'unit': 'TFLOP/s',
                          'frac': tflops(fused_ms) / mfma_peak,
-                         'traffic': pmc_traffic('fused_update_kernel') if args.gru_precision == 'f32' else None, 'traffic_unit': 'bytes/launch (PMC, profiles/pmc_latest.json)',
+                         'traffic': pmc_traffic('fused_update_kernel') if (args.gru_precision == 'f32' and stock) else None, 'traffic_unit': 'bytes/launch (PMC, profiles/pmc_latest.json)',
                          'avg_launch_ms': fused_ms,
-                         'algorithmic': '%d flop/window x %d windows/launch' % (GRU_FLOP_PER_WINDOW, B)},
+                         'algorithmic': '%d flop/window x %d windows/launch' % (flop_per_window, B)},
             # the two roles launched separately (pe_set_fused(0)), for the per-stage picture
             'roofline_gru': {'kernel': gru_name, 'bound': 'mfma', 'achieved': tflops(gru_ms),
                              'peak': mfma_peak, 'unit': 'TFLOP/s',
-                             'frac': tflops(gru_ms) / mfma_peak, 'traffic': pmc_traffic('gru_mw_kernel') if args.gru_precision == 'f32' else None,
+                             'frac': tflops(gru_ms) / mfma_peak, 'traffic': pmc_traffic('gru_mw_kernel') if (args.gru_precision == 'f32' and stock) else None,
                              'avg_launch_ms': gru_ms},
             'roofline_mfcc': {'kernel': 'mfcc_stream_kernel<%s>' % mfcc_name, 'bound': 'hbm',
                               'achieved': gbs(mfcc_ms), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
