@@ -1,82 +1,90 @@
 """
-Client-side wrapper: drop-in for ``precise_runner``
-(/root/reference/runner/precise_runner/runner.py:22-243): ``Engine``, ``PreciseEngine``
-(subprocess speaking the stdin/stdout chunk protocol), ``ListenerEngine`` (in-process),
-``ReadWriteStream``, ``TriggerDetector`` and ``PreciseRunner``.  Standard library only.
+Client side of the engine protocol -- API-compatible stand-in for the ``precise_runner`` package
+(/root/reference/runner/precise_runner/runner.py:22-243, exported names per ``__init__.py:1``).
 
-``PreciseEngine`` works unchanged against ``python -m mycroft_precise_amd.scripts.engine`` (the
-MI355X engine executable); ``ListenerEngine`` wraps an in-process
-``mycroft_precise_amd.network_runner.Listener``.
+What a user of that package relies on, and gets here unchanged:
+
+* ``Engine`` -- ``chunk_size`` (bytes per prediction), ``start()``, ``stop()``,
+  ``get_prediction(chunk) -> float``;
+* ``PreciseEngine(exe_file, model_file, chunk_size=2048)`` -- child process fed raw PCM on stdin,
+  answering one ASCII float per line; ``ValueError`` for a chunk of the wrong length;
+* ``ListenerEngine(listener, chunk_size=2048)`` -- same interface around an in-process ``Listener``;
+* ``ReadWriteStream`` -- thread-safe byte pipe with blocking ``read(n, timeout)``;
+* ``TriggerDetector(chunk_size, sensitivity, trigger_level).update(prob) -> bool``;
+* ``PreciseRunner(engine, trigger_level, sensitivity, stream, on_prediction, on_activation)`` with
+  ``start / stop / pause / play``.
+
+Only the standard library is needed (``pyaudio`` solely when no ``stream`` is supplied).  The MI355X
+engine executable is ``python -m mycroft_precise_amd.scripts.engine``.
 """
 import atexit
+import subprocess
 import threading
 import time
-from subprocess import PIPE, Popen
+
+_REARM_BYTES = 8 * 2048        # audio swallowed after an activation, in bytes (runner.py:137)
 
 
 class Engine(object):
-    """Interface: ``chunk_size`` bytes in, one confidence out (runner.py:22-33)."""
+    """Anything that turns one chunk of audio into one confidence."""
 
     def __init__(self, chunk_size=2048):
         self.chunk_size = chunk_size
 
     def start(self):
-        pass
+        """Acquire resources (no-op by default)."""
 
     def stop(self):
-        pass
+        """Release resources (no-op by default)."""
 
     def get_prediction(self, chunk):
         raise NotImplementedError
 
 
 class PreciseEngine(Engine):
-    """
-    Wraps an engine executable (runner.py:36-67).
+    """Engine living in a child process.
 
-    Args:
-        exe_file (Union[str, list]): executable, or argv prefix such as
-            ``['python', '-m', 'mycroft_precise_amd.scripts.engine']``
-        model_file (str): model to load (with its ``.params``)
-        chunk_size (int): *bytes* per prediction
+    ``exe_file`` is an executable path or an argv prefix (list); the child is started as
+    ``exe_file... model_file chunk_size`` and must speak the stdin/stdout protocol of
+    ``precise/scripts/engine.py``.
     """
 
     def __init__(self, exe_file, model_file, chunk_size=2048):
-        Engine.__init__(self, chunk_size)
-        prefix = list(exe_file) if isinstance(exe_file, list) else [exe_file]
-        self.exe_args = prefix + [model_file, str(self.chunk_size)]
+        super(PreciseEngine, self).__init__(chunk_size)
+        argv = list(exe_file) if isinstance(exe_file, list) else [exe_file]
+        self.exe_args = argv + [model_file, str(chunk_size)]
         self.proc = None
 
     def start(self):
-        self.proc = Popen(self.exe_args, stdin=PIPE, stdout=PIPE)
+        self.proc = subprocess.Popen(self.exe_args, stdin=subprocess.PIPE, stdout=subprocess.PIPE)
 
     def stop(self):
-        if self.proc:
-            self.proc.kill()
-            self.proc = None
+        child, self.proc = self.proc, None
+        if child is not None:
+            child.kill()
 
     def get_prediction(self, chunk):
         if len(chunk) != self.chunk_size:
             raise ValueError('Invalid chunk size: ' + str(len(chunk)))
-        self.proc.stdin.write(chunk)
-        self.proc.stdin.flush()
-        return float(self.proc.stdout.readline())
+        pipe_in, pipe_out = self.proc.stdin, self.proc.stdout
+        pipe_in.write(chunk)
+        pipe_in.flush()
+        return float(pipe_out.readline())
 
 
 class ListenerEngine(Engine):
-    """In-process engine around a Listener (runner.py:70-73)."""
+    """Engine backed by ``listener.update`` in this process."""
 
     def __init__(self, listener, chunk_size=2048):
-        Engine.__init__(self, chunk_size)
+        super(ListenerEngine, self).__init__(chunk_size)
         self.get_prediction = listener.update
 
 
 class ReadWriteStream(object):
-    """
-    Byte pipe that can be written at any pace; ``read(n)`` blocks until n bytes are there.  When
-    ``chop_samples`` is set and more than that is buffered, a read first drops everything but the
-    trailing ``len % chop_samples`` bytes (runner.py:76-112).
-    """
+    """Byte pipe: producers ``write`` whenever they like, a consumer ``read(n)`` blocks until ``n``
+    bytes are available (or ``timeout`` seconds passed, returning ``b''``).  With ``chop_samples`` set
+    and more than that buffered, a read first discards all but the trailing
+    ``len(buffer) % chop_samples`` bytes -- and nothing at all when that remainder is zero."""
 
     def __init__(self, s=b'', chop_samples=-1):
         self.buffer = s
@@ -86,22 +94,26 @@ class ReadWriteStream(object):
     def __len__(self):
         return len(self.buffer)
 
+    def _chop(self):
+        if 0 < self.chop_samples < len(self.buffer):
+            keep = len(self.buffer) % self.chop_samples
+            if keep:
+                self.buffer = self.buffer[-keep:]
+
     def read(self, n=-1, timeout=None):
         with self._cond:
             if n == -1:
                 n = len(self.buffer)
-            if 0 < self.chop_samples < len(self.buffer):
-                keep = len(self.buffer) % self.chop_samples
-                self.buffer = self.buffer[-keep:]          # keep == 0 keeps everything (slice [-0:])
-            deadline = None if timeout is None else time.time() + timeout
+            self._chop()
+            give_up = None if timeout is None else time.time() + timeout
             while len(self.buffer) < n:
-                remaining = None if deadline is None else deadline - time.time()
-                if remaining is not None and remaining <= 0:
+                left = None if give_up is None else give_up - time.time()
+                if left is not None and left <= 0:
                     return b''
-                if not self._cond.wait(remaining):
+                if not self._cond.wait(left):
                     return b''
-            chunk, self.buffer = self.buffer[:n], self.buffer[n:]
-            return chunk
+            head, self.buffer = self.buffer[:n], self.buffer[n:]
+            return head
 
     def write(self, s):
         with self._cond:
@@ -109,15 +121,15 @@ class ReadWriteStream(object):
             self._cond.notify_all()
 
     def flush(self):
-        """sys.stdout compatibility"""
+        """Present so the object can stand in for ``sys.stdout``."""
 
 
 class TriggerDetector:
-    """
-    Debounces per-chunk predictions into activations (runner.py:115-142): an activation fires when
-    more than ``trigger_level`` chunks net of decays were above ``1 - sensitivity``; after firing
-    the counter is parked at -(8*2048)//chunk_size and counts back up to zero, swallowing chunks.
-    """
+    """Turns a run of per-chunk confidences into discrete activations.
+
+    A counter climbs by one for every chunk above ``1 - sensitivity`` and decays by one otherwise;
+    passing ``trigger_level`` fires, after which the counter is parked ``8 * 2048 / chunk_size`` chunks
+    below zero and has to climb back before anything can fire again (runner.py:115-142)."""
 
     def __init__(self, chunk_size, sensitivity=0.5, trigger_level=3):
         self.chunk_size = chunk_size
@@ -135,22 +147,42 @@ class TriggerDetector:
         self.activation += 1
         fired = self.activation > self.trigger_level
         if fired or (hot and self.activation < 0):
-            self.activation = -(8 * 2048) // self.chunk_size
+            self.activation = -_REARM_BYTES // self.chunk_size
+        return fired
+
+
+class BatchTriggerDetector:
+    """``TriggerDetector`` for many streams at once (numpy, host side): ``update(probs[n])`` returns the
+    boolean activations of this round.  Same state machine per stream; ``pe_decode`` keeps an identical
+    one on the device for ``BatchedListener.update_detect``."""
+
+    def __init__(self, n_streams, chunk_size, sensitivity=0.5, trigger_level=3):
+        import numpy as np
+        self._np = np
+        self.chunk_size = chunk_size
+        self.sensitivity = sensitivity
+        self.trigger_level = trigger_level
+        self.activation = np.zeros(int(n_streams), dtype=np.int64)
+
+    def update(self, probs):
+        np = self._np
+        hot = np.asarray(probs, dtype=np.float64) > 1.0 - self.sensitivity
+        act = self.activation
+        counting = hot | (act < 0)                      # streams whose counter moves up this round
+        decayed = np.where(~counting & (act > 0), act - 1, act)
+        bumped = act + 1
+        fired = counting & (bumped > self.trigger_level)
+        rearm = counting & (fired | (hot & (bumped < 0)))
+        self.activation = np.where(rearm, -_REARM_BYTES // self.chunk_size, np.where(counting, bumped, decayed))
         return fired
 
 
 class PreciseRunner(object):
-    """
-    Reads audio from ``stream`` in ``engine.chunk_size``-byte chunks on a daemon thread, feeds the
-    engine, reports every prediction and debounced activations (runner.py:145-243).
+    """Pumps ``stream`` into ``engine`` on a daemon thread.
 
-    Args:
-        engine (Engine)
-        trigger_level (int): chunk activations needed to trigger on_activation
-        sensitivity (float): 0.0 .. 1.0
-        stream (BinaryIO): 16 kHz mono int16 audio source; the microphone (pyaudio) if None
-        on_prediction (Callable[[float], None])
-        on_activation (Callable[[], None])
+    Every ``engine.chunk_size`` bytes read produce one ``on_prediction(prob)``; a ``TriggerDetector``
+    built from ``sensitivity`` / ``trigger_level`` decides when to call ``on_activation()``.  Without a
+    ``stream`` the default microphone is opened through pyaudio (16 kHz, mono, int16).
     """
 
     def __init__(self, engine, trigger_level=3, sensitivity=0.5, stream=None,
@@ -161,44 +193,50 @@ class PreciseRunner(object):
         self.on_prediction = on_prediction
         self.on_activation = on_activation
         self.chunk_size = engine.chunk_size
+        self.detector = TriggerDetector(self.chunk_size, sensitivity, trigger_level)
         self.pa = None
         self.thread = None
         self.running = False
         self.is_paused = False
-        self.detector = TriggerDetector(self.chunk_size, sensitivity, trigger_level)
         atexit.register(self.stop)
 
+    # -- microphone plumbing (only without a caller-supplied stream) ---------------------------------
+    def _open_microphone(self):
+        import pyaudio
+        self.pa = pyaudio.PyAudio()
+        self.stream = self.pa.open(16000, 1, pyaudio.paInt16, True, frames_per_buffer=self.chunk_size)
+
     def _wrap_stream_read(self, stream):
-        """pyaudio streams count samples, not bytes: read(n) -> read(n // 2)."""
+        """pyaudio counts samples where everything else here counts bytes."""
         try:
             import pyaudio
         except ImportError:
             return
         if getattr(stream.read, '__func__', None) is pyaudio.Stream.read:
-            stream.read = lambda x: pyaudio.Stream.read(stream, x // 2, False)
+            stream.read = lambda nbytes: pyaudio.Stream.read(stream, nbytes // 2, False)
 
+    # -- lifecycle -----------------------------------------------------------------------------------
     def start(self):
         if self.stream is None:
-            from pyaudio import PyAudio, paInt16
-            self.pa = PyAudio()
-            self.stream = self.pa.open(16000, 1, paInt16, True, frames_per_buffer=self.chunk_size)
+            self._open_microphone()
         self._wrap_stream_read(self.stream)
         self.engine.start()
-        self.running = True
         self.is_paused = False
-        self.thread = threading.Thread(target=self._handle_predictions)
-        self.thread.daemon = True
-        self.thread.start()
+        self.running = True
+        worker = threading.Thread(target=self._handle_predictions)
+        worker.daemon = True
+        self.thread = worker
+        worker.start()
 
     def stop(self):
-        if self.thread:
+        worker, self.thread = self.thread, None
+        if worker is not None:
             self.running = False
             if isinstance(self.stream, ReadWriteStream):
-                self.stream.write(b'\0' * self.chunk_size)      # unblock the reader
-            self.thread.join()
-            self.thread = None
+                self.stream.write(b'\0' * self.chunk_size)       # wake a reader blocked on an empty pipe
+            worker.join()
         self.engine.stop()
-        if self.pa:
+        if self.pa is not None:
             self.pa.terminate()
             self.stream.stop_stream()
             self.stream = self.pa = None

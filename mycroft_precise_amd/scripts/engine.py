@@ -27,31 +27,38 @@ def build_parser():
 
 
 class EngineScript:
+    """``create(model_name=..., chunk_size=...)`` mirrors how the reference's tests drive its scripts
+    (base_script.py:13-30); ``run()`` serves predictions until stdin ends."""
+
     def __init__(self, args):
-        self.args = args
         if sys.stdin.isatty():
             raise ValueError('Please pipe audio via stdin using < audio.wav')
+        self.args = args
 
     @classmethod
     def create(cls, **kwargs):
-        ns = argparse.Namespace(model_name=None, chunk_size=-1)
-        ns.__dict__.update(kwargs)
-        return cls(ns)
+        defaults = dict(model_name=None, chunk_size=-1)
+        defaults.update(kwargs)
+        return cls(argparse.Namespace(**defaults))
+
+    @staticmethod
+    def _emit(sink, confidence):
+        sink.write((str(float(confidence)) + '\n').encode('ascii'))
+        sink.flush()
 
     def run(self):
         from ..network_runner import Listener
-        stdout = sys.stdout
-        sys.stdout = sys.stderr            # only predictions may reach the real stdout
+        real_stdout = sys.stdout
+        sys.stdout = sys.stderr            # library chatter must never reach the prediction pipe
         try:
             listener = Listener(self.args.model_name, self.args.chunk_size)
+            audio_in, sink = sys.stdin.buffer, real_stdout.buffer
             while True:
-                conf = listener.update(sys.stdin.buffer)
-                stdout.buffer.write((str(float(conf)) + '\n').encode('ascii'))
-                stdout.buffer.flush()
+                self._emit(sink, listener.update(audio_in))
         except (EOFError, KeyboardInterrupt):
             pass
         finally:
-            sys.stdout = stdout
+            sys.stdout = real_stdout
 
 
 def main(argv=None):

@@ -164,6 +164,24 @@ def test_trigger_detector_matches_reference(name):
     assert g['fired_' + name].sum() > 0
 
 
+def test_batch_trigger_detector_equals_scalar_detectors():
+    from mycroft_precise_amd.runner import BatchTriggerDetector
+    rng = np.random.default_rng(4)
+    n = 37
+    for chunk_size, sens, level in ((2048, 0.5, 3), (1024, 0.8, 1), (8192, 0.2, 0), (4096, 0.5, 5)):
+        batch = BatchTriggerDetector(n, chunk_size, sens, level)
+        singles = [TriggerDetector(chunk_size, sens, level) for _ in range(n)]
+        fired_total = 0
+        for u in range(300):
+            probs = np.clip(rng.random(n) * 0.6 + (np.sin((np.arange(n) + u) / 6.0) > 0.3) * 0.5, 0, 1)
+            got = batch.update(probs)
+            want = np.array([d.update(float(p)) for d, p in zip(singles, probs)])
+            assert np.array_equal(got, want), (chunk_size, u)
+            assert np.array_equal(batch.activation, [d.activation for d in singles])
+            fired_total += int(got.sum())
+        assert fired_total > 0
+
+
 def test_precise_engine_argv_and_chunk_check():
     e = PreciseEngine('precise-engine', 'model.pb', 4096)
     assert e.exe_args == ['precise-engine', 'model.pb', '4096'] and e.chunk_size == 4096
