@@ -10,7 +10,7 @@ A "step" is one pass of the hot path (pe_update_device: int16 PCM chunk -> MFCC 
 window -> GRU -> probability) over one batch of synthetic streams: one 1024-sample chunk for each
 of ``--streams`` (4096) streams per GPU = BASELINE.json configs[1] at N=1 and configs[2] at N=8
 (weak scaling, streams sharded across ranks, no collective on the data path; the per-step
-probabilities of the timed region are all-gathered once at its end, inside the timing).
+probabilities of the timed region are gathered to rank 0 once at its end, inside the timing).
 The PCM of all W+K steps is resident in HBM before the timed region starts.
 
 Rank 0 prints ONE JSON line: metric/value (whole-job windows/s), ms_per_step, plus
@@ -167,7 +167,7 @@ def main():
     # ---- warm-up (fills the 29-row feature windows), untimed --------------------------------
     run(0, warmup, False)
     if world > 1:                                # warm the communicator too
-        gather_probabilities(probs[:1], n_global)
+        gather_probabilities(probs, n_global, dst=0)          # same shape as the timed gather
     torch.cuda.synchronize()
     barrier()
 
@@ -175,7 +175,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(warmup, steps, True)
-    gathered = gather_probabilities(probs, n_global) if world > 1 else probs
+    gathered = gather_probabilities(probs, n_global, dst=0) if world > 1 else probs      # rank 0 only
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -183,8 +183,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert gathered.shape[-1] == n_global
-    finite = bool(torch.isfinite(gathered).all().item())
+    if rank == 0:
+        assert gathered.shape == (steps, n_global)
+    finite = bool(torch.isfinite(gathered if rank == 0 else probs).all().item())
 
     # ---- instrumented passes: HIP-event time per launch, on the launch stream --------------------
     def timed_pass(fused):
@@ -259,7 +260,7 @@ def main():
                        'streams_per_gpu': B, 'global_streams': n_global, 'chunk_samples': CHUNK,
                        'gru': 'H=%s, T=29, F=13, ' % args.units + ('f32 MFMA 16x16x4' if args.gru_precision == 'f32' else 'bf16 MFMA 16x16x32, f32 accumulate'),
                        'mfcc_dtype': args.mfcc_precision,
-                       'parallelism': 'streams sharded over %d rank(s), final all-gather of probabilities' % world},
+                       'parallelism': 'streams sharded over %d rank(s), final RCCL gather of probabilities to rank 0' % world},
             'realtime_streams': value / REALTIME_WINDOWS_PER_S,
             'outputs_finite': finite,
             # dominant kernel of the timed region: the fused launch (GRU role is its long pole)

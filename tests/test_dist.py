@@ -58,6 +58,9 @@ def _worker(rank, world, port, n_streams, steps, ret):
         want = torch.stack([torch.sin(torch.arange(n_streams, dtype=torch.float32) * 0.01 + k) * 0.5 + 0.5
                             for k in range(steps)])
         ok = bool(torch.equal(full, want))
+        # rank-0 gather variant (what bench.py times)
+        on0 = gather_probabilities(local, n_streams, dst=0)
+        ok = ok and ((rank == 0 and torch.equal(on0, want)) or (rank != 0 and on0 is None))
         # max-over-ranks timing reduction used by bench.py
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
