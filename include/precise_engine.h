@@ -101,6 +101,17 @@ int pe_update(pe_engine* e, const int16_t* pcm_host, int32_t chunk_samples, floa
 int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples,
                      float* raw_out_dev, void* hip_stream);
 
+/* n_updates consecutive pe_update calls in two launches (results bit-identical): chunk u of stream s at
+ * pcm[(u * n_streams + s) * chunk_samples], raw_out[u * n_streams + s].  All MFCC updates run first
+ * (one workgroup walks its 16 streams through the chunks), then the network for all
+ * n_updates x n_streams windows at once -- for callers that can buffer a few chunks (catch-up, bulk
+ * replay, latency-tolerant servers) this fills the machine where a single update of a few thousand
+ * streams cannot.  pe_reserve_updates sizes the feature ring for it (and restarts all streams). */
+int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samples);
+int pe_update_many(pe_engine* e, const int16_t* pcm_host, int32_t chunk_samples, int32_t n_updates, float* raw_out_host);
+int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples, int32_t n_updates,
+                          float* raw_out_dev, void* hip_stream);
+
 /* Listener.update_vectors (network_runner.py:125-146): as pe_update without the network;
  * feats_out[n_streams][n_features][n_mfcc] float32, oldest row first (may be NULL). */
 int pe_update_vectors(pe_engine* e, const int16_t* pcm_host, int32_t chunk_samples,

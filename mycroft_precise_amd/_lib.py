@@ -50,6 +50,9 @@ EXPORTS = {
     'pe_clear': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pe_update': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     'pe_update_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'pe_reserve_updates': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    'pe_update_many': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    'pe_update_many_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'pe_update_vectors': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     'pe_update_vectors_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'pe_get_vectors': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -210,6 +213,23 @@ class HipEngine:
         out = np.empty(self.n_streams, dtype=np.float32)
         self._check(self._lib.pe_update(self._h, pcm.ctypes.data, pcm.shape[1], out.ctypes.data))
         return out
+
+    def reserve_updates(self, max_updates: int, max_chunk_samples: int):
+        """Size the engine for update_many (restarts all streams)."""
+        self._check(self._lib.pe_reserve_updates(self._h, int(max_updates), int(max_chunk_samples)))
+
+    def update_many(self, pcm) -> np.ndarray:
+        """int16 [n_updates, n_streams, chunk] -> raw outputs float32 [n_updates, n_streams]; identical to
+        n_updates consecutive update() calls."""
+        pcm = np.ascontiguousarray(pcm, dtype='<i2')
+        if pcm.ndim != 3 or pcm.shape[1] != self.n_streams:
+            raise ValueError('pcm must be int16 [n_updates, n_streams=%d, chunk_samples], got %r' % (self.n_streams, pcm.shape))
+        out = np.empty((pcm.shape[0], self.n_streams), dtype=np.float32)
+        self._check(self._lib.pe_update_many(self._h, pcm.ctypes.data, pcm.shape[2], pcm.shape[0], out.ctypes.data))
+        return out
+
+    def update_many_device(self, pcm_ptr: int, chunk_samples: int, n_updates: int, out_ptr: int, stream: int = 0):
+        self._check(self._lib.pe_update_many_device(self._h, pcm_ptr, chunk_samples, n_updates, out_ptr, stream))
 
     def update_vectors(self, pcm, want_features=True):
         pcm = self._pcm(pcm)

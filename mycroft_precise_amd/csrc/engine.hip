@@ -48,6 +48,9 @@ struct pe_engine {
     bool fused = true;      // MFCC || GRU in one launch when the chunk size allows it
     int gru_waves = 0;      // 0 = auto (4 waves per tile while tiles <= 1024, else 1), or forced 1 / 4
     float* ring = nullptr;
+    // several updates per call (pe_reserve_updates / pe_update_many*)
+    int max_updates = 1;
+    uint32_t* ke_hist = nullptr;
     // tables (both precisions share the int tables)
     unsigned char* table_blob = nullptr;
     int table_blob_bytes = 0;
@@ -396,6 +399,7 @@ MfccStreamArgs<R> mfcc_args(const pe_engine* e, const int16_t* pcm_dev, int chun
     a.st_q = e->st_q[c]; a.st_kc = e->st_kc[c]; a.st_ke = e->st_ke[c];
     a.st_q_next = e->st_q[n]; a.st_kc_next = e->st_kc[n]; a.st_ke_next = e->st_ke[n];
     a.ring = e->ring;
+    a.n_updates = 1; a.ke_hist = nullptr; a.n_padded = e->n_padded;
     return a;
 }
 
@@ -831,6 +835,76 @@ int pe_decode(pe_engine* e, const float* raw_host, double* conf_out_host, unsign
     if (conf_out_host) PE_HIP(e, hipMemcpy(conf_out_host, e->st_conf.p, n * sizeof(double), hipMemcpyDeviceToHost));
     if (fired_out_host) PE_HIP(e, hipMemcpy(fired_out_host, e->st_fired.p, n, hipMemcpyDeviceToHost));
     if (!conf_out_host && !fired_out_host) PE_HIP(e, hipStreamSynchronize(nullptr));
+    return PE_OK;
+}
+
+int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samples) {
+    if (!e || max_updates < 1 || max_chunk_samples < 1) return fail(e, PE_ERR_INVALID, "bad arguments to pe_reserve_updates");
+    if (e->wide) return fail(e, PE_ERR_UNSUPPORTED, "pe_update_many has no wide-GRU path");
+    PE_HIP(e, hipSetDevice(e->device));
+    PE_HIP(e, hipDeviceSynchronize());
+    const int flen = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
+    const int pending = (e->prm.window_samples - flen + e->prm.hop_samples - 1) / e->prm.hop_samples;
+    const long long frames = ((long long)max_updates * max_chunk_samples + e->prm.hop_samples - 1) / e->prm.hop_samples + 1;
+    const int slots = next_pow2((int)(e->prm.n_features + pending + frames));
+    if (slots != e->ring_slots) {
+        for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it)
+            if (*it == e->ring) { e->allocs.erase(it); break; }
+        (void)hipFree(e->ring);
+        e->device_bytes -= (int64_t)e->n_tiles * e->ring_slots * kTileStreams * kRowFloats * (int64_t)sizeof(float);
+        e->ring = nullptr;
+        e->ring_slots = slots;
+        int rc = dev_alloc(e, &e->ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kRowFloats);
+        if (rc) return rc;
+    }
+    if (!e->ke_hist || max_updates > e->max_updates) {
+        int rc = dev_alloc(e, &e->ke_hist, (size_t)max_updates * e->n_padded);
+        if (rc) return rc;
+    }
+    e->max_updates = max_updates;
+    return pe_clear(e, nullptr);          // the ring was re-laid out: streams restart
+}
+
+int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, int32_t n_updates, float* raw_out_dev, void* stream) {
+    int rc = check_chunk(e, pcm_dev, chunk);
+    if (rc) return rc;
+    if (!raw_out_dev || n_updates < 1) return fail(e, PE_ERR_INVALID, "bad arguments to pe_update_many_device");
+    if (n_updates > e->max_updates || !e->ke_hist) return fail(e, PE_ERR_INVALID, "call pe_reserve_updates(e, >= %d, >= %d) first", n_updates, chunk);
+    const int flen = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
+    const int pending = (e->prm.window_samples - flen + e->prm.hop_samples - 1) / e->prm.hop_samples;
+    const long long frames = ((long long)n_updates * chunk + e->prm.hop_samples - 1) / e->prm.hop_samples + 1;
+    if (e->prm.n_features + pending + frames > e->ring_slots) return fail(e, PE_ERR_INVALID, "reserved ring too small for %d updates of %d samples", n_updates, chunk);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (e->prm.mfcc_precision == 0) {
+        MfccStreamArgs<double> a = mfcc_args<double>(e, pcm_dev, chunk);
+        a.n_updates = n_updates; a.ke_hist = e->ke_hist;
+        PE_HIP(e, launch_mfcc_many_f64(a, s));
+    } else {
+        MfccStreamArgs<float> a = mfcc_args<float>(e, pcm_dev, chunk);
+        a.n_updates = n_updates; a.ke_hist = e->ke_hist;
+        PE_HIP(e, launch_mfcc_many_f32(a, s));
+    }
+    e->cur ^= 1;
+    GruArgs g = gru_args(e);
+    g.st_ke = e->ke_hist;
+    g.out = raw_out_dev;
+    g.waves_per_tile = 1;
+    PE_HIP(e, launch_gru_many(g, n_updates, e->n_padded, s));
+    return PE_OK;
+}
+
+int pe_update_many(pe_engine* e, const int16_t* pcm_host, int32_t chunk, int32_t n_updates, float* raw_out_host) {
+    int rc = check_chunk(e, pcm_host, chunk);
+    if (rc) return rc;
+    if (!raw_out_host || n_updates < 1) return fail(e, PE_ERR_INVALID, "bad arguments to pe_update_many");
+    PE_HIP(e, hipSetDevice(e->device));
+    const size_t pcm_bytes = (size_t)n_updates * e->n_streams * chunk * sizeof(int16_t);
+    const size_t out_bytes = (size_t)n_updates * e->n_streams * sizeof(float);
+    if ((rc = ensure(e, e->st_pcm, pcm_bytes))) return rc;
+    if ((rc = ensure(e, e->st_out, out_bytes))) return rc;
+    PE_HIP(e, hipMemcpy(e->st_pcm.p, pcm_host, pcm_bytes, hipMemcpyHostToDevice));
+    if ((rc = pe_update_many_device(e, static_cast<const int16_t*>(e->st_pcm.p), chunk, n_updates, static_cast<float*>(e->st_out.p), nullptr))) return rc;
+    PE_HIP(e, hipMemcpy(raw_out_host, e->st_out.p, out_bytes, hipMemcpyDeviceToHost));
     return PE_OK;
 }
 

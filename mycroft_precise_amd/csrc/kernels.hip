@@ -16,6 +16,32 @@ __global__ __launch_bounds__(256) void mfcc_stream_kernel(const MfccStreamArgs<R
 }
 
 template <class R>
+__global__ __launch_bounds__(256) void mfcc_many_kernel(const MfccStreamArgs<R> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    mfcc_many_tile<R>(a, blockIdx.x, smem);
+}
+
+// network for a whole batch of updates: workgroup (one wave) b serves update b / n_tiles, tile b % n_tiles
+template <int R>
+__global__ __launch_bounds__(64) void gru_many_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
+    const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
+    GruArgs b = a;
+    b.st_ke = a.st_ke + (size_t)u * n_padded;
+    b.out = a.out + (size_t)u * a.n_streams;
+    b.predict_ke = 0;
+    gru_tile<R, kRing>(b, tile, threadIdx.x);
+}
+
+__global__ __launch_bounds__(64) void gru_many_bf16_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
+    const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
+    GruArgs b = a;
+    b.st_ke = a.st_ke + (size_t)u * n_padded;
+    b.out = a.out + (size_t)u * a.n_streams;
+    b.predict_ke = 0;
+    gru_tile_bf16<kRing>(b, tile, threadIdx.x);
+}
+
+template <class R>
 __global__ __launch_bounds__(256) void mfcc_offline_kernel(const MfccOfflineArgs<R> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     mfcc_offline_block<R>(a, smem);
@@ -136,6 +162,16 @@ static hipError_t launch_offline(const MfccOfflineArgs<R>& a, hipStream_t s) {
 
 hipError_t launch_mfcc_stream_f64(const MfccStreamArgs<double>& a, hipStream_t s) { return launch_stream<double>(a, s); }
 hipError_t launch_mfcc_stream_f32(const MfccStreamArgs<float>& a, hipStream_t s) { return launch_stream<float>(a, s); }
+template <class R>
+static hipError_t launch_many(const MfccStreamArgs<R>& a, hipStream_t s) {
+    const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
+    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc);
+    hipLaunchKernelGGL(mfcc_many_kernel<R>, dim3(tiles), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_mfcc_many_f64(const MfccStreamArgs<double>& a, hipStream_t s) { return launch_many<double>(a, s); }
+hipError_t launch_mfcc_many_f32(const MfccStreamArgs<float>& a, hipStream_t s) { return launch_many<float>(a, s); }
+
 hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, hipStream_t s) { return launch_offline<double>(a, s); }
 hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, hipStream_t s) { return launch_offline<float>(a, s); }
 
@@ -171,6 +207,33 @@ hipError_t launch_gru_small(const GruArgs& a, int from_ring, hipStream_t s) {
         case 6: return launch_r<6>(a, from_ring, s);
         case 7: return launch_r<7>(a, from_ring, s);
         case 8: return launch_r<8>(a, from_ring, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int R>
+static hipError_t launch_many_r(const GruArgs& a, int n_updates, int n_padded, hipStream_t s) {
+    const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
+    hipLaunchKernelGGL((gru_many_kernel<R>), dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
+    return hipGetLastError();
+}
+
+hipError_t launch_gru_many(const GruArgs& a, int n_updates, int n_padded, hipStream_t s) {
+    const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
+    if (tiles == 0 || n_updates == 0) return hipSuccess;
+    if (a.bf16) {
+        hipLaunchKernelGGL(gru_many_bf16_kernel, dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
+        return hipGetLastError();
+    }
+    switch (gru_small_regs(a.units)) {
+        case 1: return launch_many_r<1>(a, n_updates, n_padded, s);
+        case 2: return launch_many_r<2>(a, n_updates, n_padded, s);
+        case 3: return launch_many_r<3>(a, n_updates, n_padded, s);
+        case 4: return launch_many_r<4>(a, n_updates, n_padded, s);
+        case 5: return launch_many_r<5>(a, n_updates, n_padded, s);
+        case 6: return launch_many_r<6>(a, n_updates, n_padded, s);
+        case 7: return launch_many_r<7>(a, n_updates, n_padded, s);
+        case 8: return launch_many_r<8>(a, n_updates, n_padded, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -511,6 +511,115 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
     PE_T(11);
 }
 
+// ---- several updates of every stream in ONE launch (pe_update_many*) ------------------------------------
+// Chunk u of stream s sits at pcm + (u * n_streams + s) * chunk.  A group walks its stream through the
+// n_updates chunks in order -- counters in registers, leftover through its carry row, the next chunk's
+// lines touched while the current one is transformed -- and records the emitted-frame counter after
+// every update in ke_hist[u][stream], so that the network can afterwards be run for all
+// n_updates x n_streams windows at once (bit-identical to n_updates single updates).
+template <class R>
+__device__ __forceinline__ void mfcc_many_tile(const MfccStreamArgs<R>& a, const int tile, unsigned char* smem) {
+    using K = RealK<R>;
+    const StreamGeom& geo = a.geo;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, r = lane & 15;
+    const int j = wave * 4 + grp;
+    const long long s = (long long)tile * kTileStreams + j;
+    const bool active = s < geo.n_streams;
+    LdsTab<R> tab;
+    R* scratch = lds_setup<R>(smem, a.tab, geo.n_filt, geo.n_mfcc, tab);
+    __syncthreads();
+    if (!active) return;
+    R* S = scratch + (wave * 4 + grp) * kGroupScratch;
+    const int C = a.chunk, hop = geo.hop, flen = geo.frame_len, slots = geo.ring_slots;
+    float* ring_rows = a.ring + ((size_t)tile * slots * kTileStreams + j) * kRowFloats;
+    int16_t* carw = a.carry + (size_t)s * kCarryCap;
+    const size_t update_stride = (size_t)geo.n_streams * C;
+
+    int q = a.st_q[s];
+    uint32_t kc = a.st_kc[s], ke = a.st_ke[s];
+    for (int line = r * 64; line < C; line += 16 * 64)
+        (void)*reinterpret_cast<const volatile int16_t*>(a.pcm + (size_t)s * C + line);
+
+    for (int u = 0; u < a.n_updates; ++u) {
+        const int16_t* row = a.pcm + (size_t)u * update_stride + (size_t)s * C;
+        if (u + 1 < a.n_updates)                               // next chunk on its way while this one is transformed
+            for (int line = r * 64; line < C; line += 16 * 64)
+                (void)*reinterpret_cast<const volatile int16_t*>(row + update_stride + line);
+        const int avail = q + C;
+        const int nnew = avail >= flen ? 1 + (avail - flen) / hop : 0;
+        const int qn = avail - nnew * hop;
+        PcmView pv;
+        pv.row = row; pv.car = carw; pv.q = q;
+        pv.pairs = a.pcm_pairs_ok && ((q & 1) == 0) && ((update_stride & 1) == 0);
+        auto fetch = [&](int vb, int limit, int (&dst)[16]) {
+            if (pv.pairs && ((vb | limit) & 1) == 0) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int n = 32 * c + 2 * r;
+                    const int v = vb + (n < limit ? n : 0);
+                    const int16_t* p = (v < q) ? (pv.car + v) : (pv.row + (v - q));
+                    const int val = *reinterpret_cast<const int*>(p);
+                    dst[c] = n < limit ? val : 0;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int n = 32 * c + 2 * r;
+                    dst[c] = (n < limit) ? pv.pair(vb + n, n + 1 < limit) : 0;
+                }
+            }
+        };
+        int cur[16], left[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { cur[c] = 0; left[c] = 0; }
+        const int f_first = nnew > slots ? nnew - slots : 0;
+        if (f_first < nnew) fetch(f_first * hop, flen, cur);
+        if (qn > 0) fetch(nnew * hop, qn, left);
+        float last_row = 0.0f;
+        int last_slot = -1;
+        for (int f = f_first; f < nnew; ++f) {
+            auto load = [&](int c, R& xr, R& xi) {
+                xr = (R)(int)(short)(cur[c] & 0xffff) * K::INV_I16;
+                xi = (R)(cur[c] >> 16) * K::INV_I16;
+            };
+            const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load);
+            const int slot = (int)((kc + (uint32_t)f) & (uint32_t)(slots - 1));
+            const float rowv = (r < geo.n_mfcc) ? (float)coeff : 0.0f;
+            if (f + 1 < nnew) {
+                ring_rows[(size_t)slot * kTileStreams * kRowFloats + r] = rowv;
+                fetch((f + 1) * hop, flen, cur);
+            } else {
+                last_row = rowv;
+                last_slot = slot;
+            }
+        }
+        if (qn > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every read of the old carry has landed
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int n = 32 * c + 2 * r;
+                if (n + 1 < qn) *reinterpret_cast<int*>(carw + n) = left[c];
+                else if (n < qn) carw[n] = (int16_t)(left[c] & 0xffff);
+            }
+        }
+        if (last_slot >= 0) ring_rows[(size_t)last_slot * kTileStreams * kRowFloats + r] = last_row;
+        kc += (uint32_t)nnew;
+        const int m = qn + hop * (int)(kc - ke);
+        if (m >= geo.window) ke += 1u + (uint32_t)((m - geo.window) / hop);
+        q = qn;
+        if (r == 0) a.ke_hist[(size_t)u * a.n_padded + s] = ke;
+        // the next update's carry loads must see this update's carry stores (same lanes, same addresses)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (r == 0) {
+        a.st_q_next[s] = q;
+        a.st_kc_next[s] = kc;
+        a.st_ke_next[s] = ke;
+    }
+}
+
 // ---- stateless whole-buffer form (vectorize_raw) ----------------------------------------------
 template <class R>
 __device__ __forceinline__ void mfcc_offline_block(const MfccOfflineArgs<R>& a, unsigned char* smem) {

@@ -84,6 +84,10 @@ struct MfccStreamArgs {
     uint32_t* st_kc_next;
     uint32_t* st_ke_next;
     float* ring;            // [n_tiles][ring_slots][16 streams][16 floats]
+    // several updates per launch (mfcc_many_tile): chunk u of stream s at pcm + (u*n_streams + s)*chunk
+    int n_updates;
+    uint32_t* ke_hist;      // [n_updates][n_padded] emitted-frame counter after every update
+    int n_padded;
 };
 
 template <class R>
@@ -194,6 +198,10 @@ hipError_t launch_mfcc_stream_f32(const MfccStreamArgs<float>& a, hipStream_t s)
 // one launch, two roles: GRU waves read the feature windows as they will be after this update
 // while MFCC workgroups compute this update's frames (legal when chunk <= window - frame_len:
 // no frame computed now becomes visible now)
+hipError_t launch_mfcc_many_f64(const MfccStreamArgs<double>& a, hipStream_t s);
+hipError_t launch_mfcc_many_f32(const MfccStreamArgs<float>& a, hipStream_t s);
+// network for n_updates x n_streams windows, emitted counters from ke_hist, out[u][stream]
+hipError_t launch_gru_many(const GruArgs& a, int n_updates, int n_padded, hipStream_t s);
 hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const GruArgs& g, hipStream_t s);
 hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const GruArgs& g, hipStream_t s);
 hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, hipStream_t s);

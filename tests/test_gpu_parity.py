@@ -172,6 +172,40 @@ def test_fused_launch_equals_two_dependent_launches(stock_weights):
         assert np.array_equal(a.engine.get_vectors(), b.engine.get_vectors())
 
 
+@pytest.mark.parametrize('gru', ['f32', 'bf16'])
+def test_update_many_equals_consecutive_updates(stock_weights, gru):
+    """pe_update_many: n_updates chunks per stream in two launches == n_updates pe_update calls, bit
+    for bit, for several batch depths and chunk sizes (incl. odd ones and chunks that complete > 1 frame),
+    and interleaved with single updates on the same engine."""
+    from mycroft_precise_amd._lib import HipEngine
+    n = 70
+    kinds = ['tone_noise'] * (n - 3) + ['zeros', 'square', 'quiet']
+    for chunk, depth in ((1024, 8), (1024, 3), (801, 5), (2400, 4), (160, 16)):
+        total = 24 * depth
+        pcm = _stream_batch(kinds, total // depth * depth, chunk)            # [n_up, n, chunk]
+        n_up = pcm.shape[0]
+        a = HipEngine(P.pr, stock_weights, n_streams=n, gru_precision=gru)
+        b = HipEngine(P.pr, stock_weights, n_streams=n, gru_precision=gru)
+        b.reserve_updates(depth, chunk)
+        assert b.info().ring_slots >= a.info().ring_slots
+        u = 0
+        while u < n_up:
+            d = depth if (u // depth) % 3 != 2 else 1          # every third round: a plain single update
+            d = min(d, n_up - u)
+            want = np.stack([a.update(pcm[u + i]) for i in range(d)])
+            got = b.update_many(pcm[u:u + d]) if d > 1 else b.update(pcm[u])[None]
+            assert np.array_equal(got, want), (chunk, depth, u)
+            u += d
+        for x, y in zip(a.stream_state(), b.stream_state()):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a.get_vectors(), b.get_vectors())
+        a.close(); b.close()
+    eng = HipEngine(P.pr, stock_weights, n_streams=4)
+    with pytest.raises(ValueError):
+        eng.update_many(np.zeros((2, 4, 1024), np.int16))          # not reserved
+    eng.close()
+
+
 def test_gru_kernel_shapes_agree_bitwise(stock_weights):
     """pe_set_gru_waves: one wave per tile vs four waves sharing a tile issue the same MFMAs in the
     same order per output element, so they must agree bit for bit (fused and unfused)."""

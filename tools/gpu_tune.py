@@ -61,6 +61,31 @@ for B in (4096, 65536):
             wall, e1, e2 = bench_cfg(B, fused, 1, prec, gru='bf16')
             print('%-8d %-6s %-6s %-5s | %10.2f %10.2f %10.2f | %12.1f' % (B, fused, 'bf16', prec, wall, e1, e2, B / wall), flush=True)
 
+def bench_many(B, depth, prec='f64', gru='f32', rounds=40):
+    eng = _lib.HipEngine(pr, w, n_streams=B, mfcc_precision=prec, gru_precision=gru)
+    eng.reserve_updates(depth, 1024)
+    n_res = 64
+    pcm = (torch.randn((n_res, B, 1024), device=dev) * 3000).to(torch.int16)
+    out = torch.zeros((depth, B), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for i in range(6):
+        eng.update_many_device(pcm[(i * depth) % (n_res - depth)].data_ptr(), 1024, depth, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(rounds):
+        eng.update_many_device(pcm[(i * depth) % (n_res - depth)].data_ptr(), 1024, depth, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / (rounds * depth) * 1e6
+    eng.close()
+    return wall
+
+
+for B in (4096, 16384):
+    for depth in (2, 4, 8, 16):
+        for gru in ('f32', 'bf16'):
+            wall = bench_many(B, depth, gru=gru)
+            print('%-8d MANY depth=%-3d %-5s f64 | %10.2f us/update | %12.1f Mwin/s' % (B, depth, gru, wall, B / wall), flush=True)
+
 # ---- MFCC section timers (debug library) ---------------------------------------------------------
 dbg = os.path.join(REPO, 'mycroft_precise_amd', 'csrc', 'build', 'libprecise_engine_dbg.so')
 if os.path.exists(dbg):
