@@ -40,6 +40,7 @@ struct pe_engine {
     int64_t device_bytes = 0;
     // streaming state
     int16_t* carry = nullptr;
+    int16_t* carry_alt = nullptr;            // pe_update_many writes the leftover here, then the two swap
     // per-stream counters, ping-pong: [cur] is the state now, [cur ^ 1] receives the next update's
     int32_t* st_q[2] = {nullptr, nullptr};
     uint32_t* st_kc[2] = {nullptr, nullptr};
@@ -54,6 +55,7 @@ struct pe_engine {
     // tables (both precisions share the int tables)
     unsigned char* table_blob = nullptr;
     int table_blob_bytes = 0;
+    int mel_parts = 0;                       // partial-sum slots of the mel pass (build_tables)
     // packed network
     float* wxd = nullptr;
     float* wx = nullptr; float* wr1 = nullptr; float* wr2 = nullptr; float* bias = nullptr; float* wd = nullptr;
@@ -187,6 +189,7 @@ int build_tables(pe_engine* e, const double* mel_filters) {
         return x.stream < y.stream;
     });
     if ((int)runs.size() > kMaxMelParts - 1) return fail(e, PE_ERR_UNSUPPORTED, "mel filterbank needs %zu partial sums, limit %d", runs.size(), kMaxMelParts);
+    e->mel_parts = (int)runs.size();
     std::vector<int> flush((size_t)kMelSteps * 16, (int)0xffffffff), pstart(n_filt + 1, 0);
     for (size_t slot = 0; slot < runs.size(); ++slot) {
         const Run& q = runs[slot];
@@ -383,6 +386,7 @@ MfccTables<R> tables(const pe_engine* e) {
     MfccTables<R> t;
     t.blob = e->table_blob;
     t.blob_bytes = e->table_blob_bytes;
+    t.mel_parts = e->mel_parts;
     return t;
 }
 
@@ -400,6 +404,7 @@ MfccStreamArgs<R> mfcc_args(const pe_engine* e, const int16_t* pcm_dev, int chun
     a.st_q_next = e->st_q[n]; a.st_kc_next = e->st_kc[n]; a.st_ke_next = e->st_ke[n];
     a.ring = e->ring;
     a.n_updates = 1; a.ke_hist = nullptr; a.n_padded = e->n_padded;
+    a.n_frame_rows = 1; a.carry_next = e->carry;
     return a;
 }
 
@@ -583,7 +588,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         for (auto& ev : e->ev)
             if (hipEventCreate(&ev) != hipSuccess) { rc = fail(e, PE_ERR_HIP, "hipEventCreate failed"); break; }
         if (rc) break;
-        const size_t lds = lds_layout_bytes(p->mfcc_precision == 0 ? 8 : 4, p->n_filt, p->n_mfcc);
+        const size_t lds = lds_layout_bytes(p->mfcc_precision == 0 ? 8 : 4, p->n_filt, p->n_mfcc, e->mel_parts, kThroughputGroups);
         if (lds > 160 * 1024) { rc = fail(e, PE_ERR_UNSUPPORTED, "MFCC kernel would need %zu bytes of LDS", lds); break; }
         if ((rc = pe_clear(e, nullptr))) break;
         hipError_t se = hipDeviceSynchronize();
@@ -861,6 +866,10 @@ int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samp
         int rc = dev_alloc(e, &e->ke_hist, (size_t)max_updates * e->n_padded);
         if (rc) return rc;
     }
+    if (!e->carry_alt) {
+        int rc = dev_alloc(e, &e->carry_alt, (size_t)e->n_padded * kCarryCap);
+        if (rc) return rc;
+    }
     e->max_updates = max_updates;
     return pe_clear(e, nullptr);          // the ring was re-laid out: streams restart
 }
@@ -873,17 +882,22 @@ int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, i
     const int flen = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
     const int pending = (e->prm.window_samples - flen + e->prm.hop_samples - 1) / e->prm.hop_samples;
     const long long frames = ((long long)n_updates * chunk + e->prm.hop_samples - 1) / e->prm.hop_samples + 1;
+    if ((long long)n_updates * chunk >= (1ll << 30)) return fail(e, PE_ERR_INVALID, "n_updates * chunk_samples must stay below 2^30");
     if (e->prm.n_features + pending + frames > e->ring_slots) return fail(e, PE_ERR_INVALID, "reserved ring too small for %d updates of %d samples", n_updates, chunk);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // frames one stream can complete in this call: one workgroup row per frame, at most kMaxFrameRows rows
+    const long long fmax = ((long long)(kCarryCap - 1) + (long long)n_updates * chunk - flen) / e->prm.hop_samples + 1;
+    const int rows = (int)(fmax < 1 ? 1 : fmax > kMaxFrameRows ? kMaxFrameRows : fmax);
     if (e->prm.mfcc_precision == 0) {
         MfccStreamArgs<double> a = mfcc_args<double>(e, pcm_dev, chunk);
-        a.n_updates = n_updates; a.ke_hist = e->ke_hist;
+        a.n_updates = n_updates; a.ke_hist = e->ke_hist; a.n_frame_rows = rows; a.carry_next = e->carry_alt;
         PE_HIP(e, launch_mfcc_many_f64(a, s));
     } else {
         MfccStreamArgs<float> a = mfcc_args<float>(e, pcm_dev, chunk);
-        a.n_updates = n_updates; a.ke_hist = e->ke_hist;
+        a.n_updates = n_updates; a.ke_hist = e->ke_hist; a.n_frame_rows = rows; a.carry_next = e->carry_alt;
         PE_HIP(e, launch_mfcc_many_f32(a, s));
     }
+    std::swap(e->carry, e->carry_alt);
     e->cur ^= 1;
     GruArgs g = gru_args(e);
     g.st_ke = e->ke_hist;

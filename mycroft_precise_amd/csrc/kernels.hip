@@ -16,9 +16,9 @@ __global__ __launch_bounds__(256) void mfcc_stream_kernel(const MfccStreamArgs<R
 }
 
 template <class R>
-__global__ __launch_bounds__(256) void mfcc_many_kernel(const MfccStreamArgs<R> a) {
+__global__ __launch_bounds__(16 * kThroughputGroups) void mfcc_many_kernel(const MfccStreamArgs<R> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    mfcc_many_tile<R>(a, blockIdx.x, smem);
+    mfcc_many_tile<R>(a, smem);
 }
 
 // network for a whole batch of updates: workgroup (one wave) b serves update b / n_tiles, tile b % n_tiles
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void gru_many_bf16_kernel(const GruArgs a, cons
 }
 
 template <class R>
-__global__ __launch_bounds__(256) void mfcc_offline_kernel(const MfccOfflineArgs<R> a) {
+__global__ __launch_bounds__(16 * kThroughputGroups) void mfcc_offline_kernel(const MfccOfflineArgs<R> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     mfcc_offline_block<R>(a, smem);
 }
@@ -145,7 +145,7 @@ static int frame_split(const StreamGeom&, int, int) { return 1; }
 template <class R>
 static hipError_t launch_stream(const MfccStreamArgs<R>& a, hipStream_t s) {
     const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
-    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc);
+    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc, a.tab.mel_parts, 16);
     const int nsel = frame_split(a.geo, a.chunk, tiles);
     hipLaunchKernelGGL(mfcc_stream_kernel<R>, dim3(tiles * nsel), dim3(256), lds, s, a, nsel);
     return hipGetLastError();
@@ -154,9 +154,9 @@ static hipError_t launch_stream(const MfccStreamArgs<R>& a, hipStream_t s) {
 template <class R>
 static hipError_t launch_offline(const MfccOfflineArgs<R>& a, hipStream_t s) {
     if (a.n_frames <= 0) return hipSuccess;
-    const long long blocks = (a.n_frames + 15) / 16;
-    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc);
-    hipLaunchKernelGGL(mfcc_offline_kernel<R>, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    const long long blocks = (a.n_frames + kThroughputGroups - 1) / kThroughputGroups;
+    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc, a.tab.mel_parts, kThroughputGroups);
+    hipLaunchKernelGGL(mfcc_offline_kernel<R>, dim3((unsigned)blocks), dim3(16 * kThroughputGroups), lds, s, a);
     return hipGetLastError();
 }
 
@@ -165,8 +165,10 @@ hipError_t launch_mfcc_stream_f32(const MfccStreamArgs<float>& a, hipStream_t s)
 template <class R>
 static hipError_t launch_many(const MfccStreamArgs<R>& a, hipStream_t s) {
     const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
-    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc);
-    hipLaunchKernelGGL(mfcc_many_kernel<R>, dim3(tiles), dim3(256), lds, s, a);
+    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc, a.tab.mel_parts, kThroughputGroups);
+    const long long groups = (long long)tiles * (a.n_frame_rows + 1) * kTileStreams;
+    hipLaunchKernelGGL(mfcc_many_kernel<R>, dim3((unsigned)((groups + kThroughputGroups - 1) / kThroughputGroups)),
+                       dim3(16 * kThroughputGroups), lds, s, a);
     return hipGetLastError();
 }
 hipError_t launch_mfcc_many_f64(const MfccStreamArgs<double>& a, hipStream_t s) { return launch_many<double>(a, s); }
@@ -241,7 +243,7 @@ hipError_t launch_gru_many(const GruArgs& a, int n_updates, int n_padded, hipStr
 template <class R, int RG>
 static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const GruArgs& g, hipStream_t s) {
     const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
-    const size_t lds = lds_layout_bytes(sizeof(R), m.geo.n_filt, m.geo.n_mfcc);
+    const size_t lds = lds_layout_bytes(sizeof(R), m.geo.n_filt, m.geo.n_mfcc, m.tab.mel_parts, 16);
     const int nsel = frame_split(m.geo, m.chunk, tiles);
     if (g.waves_per_tile == 4) {
         hipLaunchKernelGGL((fused_update_kernel<R, RG, true>), dim3(tiles + tiles * nsel), dim3(256), lds, s, m, g, tiles, tiles, nsel);
@@ -257,7 +259,7 @@ static hipError_t launch_fused(const MfccStreamArgs<R>& m, const GruArgs& g, hip
     if (g.bf16) {
         const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
         const int gru_blocks = (tiles + 3) / 4;
-        const size_t lds = lds_layout_bytes(sizeof(R), m.geo.n_filt, m.geo.n_mfcc);
+        const size_t lds = lds_layout_bytes(sizeof(R), m.geo.n_filt, m.geo.n_mfcc, m.tab.mel_parts, 16);
         hipLaunchKernelGGL((fused_update_bf16_kernel<R>), dim3(gru_blocks + tiles), dim3(256), lds, s, m, g, gru_blocks, tiles);
         return hipGetLastError();
     }

@@ -129,6 +129,8 @@ struct LdsTab {
     const R* mel_w;         // [2][17][16]
     const int* mel_flush;   // [17][16]
     const int* mel_pstart;  // [n_filt + 1]
+    int spare;              // partial-sum slot nobody reads
+    int group_reals;        // LDS reals per 16-lane group
 };
 
 // Copy the blob with 16-byte loads (all of a thread's loads in flight before its first store), and
@@ -158,6 +160,7 @@ __device__ __forceinline__ R* lds_setup(unsigned char* smem, const MfccTables<R>
     size_t off = (size_t)((unsigned char*)(mw + 2 * kMelSteps * 16) - smem);
     off = (off + 15) & ~(size_t)15;
     int* fl = reinterpret_cast<int*>(smem + off);
+    t.spare = g.mel_parts; t.group_reals = group_scratch_reals(g.mel_parts);
     t.tw256 = tw; t.w512 = w5; t.dct = dct; t.mel_w = mw; t.mel_flush = fl; t.mel_pstart = fl + kMelSteps * 16;
     return reinterpret_cast<R*>(smem + g.blob_bytes);
 }
@@ -271,8 +274,8 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
     // keeps one running sum per "stream" (1st / 2nd filter of the bin) and drops it into a partial
     // slot whenever the table says the filter under that stream changes.  Slots are numbered filter
     // by filter, so the second pass adds a contiguous range in a fixed order.
-    R* LM = S + kPowerPad;
-    R* PART = LM + kMaxFilt;
+    R* LM = S;                    // log-mel energies: over the head of the power spectrum, dead by then
+    R* PART = S + kPowerPad;
 #ifndef PE_ABL_MEL
     {
         R acc0 = R(0), acc1 = R(0);
@@ -284,8 +287,8 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
             // no branch: a step that ends no run stores to the spare slot and keeps its sum
             const int fl = t.mel_flush[i * 16 + r];
             const int s0 = fl & 0xffff, s1 = (fl >> 16) & 0xffff;
-            PART[s0 != 0xffff ? s0 : kMaxMelParts - 1] = acc0;
-            PART[s1 != 0xffff ? s1 : kMaxMelParts - 1] = acc1;
+            PART[s0 != 0xffff ? s0 : t.spare] = acc0;
+            PART[s1 != 0xffff ? s1 : t.spare] = acc1;
             acc0 = s0 != 0xffff ? R(0) : acc0;
             acc1 = s1 != 0xffff ? R(0) : acc1;
         }
@@ -461,7 +464,7 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
     __syncthreads();
     PE_T(1);
     if (!active) return;
-    R* S = scratch + (wave * 4 + grp) * kGroupScratch;
+    R* S = scratch + (wave * 4 + grp) * tab.group_reals;
     float* ring_rows = a.ring + ((size_t)tile * slots * kTileStreams + j) * kRowFloats;
 
     float last_row = 0.0f;                                   // the final frame's ring store is issued
@@ -511,111 +514,132 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
     PE_T(11);
 }
 
-// ---- several updates of every stream in ONE launch (pe_update_many*) ------------------------------------
-// Chunk u of stream s sits at pcm + (u * n_streams + s) * chunk.  A group walks its stream through the
-// n_updates chunks in order -- counters in registers, leftover through its carry row, the next chunk's
-// lines touched while the current one is transformed -- and records the emitted-frame counter after
-// every update in ke_hist[u][stream], so that the network can afterwards be run for all
-// n_updates x n_streams windows at once (bit-identical to n_updates single updates).
+// n_updates consecutive updates of every stream in ONE launch (pe_update_many).  Which samples form
+// which frame is closed-form integer arithmetic over the virtual stream
+//     [carry (q samples)] ++ chunk 0 ++ chunk 1 ++ ... ++ chunk n_updates-1,
+// so the frames of a call are independent tasks: the 16-lane group of task (tile, kb, stream) transforms
+// frames kb, kb + n_kb, ... of its stream (n_kb rows share a tile), and one more row (kb == n_kb) does the
+// bookkeeping -- leftover samples to carry_next, counters to st_*_next, and the emitted-frame counter
+// after EVERY update (ke_hist) that tells the network launch which window each update saw.
+// carry_next must not alias carry: other rows still read the old carry.
 template <class R>
-__device__ __forceinline__ void mfcc_many_tile(const MfccStreamArgs<R>& a, const int tile, unsigned char* smem) {
+__device__ __forceinline__ void mfcc_many_tile(const MfccStreamArgs<R>& a, unsigned char* smem) {
     using K = RealK<R>;
     const StreamGeom& geo = a.geo;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, r = lane & 15;
-    const int j = wave * 4 + grp;
+    // task = (tile, row, stream of the tile), rows 0..n_kb-1 transform frames, row n_kb keeps the books
+    const int n_kb = a.n_frame_rows;
+    const long long task = (long long)blockIdx.x * (blockDim.x >> 4) + wave * 4 + grp;
+    const int j = (int)(task & 15);
+    const int kb = (int)((task >> 4) % (n_kb + 1));
+    const int tile = (int)((task >> 4) / (n_kb + 1));
     const long long s = (long long)tile * kTileStreams + j;
     const bool active = s < geo.n_streams;
+    const bool book = kb == n_kb;
     LdsTab<R> tab;
-    R* scratch = lds_setup<R>(smem, a.tab, geo.n_filt, geo.n_mfcc, tab);
-    __syncthreads();
+    R* scratch = nullptr;
+    // with 16 groups per workgroup a workgroup is exactly one row: bookkeeping workgroups need no tables
+    if (!(kThroughputGroups == 16 && book)) {
+        scratch = lds_setup<R>(smem, a.tab, geo.n_filt, geo.n_mfcc, tab);
+        __syncthreads();
+    }
     if (!active) return;
-    R* S = scratch + (wave * 4 + grp) * kGroupScratch;
-    const int C = a.chunk, hop = geo.hop, flen = geo.frame_len, slots = geo.ring_slots;
-    float* ring_rows = a.ring + ((size_t)tile * slots * kTileStreams + j) * kRowFloats;
-    int16_t* carw = a.carry + (size_t)s * kCarryCap;
+    const int C = a.chunk, hop = geo.hop, flen = geo.frame_len, slots = geo.ring_slots, U = a.n_updates;
     const size_t update_stride = (size_t)geo.n_streams * C;
+    const int q = a.st_q[s];
+    const uint32_t kc = a.st_kc[s];
+    const int avail = q + U * C;
+    const int nnew = avail >= flen ? 1 + (avail - flen) / hop : 0;
+    const int16_t* car = a.carry + (size_t)s * kCarryCap;
+    const int16_t* base = a.pcm + (size_t)s * C;
 
-    int q = a.st_q[s];
-    uint32_t kc = a.st_kc[s], ke = a.st_ke[s];
-    for (int line = r * 64; line < C; line += 16 * 64)
-        (void)*reinterpret_cast<const volatile int16_t*>(a.pcm + (size_t)s * C + line);
-
-    for (int u = 0; u < a.n_updates; ++u) {
-        const int16_t* row = a.pcm + (size_t)u * update_stride + (size_t)s * C;
-        if (u + 1 < a.n_updates)                               // next chunk on its way while this one is transformed
-            for (int line = r * 64; line < C; line += 16 * 64)
-                (void)*reinterpret_cast<const volatile int16_t*>(row + update_stride + line);
-        const int avail = q + C;
-        const int nnew = avail >= flen ? 1 + (avail - flen) / hop : 0;
-        const int qn = avail - nnew * hop;
-        PcmView pv;
-        pv.row = row; pv.car = carw; pv.q = q;
-        pv.pairs = a.pcm_pairs_ok && ((q & 1) == 0) && ((update_stride & 1) == 0);
-        auto fetch = [&](int vb, int limit, int (&dst)[16]) {
-            if (pv.pairs && ((vb | limit) & 1) == 0) {
+    // virtual sample v (0 <= v < avail): carry below q, chunk (v - q) / C above
+    auto vsample = [&](int v) -> int {
+        if (v < q) return (int)car[v];
+        const int w = v - q, u = w / C;
+        return (int)base[(size_t)u * update_stride + (w - u * C)];
+    };
+    // dword loads of (even, odd) pairs: every quantity that shifts a pair boundary must be even, and a
+    // frame may cross at most one chunk boundary
+    const bool fast = a.pcm_pairs_ok && ((q | hop | C) & 1) == 0 && C >= flen;
+    auto fetch = [&](int vb, int limit, int (&dst)[16]) {
+        if (fast && ((vb | limit) & 1) == 0) {
+            const int w0 = vb - q;                              // < 0: the span starts inside the carry
+            int u0 = 0, off0 = w0;
+            if (w0 >= 0) { u0 = w0 / C; off0 = w0 - u0 * C; }
+            const int16_t* rowu = base + (size_t)u0 * update_stride;
+            const ptrdiff_t wrap = (ptrdiff_t)update_stride - C;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const int n = 32 * c + 2 * r;
-                    const int v = vb + (n < limit ? n : 0);
-                    const int16_t* p = (v < q) ? (pv.car + v) : (pv.row + (v - q));
-                    const int val = *reinterpret_cast<const int*>(p);
-                    dst[c] = n < limit ? val : 0;
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const int n = 32 * c + 2 * r;
-                    dst[c] = (n < limit) ? pv.pair(vb + n, n + 1 < limit) : 0;
-                }
+            for (int c = 0; c < 16; ++c) {
+                const int n = 32 * c + 2 * r;
+                const int nn = n < limit ? n : 0;
+                const int v = vb + nn, off = off0 + nn;
+                const int16_t* p = (v < q) ? (car + v) : (rowu + off + (off >= C ? wrap : 0));
+                const int val = *reinterpret_cast<const int*>(p);
+                dst[c] = n < limit ? val : 0;
             }
-        };
-        int cur[16], left[16];
+        } else {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) { cur[c] = 0; left[c] = 0; }
-        const int f_first = nnew > slots ? nnew - slots : 0;
-        if (f_first < nnew) fetch(f_first * hop, flen, cur);
-        if (qn > 0) fetch(nnew * hop, qn, left);
-        float last_row = 0.0f;
-        int last_slot = -1;
-        for (int f = f_first; f < nnew; ++f) {
+            for (int c = 0; c < 16; ++c) {
+                const int n = 32 * c + 2 * r;
+                const int lo = n < limit ? (vsample(vb + n) & 0xffff) : 0;
+                const int hi = n + 1 < limit ? vsample(vb + n + 1) : 0;
+                dst[c] = lo | (hi << 16);
+            }
+        }
+    };
+
+    if (!book) {
+        R* S = scratch + (wave * 4 + grp) * tab.group_reals;
+        float* ring_rows = a.ring + ((size_t)tile * slots * kTileStreams + j) * kRowFloats;
+        const int f_first = nnew > slots ? nnew - slots : 0;   // older frames would be overwritten anyway
+        int k = kb;
+        if (k < f_first) k += ((f_first - k + n_kb - 1) / n_kb) * n_kb;
+        int cur[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) cur[c] = 0;
+        if (k < nnew) fetch(k * hop, flen, cur);
+        for (; k < nnew; k += n_kb) {                          // one trip unless the rows were capped (kMaxFrameRows)
             auto load = [&](int c, R& xr, R& xi) {
                 xr = (R)(int)(short)(cur[c] & 0xffff) * K::INV_I16;
                 xi = (R)(cur[c] >> 16) * K::INV_I16;
             };
             const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load);
-            const int slot = (int)((kc + (uint32_t)f) & (uint32_t)(slots - 1));
-            const float rowv = (r < geo.n_mfcc) ? (float)coeff : 0.0f;
-            if (f + 1 < nnew) {
-                ring_rows[(size_t)slot * kTileStreams * kRowFloats + r] = rowv;
-                fetch((f + 1) * hop, flen, cur);
-            } else {
-                last_row = rowv;
-                last_slot = slot;
-            }
+            const int slot = (int)((kc + (uint32_t)k) & (uint32_t)(slots - 1));
+            ring_rows[(size_t)slot * kTileStreams * kRowFloats + r] = (r < geo.n_mfcc) ? (float)coeff : 0.0f;
+            if (k + n_kb < nnew) fetch((k + n_kb) * hop, flen, cur);
         }
-        if (qn > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every read of the old carry has landed
-            __builtin_amdgcn_wave_barrier();
+        return;
+    }
+
+    // ---- bookkeeping row ---------------------------------------------------------------------------------
+    const int qn = avail - nnew * hop;
+    if (qn > 0) {
+        int left[16];
+        fetch(nnew * hop, qn, left);
+        int16_t* carw = a.carry_next + (size_t)s * kCarryCap;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const int n = 32 * c + 2 * r;
-                if (n + 1 < qn) *reinterpret_cast<int*>(carw + n) = left[c];
-                else if (n < qn) carw[n] = (int16_t)(left[c] & 0xffff);
-            }
+        for (int c = 0; c < 16; ++c) {
+            const int n = 32 * c + 2 * r;
+            if (n + 1 < qn) *reinterpret_cast<int*>(carw + n) = left[c];
+            else if (n < qn) carw[n] = (int16_t)(left[c] & 0xffff);
         }
-        if (last_slot >= 0) ring_rows[(size_t)last_slot * kTileStreams * kRowFloats + r] = last_row;
-        kc += (uint32_t)nnew;
-        const int m = qn + hop * (int)(kc - ke);
-        if (m >= geo.window) ke += 1u + (uint32_t)((m - geo.window) / hop);
-        q = qn;
-        if (r == 0) a.ke_hist[(size_t)u * a.n_padded + s] = ke;
-        // the next update's carry loads must see this update's carry stores (same lanes, same addresses)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (r == 0) {
-        a.st_q_next[s] = q;
-        a.st_kc_next[s] = kc;
+        int qu = q;
+        uint32_t kcu = kc, ke = a.st_ke[s];
+        for (int u = 0; u < U; ++u) {                          // the counters update by update, as pe_update moves them
+            const int av = qu + C;
+            const int nn = av >= flen ? 1 + (av - flen) / hop : 0;
+            qu = av - nn * hop;
+            kcu += (uint32_t)nn;
+            const int m = qu + hop * (int)(kcu - ke);
+            if (m >= geo.window) ke += 1u + (uint32_t)((m - geo.window) / hop);
+            a.ke_hist[(size_t)u * a.n_padded + s] = ke;
+        }
+        a.st_q_next[s] = qu;
+        a.st_kc_next[s] = kcu;
         a.st_ke_next[s] = ke;
     }
 }
@@ -629,9 +653,9 @@ __device__ __forceinline__ void mfcc_offline_block(const MfccOfflineArgs<R>& a, 
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, r = lane & 15;
-    const long long fr = (long long)blockIdx.x * 16 + wave * 4 + grp;
+    const long long fr = (long long)blockIdx.x * (blockDim.x >> 4) + wave * 4 + grp;
     if (fr >= a.n_frames) return;
-    R* S = scratch + (wave * 4 + grp) * kGroupScratch;
+    R* S = scratch + (wave * 4 + grp) * tab.group_reals;
     const double* x = a.audio + fr * geo.hop;
     const int flen = geo.frame_len;
     auto load = [&](int c, R& xr, R& xi) {

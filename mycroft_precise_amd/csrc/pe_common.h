@@ -20,7 +20,22 @@ constexpr int kTrStride = 17;                       // padded row of the 16x16 L
 constexpr int kPowerPad = 16 * kTrStride + 2;       // power spectrum, bin b at b + (b >> 4)
 constexpr int kMelSteps = 17;                       // bins per lane in the mel pass: 16 r .. 16 r + 16
 constexpr int kMaxMelParts = 128;                   // partial filter sums per frame
-constexpr int kGroupScratch = kPowerPad + kMaxFilt + kMaxMelParts;   // reals of LDS per 16-lane group
+constexpr int kMaxFrameRows = 64;                   // pe_update_many: workgroup rows per tile sharing a call's frames
+#ifndef PE_TG
+#define PE_TG 16
+#endif
+// 16-lane groups per workgroup of the batch MFCC kernels.  Measured on MI355X (pe_update_many, 4096 streams x 8
+// updates, f64): 16 groups (256 threads, 2 workgroups per CU) 16.2 us per update; 24 groups (384 threads, 3 waves
+// per SIMD) 19.2; 48 groups (768 threads) 16.7 -- the stage is issue-bound, not occupancy-bound.
+constexpr int kThroughputGroups = PE_TG;
+// reals of LDS per 16-lane group: the padded power spectrum (whose head is reused for the n_filt log-mel
+// energies once the mel pass has consumed it) + the partial filter sums + 1 spare slot, padded to
+// 18 mod 64 so that the four groups of a wave start 36 (f64) / 18 (f32) banks apart: a stride of 32 banks
+// (what the unpadded 336 reals give in f64) costs 1.4 us per update in bank conflicts.
+__host__ __device__ inline int group_scratch_reals(int mel_parts) {
+    const int need = kPowerPad + mel_parts + 1;
+    return need + ((18 - need % 64) + 64) % 64;
+}
 
 // The constant tables live in ONE device blob laid out exactly as they sit in LDS:
 //   [tw256: 256 cplx][w512: 130 cplx][dct: n_mfcc*n_filt R][mel_w: 2*17*16 R][pad16]
@@ -36,8 +51,8 @@ __host__ __device__ inline size_t table_blob_bytes(int real_size, int n_filt, in
     return b;
 }
 
-__host__ __device__ inline size_t lds_layout_bytes(int real_size, int n_filt, int n_mfcc) {
-    return table_blob_bytes(real_size, n_filt, n_mfcc) + (size_t)16 * kGroupScratch * real_size;
+__host__ __device__ inline size_t lds_layout_bytes(int real_size, int n_filt, int n_mfcc, int mel_parts, int groups) {
+    return table_blob_bytes(real_size, n_filt, n_mfcc) + (size_t)groups * group_scratch_reals(mel_parts) * real_size;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -53,6 +68,7 @@ struct MfccTables {
     //   mel_pstart [n_filt+1]: partial-sum slots of filter f are [pstart[f], pstart[f+1])
     const void* blob;
     int blob_bytes;
+    int mel_parts;          // partial-sum slots in use; slot mel_parts is the spare one
 };
 
 struct StreamGeom {
@@ -86,6 +102,8 @@ struct MfccStreamArgs {
     float* ring;            // [n_tiles][ring_slots][16 streams][16 floats]
     // several updates per launch (mfcc_many_tile): chunk u of stream s at pcm + (u*n_streams + s)*chunk
     int n_updates;
+    int n_frame_rows;       // workgroup rows per tile that share the frames of a call (+ 1 bookkeeping row)
+    int16_t* carry_next;    // leftover after the call; must not alias carry
     uint32_t* ke_hist;      // [n_updates][n_padded] emitted-frame counter after every update
     int n_padded;
 };
