@@ -321,7 +321,7 @@ int pack_gru_weights_bf16(pe_engine* e, const pe_gru_layer& L, const float* dens
 // row i of a tile <-> unit 16 tau + 4 (i & 3) + (i >> 2); k-step rho, k-slot gk <-> source unit 4 rho + gk
 // (layer 0 input: k-step kk <-> feature 4 gk + kk).  Streams: [wave][k-group][tile][lane] float4.
 int pack_gru_weights_wide(pe_engine* e, const pe_weights* w) {
-    const int H = w->layers[0].units, TPW = H / 64, H16 = H / 16;
+    const int H = w->layers[0].units, WV = gru_wide_waves(H), TPW = H / (16 * WV), H16 = H / 16;
     for (int l = 0; l < w->n_layers; ++l) {
         const pe_gru_layer& L = w->layers[l];
         const int kx4 = l == 0 ? 1 : H16;
@@ -333,9 +333,9 @@ int pack_gru_weights_wide(pe_engine* e, const pe_weights* w) {
         };
         for (int phase = 0; phase < 2; ++phase) {
             const int NT = phase == 0 ? 2 * TPW : TPW;
-            std::vector<float> wx((size_t)4 * kx4 * NT * 64 * 4, 0.f), wr((size_t)4 * H16 * NT * 64 * 4, 0.f);
-            std::vector<float> bias((size_t)4 * NT * 4 * 64, 0.f);
-            for (int wv = 0; wv < 4; ++wv)
+            std::vector<float> wx((size_t)WV * kx4 * NT * 64 * 4, 0.f), wr((size_t)WV * H16 * NT * 64 * 4, 0.f);
+            std::vector<float> bias((size_t)WV * NT * 4 * 64, 0.f);
+            for (int wv = 0; wv < WV; ++wv)
                 for (int tl = 0; tl < NT; ++tl) {
                     const int gate = phase == 0 ? (tl < TPW ? 0 : 1) : 2;
                     const int tau = wv * TPW + (tl % TPW);
@@ -359,8 +359,8 @@ int pack_gru_weights_wide(pe_engine* e, const pe_weights* w) {
             if ((rc = dev_upload(e, &e->wide_buf[l][phase == 0 ? 4 : 5], bias))) return rc;
         }
     }
-    std::vector<float> wd((size_t)4 * TPW * 4 * 64, 0.f);
-    for (int wv = 0; wv < 4; ++wv)
+    std::vector<float> wd((size_t)WV * TPW * 4 * 64, 0.f);
+    for (int wv = 0; wv < WV; ++wv)
         for (int tp = 0; tp < TPW; ++tp)
             for (int q = 0; q < 4; ++q)
                 for (int lane = 0; lane < 64; ++lane)

@@ -162,6 +162,7 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
             acc[tl] = mfma(wx[tl][0], x[0], bias[tl]);
 #pragma unroll
             for (int kk = 1; kk < 4; ++kk) acc[tl] = mfma(wx[tl][kk], x[kk], acc[tl]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (delta) {
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
@@ -174,10 +175,14 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
             xprev = x;
         }
         // phase 1: + h . U for the z / r rows
+        // (tile-outer: back-to-back MFMAs into ONE accumulator issue at the full rate, alternating
+        // accumulators costs a third of it -- tools/micro/mfma_peak.hip)
 #pragma unroll
-        for (int rho = 0; rho < R; ++rho)
+        for (int tl = 0; tl < G::P1_END; ++tl) {
 #pragma unroll
-            for (int tl = 0; tl < G::P1_END; ++tl) acc[tl] = mfma(wr1[tl][rho], h[rho], acc[tl]);
+            for (int rho = 0; rho < R; ++rho) acc[tl] = mfma(wr1[tl][rho], h[rho], acc[tl]);
+            __builtin_amdgcn_sched_barrier(0);               // keep the run together: the scheduler would interleave
+        }
         float z[R], rh[R];
 #pragma unroll
         for (int rho = 0; rho < R; ++rho) {
@@ -188,9 +193,11 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
         }
         // phase 2: + (r*h) . U for the candidate rows
 #pragma unroll
-        for (int rho = 0; rho < R; ++rho)
+        for (int tl = G::P2_BEGIN; tl < G::NT; ++tl) {
 #pragma unroll
-            for (int tl = G::P2_BEGIN; tl < G::NT; ++tl) acc[tl] = mfma(wr2[tl - G::P2_BEGIN][rho], rh[rho], acc[tl]);
+            for (int rho = 0; rho < R; ++rho) acc[tl] = mfma(wr2[tl - G::P2_BEGIN][rho], rh[rho], acc[tl]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int rho = 0; rho < R; ++rho) {
             const int sh = 2 * R + rho;

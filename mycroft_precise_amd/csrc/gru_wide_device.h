@@ -6,9 +6,10 @@
 // (GRU(H, return_sequences) -> GRU(H) -> Dense(1, sigmoid)), where the weights (786 KB per H=256
 // matrix pair) no longer fit registers.
 //
-// One 256-thread workgroup owns one tile of 16 streams for the whole window:
-//   * wave w owns hidden units [H/4 * w, H/4 * (w+1)) of every gate: TPW output tiles of z, of r and
-//     of the candidate.  Row 4 g + reg of tile tau is unit 16 tau + 4 reg + g, so a lane's four D
+// One workgroup of WAVES waves (4; 8 is a build switch that measured slower) owns one tile of 16 streams
+// for the whole window:
+//   * wave w owns hidden units [H/WAVES * w, H/WAVES * (w+1)) of every gate: TPW output tiles of z, of r
+//     and of the candidate.  Row 4 g + reg of tile tau is unit 16 tau + 4 reg + g, so a lane's four D
 //     registers of a tile are k-slot g of four consecutive k-steps (rho = 4 tau + reg) of the next
 //     contraction: a tile's new state goes to LDS as ONE ds_write_b128 per lane and comes back as the
 //     B operands of four MFMAs with ONE ds_read_b128;
@@ -26,27 +27,49 @@
 
 namespace pe {
 
-// acc[tl] += sum over k-groups of W . B, B operands (float4 = four consecutive k-steps) from LDS
+// acc[tl] += sum over k-groups of W . B, B operands (float4 = four consecutive k-steps) from LDS.
+// Weights arrive through a register ring, PE_WIDE_PF k-groups (each NT x 4 MFMAs = NT x 128 cycles of
+// matrix work) ahead of their use; the B quad one k-group ahead.  n4 is a multiple of 4.  Measured at
+// 256 x 2 layers, 4096 streams: distance 1 1.254 ms per launch, distance 2 1.305, distance 3 spills.
+#ifndef PE_WIDE_PF
+#define PE_WIDE_PF 1
+#endif
 template <int NT>
 __device__ __forceinline__ void wide_accumulate(f32x4 (&acc)[NT], const float4* __restrict__ w, const float* B, const int n4) {
-    float4 cur[NT], nxt[NT];
+    constexpr int D = PE_WIDE_PF;
+    float4 st[4][NT];
 #pragma unroll
-    for (int tl = 0; tl < NT; ++tl) cur[tl] = w[tl * 64];
-    for (int r4 = 0; r4 < n4; ++r4) {
-        const int rn = r4 + 1 < n4 ? r4 + 1 : r4;            // clamped prefetch, no branch
+    for (int d = 0; d < D; ++d) {
+        const int rd = d < n4 ? d : n4 - 1;
 #pragma unroll
-        for (int tl = 0; tl < NT; ++tl) nxt[tl] = w[(rn * NT + tl) * 64];
-        const float4 b = *reinterpret_cast<const float4*>(B + r4 * 256);
+        for (int tl = 0; tl < NT; ++tl) st[d][tl] = w[(rd * NT + tl) * 64];
+    }
+    float4 b = *reinterpret_cast<const float4*>(B);
+#pragma unroll 1
+    for (int r4 = 0; r4 < n4; r4 += 4) {
 #pragma unroll
-        for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma(cur[tl].x, b.x, acc[tl]);
+        for (int u = 0; u < 4; ++u) {
+            const int rn = r4 + u + D < n4 ? r4 + u + D : n4 - 1;            // clamped prefetch, no branch
 #pragma unroll
-        for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma(cur[tl].y, b.y, acc[tl]);
+            for (int tl = 0; tl < NT; ++tl) st[(u + D) & 3][tl] = w[(rn * NT + tl) * 64];
+            const int rb = r4 + u + 1 < n4 ? r4 + u + 1 : n4 - 1;
+            const float4 bn = *reinterpret_cast<const float4*>(B + rb * 256);
+            // the loads above must be ISSUED here: left alone, the scheduler sinks them to the end of the MFMA
+            // block below (to reuse registers) and the next k-group then waits out the whole L2 latency
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma(cur[tl].z, b.z, acc[tl]);
-#pragma unroll
-        for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma(cur[tl].w, b.w, acc[tl]);
-#pragma unroll
-        for (int tl = 0; tl < NT; ++tl) cur[tl] = nxt[tl];
+            for (int tl = 0; tl < NT; ++tl) {
+                acc[tl] = mfma(st[u][tl].x, b.x, acc[tl]);
+                acc[tl] = mfma(st[u][tl].y, b.y, acc[tl]);
+                acc[tl] = mfma(st[u][tl].z, b.z, acc[tl]);
+                acc[tl] = mfma(st[u][tl].w, b.w, acc[tl]);
+#ifdef PE_WIDE_RUN
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            b = bn;
+        }
     }
 }
 
@@ -64,10 +87,10 @@ __device__ __forceinline__ void wide_accumulate_x(f32x4 (&acc)[NT], const float4
 }
 
 // MODE as in gru_device.h (kFeats / kRing / kRows).  LDS: [layer][HB | RH][H/16][64 lanes][4] floats.
-template <int TPW, int MODE>
+template <int TPW, int MODE, int WAVES>
 __device__ __forceinline__ void gru_wide_tile(const WideArgs& wa, const int tile, const int wave, const int lane, float* lds) {
     const GruArgs& a = wa.base;
-    constexpr int H = 64 * TPW, H16 = H / 16;
+    constexpr int H = 16 * TPW * WAVES, H16 = H / 16;
     const int g = lane >> 4, j = lane & 15;
     const long long stream = (long long)tile * kTileStreams + j;
     const bool valid = stream < a.n_streams;
@@ -111,7 +134,7 @@ __device__ __forceinline__ void gru_wide_tile(const WideArgs& wa, const int tile
     // ---- LDS state: h0 = 0 ------------------------------------------------------------------------------
     float* HB[2] = {lds, lds + 2 * H16 * 256};
     float* RH[2] = {lds + H16 * 256, lds + 3 * H16 * 256};
-    for (int i = threadIdx.x; i < 4 * H16 * 256; i += 256) lds[i] = 0.f;
+    for (int i = threadIdx.x; i < 4 * H16 * 256; i += 64 * WAVES) lds[i] = 0.f;
     float hown[2][TPW][4];
 #pragma unroll
     for (int l = 0; l < 2; ++l)
@@ -189,8 +212,10 @@ __device__ __forceinline__ void gru_wide_tile(const WideArgs& wa, const int tile
     if (g == 0) lds[wave * 16 + j] = part;
     __syncthreads();
     if (wave == 0 && g == 0 && valid) {
-        const float logit = lds[j] + lds[16 + j] + lds[32 + j] + lds[48 + j] + a.dense_bias;
-        a.out[stream] = 1.0f / (1.0f + expf(-logit));
+        float logit = lds[j];
+#pragma unroll
+        for (int wv = 1; wv < WAVES; ++wv) logit += lds[wv * 16 + j];
+        a.out[stream] = 1.0f / (1.0f + expf(-(logit + a.dense_bias)));
     }
 }
 

@@ -54,30 +54,40 @@ __global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
 }
 
 // ---- wide / stacked GRU: one workgroup per 16-stream tile, weights streamed from L2 -------------------
-template <int TPW, int MODE>
-__global__ __launch_bounds__(256) void gru_wide_kernel(const WideArgs a) {
+template <int TPW, int MODE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gru_wide_kernel(const WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    gru_wide_tile<TPW, MODE>(a, blockIdx.x, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
+#ifdef PE_WIDE_STAGGER
+    for (int i = (blockIdx.x >> 3) & 31; i > 0; --i) __builtin_amdgcn_s_sleep(PE_WIDE_STAGGER);
+#endif
+    gru_wide_tile<TPW, MODE, WAVES>(a, blockIdx.x, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
 }
 
-template <int TPW>
+template <int TPW, int WAVES>
 static hipError_t launch_wide_t(const WideArgs& a, int mode, hipStream_t s) {
     const int tiles = (a.base.n_streams + kTileStreams - 1) / kTileStreams;
     if (tiles == 0) return hipSuccess;
-    const size_t lds = (size_t)4 * (64 * TPW / 16) * 256 * sizeof(float);      // 2 layers x {h, r*h}
-    if (mode == kRing) hipLaunchKernelGGL((gru_wide_kernel<TPW, kRing>), dim3(tiles), dim3(256), lds, s, a);
-    else if (mode == kRows) hipLaunchKernelGGL((gru_wide_kernel<TPW, kRows>), dim3(tiles), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((gru_wide_kernel<TPW, kFeats>), dim3(tiles), dim3(256), lds, s, a);
+    const size_t lds = (size_t)4 * (TPW * WAVES) * 256 * sizeof(float);      // 2 layers x {h, r*h}
+    if (mode == kRing) hipLaunchKernelGGL((gru_wide_kernel<TPW, kRing, WAVES>), dim3(tiles), dim3(64 * WAVES), lds, s, a);
+    else if (mode == kRows) hipLaunchKernelGGL((gru_wide_kernel<TPW, kRows, WAVES>), dim3(tiles), dim3(64 * WAVES), lds, s, a);
+    else hipLaunchKernelGGL((gru_wide_kernel<TPW, kFeats, WAVES>), dim3(tiles), dim3(64 * WAVES), lds, s, a);
     return hipGetLastError();
 }
 
+// 8 waves per workgroup (two per SIMD) for H = 128 / 256 was measured and is NOT faster: 256 x 2 layers, 4096
+// streams: 4 waves 1.254 ms per launch, 8 waves 1.325 ms (tools/gpu_wide.py) -- kept as a build switch only.
+#ifndef PE_WIDE8
+#define PE_WIDE8 0
+#endif
+int gru_wide_waves(int units) { return (PE_WIDE8 && units % 128 == 0) ? 8 : 4; }
+
 hipError_t launch_gru_wide(const WideArgs& a, int mode, hipStream_t s) {
     switch (a.units / 64) {
-        case 1: return launch_wide_t<1>(a, mode, s);
-        case 2: return launch_wide_t<2>(a, mode, s);
-        case 3: return launch_wide_t<3>(a, mode, s);
-        case 4: return launch_wide_t<4>(a, mode, s);
+        case 1: return launch_wide_t<1, 4>(a, mode, s);
+        case 2: return PE_WIDE8 ? launch_wide_t<1, 8>(a, mode, s) : launch_wide_t<2, 4>(a, mode, s);
+        case 3: return launch_wide_t<3, 4>(a, mode, s);
+        case 4: return PE_WIDE8 ? launch_wide_t<2, 8>(a, mode, s) : launch_wide_t<4, 4>(a, mode, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -226,6 +226,7 @@ hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, hipStream_t
 hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, hipStream_t s);
 hipError_t launch_gru_small(const GruArgs& a, int input_mode, hipStream_t s);   // units <= 32; 0 feats, 1 ring, 2 rows
 int gru_small_regs(int units);                  // R = ceil(units/4)
+int gru_wide_waves(int units);                  // waves per workgroup of the wide kernel (the weight packing follows it)
 int gru_small_tiles(int units);                 // NT = ceil(3R/4)
 hipError_t launch_gru_wide(const WideArgs& a, int input_mode, hipStream_t s);      // units 64..256, 1-2 layers
 hipError_t launch_gather(const GatherArgs& a, hipStream_t s);
