@@ -162,7 +162,6 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
             acc[tl] = mfma(wx[tl][0], x[0], bias[tl]);
 #pragma unroll
             for (int kk = 1; kk < 4; ++kk) acc[tl] = mfma(wx[tl][kk], x[kk], acc[tl]);
-            __builtin_amdgcn_sched_barrier(0);
         }
         if (delta) {
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
@@ -174,15 +173,14 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
                 for (int kk = 0; kk < 4; ++kk) acc[tl] = mfma(wxd[tl][kk], d[kk], acc[tl]);
             xprev = x;
         }
-        // phase 1: + h . U for the z / r rows
-        // (tile-outer: back-to-back MFMAs into ONE accumulator issue at the full rate, alternating
-        // accumulators costs a third of it -- tools/micro/mfma_peak.hip)
+        // phase 1: + h . U for the z / r rows.  (Measured alternatives, MI355X, gru_many_kernel<5> over 2048
+        // tiles: this k-outer order 65.4 us; tile-outer runs of R dependent MFMAs 66-67 us; each chain split
+        // into two independent halves added at the end 69.3 us, and 16.9 instead of 15.6 us for the 4-wave
+        // kernel -- the extra adds and hazards cost more than the shorter dependent chain saves.)
 #pragma unroll
-        for (int tl = 0; tl < G::P1_END; ++tl) {
+        for (int rho = 0; rho < R; ++rho)
 #pragma unroll
-            for (int rho = 0; rho < R; ++rho) acc[tl] = mfma(wr1[tl][rho], h[rho], acc[tl]);
-            __builtin_amdgcn_sched_barrier(0);               // keep the run together: the scheduler would interleave
-        }
+            for (int tl = 0; tl < G::P1_END; ++tl) acc[tl] = mfma(wr1[tl][rho], h[rho], acc[tl]);
         float z[R], rh[R];
 #pragma unroll
         for (int rho = 0; rho < R; ++rho) {
@@ -193,11 +191,9 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
         }
         // phase 2: + (r*h) . U for the candidate rows
 #pragma unroll
-        for (int tl = G::P2_BEGIN; tl < G::NT; ++tl) {
+        for (int rho = 0; rho < R; ++rho)
 #pragma unroll
-            for (int rho = 0; rho < R; ++rho) acc[tl] = mfma(wr2[tl - G::P2_BEGIN][rho], rh[rho], acc[tl]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            for (int tl = G::P2_BEGIN; tl < G::NT; ++tl) acc[tl] = mfma(wr2[tl - G::P2_BEGIN][rho], rh[rho], acc[tl]);
 #pragma unroll
         for (int rho = 0; rho < R; ++rho) {
             const int sh = 2 * R + rho;

@@ -63,9 +63,6 @@ __device__ __forceinline__ void wide_accumulate(f32x4 (&acc)[NT], const float4* 
                 acc[tl] = mfma(st[u][tl].y, b.y, acc[tl]);
                 acc[tl] = mfma(st[u][tl].z, b.z, acc[tl]);
                 acc[tl] = mfma(st[u][tl].w, b.w, acc[tl]);
-#ifdef PE_WIDE_RUN
-                __builtin_amdgcn_sched_barrier(0);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             b = bn;
