@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void gru_bf16_kernel(const GruArgs a) {
 
 // fused update with the bf16 network role (four tiles per GRU workgroup, one wave each)
 template <class R>
-__global__ __launch_bounds__(256) void fused_update_bf16_kernel(const MfccStreamArgs<R> m, const GruArgs g,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void fused_update_bf16_kernel(const MfccStreamArgs<R> m, const GruArgs g,
                                                                 const int n_gru_blocks, const int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
@@ -125,8 +125,11 @@ __global__ __launch_bounds__(256) void gru_mw_kernel(const GruArgs a) {
 // update; workgroups after them compute this update's MFCC frames.  The GRU workgroups are
 // dispatched first: they are the long pole.  MW = true: one GRU workgroup per tile, its four waves
 // share the tile (gru_tile_mw); MW = false: four tiles per GRU workgroup, one wave each.
+// (waves_per_eu(2): a GRU and an MFCC workgroup must fit one CU together, i.e. <= 256 registers per lane;
+// without the bound an innocent change to the MFCC code once pushed the allocation to 267 and the
+// launch from 21 to 30 us.)
 template <class R, int RG, bool MW>
-__global__ __launch_bounds__(256) void fused_update_kernel(const MfccStreamArgs<R> m, const GruArgs g,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void fused_update_kernel(const MfccStreamArgs<R> m, const GruArgs g,
                                                            const int n_gru_blocks, const int n_tiles, const int nsel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;

@@ -42,6 +42,9 @@ template <> struct RealK<double> {
     static constexpr double EPS = 2.220446049250313e-16;   // np.finfo(float).eps (sonopy safe_log)
     static constexpr double INV_FFT = 1.0 / 512.0;
     static constexpr double INV_I16 = 1.0 / 32768.0;       // util.py:37
+    // int16 samples enter the FFT unscaled; the exact power-of-two factor 2^-30 = INV_I16^2 is folded into the
+    // power scale instead (bit-identical: scaling by powers of two commutes with every rounding in between)
+    static constexpr double PSCALE_I16 = (1.0 / 512.0) / 1073741824.0;
 };
 template <> struct RealK<float> {
     static constexpr float C1 = 0.92387953251128673848f;
@@ -50,6 +53,7 @@ template <> struct RealK<float> {
     static constexpr float EPS = 2.220446049250313e-16f;
     static constexpr float INV_FFT = 1.0f / 512.0f;
     static constexpr float INV_I16 = 1.0f / 32768.0f;
+    static constexpr float PSCALE_I16 = (1.0f / 512.0f) / 1073741824.0f;
 };
 
 __device__ __forceinline__ double real_log(double x) { return log(x); }
@@ -169,7 +173,8 @@ __device__ __forceinline__ R* lds_setup(unsigned char* smem, const MfccTables<R>
 // frame (already scaled to [-1,1), zero beyond frame_len; typically from registers loaded earlier).
 // Returns coefficient r in lane r (lanes >= n_mfcc return 0).  S: this group's LDS scratch.
 template <class R, class Load>
-__device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_filt, int n_mfcc, Load load) {
+__device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_filt, int n_mfcc, Load load,
+                                        const R pscale = RealK<R>::INV_FFT) {
     using K = RealK<R>;
     R re[16], im[16];
 #pragma unroll
@@ -249,8 +254,8 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
         const R tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
         const R x1r = er + tr, x1i = ei + ti, x2r = er - tr, x2i = ei - ti;
 #ifndef PE_ABL_POWER
-        const R p1 = (x1r * x1r + x1i * x1i) * K::INV_FFT;
-        const R p2 = (x2r * x2r + x2i * x2i) * K::INV_FFT;
+        const R p1 = (x1r * x1r + x1i * x1i) * pscale;
+        const R p2 = (x2r * x2r + x2i * x2i) * pscale;
 #else
         const R p1 = a + c + w.x, p2 = b + d;
 #endif
@@ -260,7 +265,7 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
         psum += p1 + p2;
     }
     if (r == 0) {
-        const R p128 = (re[8] * re[8] + im[8] * im[8]) * K::INV_FFT;
+        const R p128 = (re[8] * re[8] + im[8] * im[8]) * pscale;
         S[128 + 8] = p128;
         psum += p128;
     }
@@ -471,10 +476,10 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
     int last_slot = -1;                                      // after the carry stores (see below)
     for (int f = f_first; f < nnew; f += nsel) {
         auto load = [&](int c, R& xr, R& xi) {
-            xr = (R)(int)(short)(cur[c] & 0xffff) * K::INV_I16;
-            xi = (R)(cur[c] >> 16) * K::INV_I16;
+            xr = (R)(int)(short)(cur[c] & 0xffff);
+            xi = (R)(cur[c] >> 16);
         };
-        const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load);
+        const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load, K::PSCALE_I16);
         const uint32_t k = kc + (uint32_t)f;
         const int slot = (int)(k & (uint32_t)(slots - 1));
         const float row = (r < geo.n_mfcc) ? (float)coeff : 0.0f;
@@ -602,10 +607,10 @@ __device__ __forceinline__ void mfcc_many_tile(const MfccStreamArgs<R>& a, unsig
         if (k < nnew) fetch(k * hop, flen, cur);
         for (; k < nnew; k += n_kb) {                          // one trip unless the rows were capped (kMaxFrameRows)
             auto load = [&](int c, R& xr, R& xi) {
-                xr = (R)(int)(short)(cur[c] & 0xffff) * K::INV_I16;
-                xi = (R)(cur[c] >> 16) * K::INV_I16;
+                xr = (R)(int)(short)(cur[c] & 0xffff);
+                xi = (R)(cur[c] >> 16);
             };
-            const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load);
+            const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load, K::PSCALE_I16);
             const int slot = (int)((kc + (uint32_t)k) & (uint32_t)(slots - 1));
             ring_rows[(size_t)slot * kTileStreams * kRowFloats + r] = (r < geo.n_mfcc) ? (float)coeff : 0.0f;
             if (k + n_kb < nnew) fetch((k + n_kb) * hop, flen, cur);
