@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libprecise_engine.so')
+# PE_LIB: load an experiment build (tools/build_variants.sh) instead of the in-tree library
+LIB_PATH = os.environ.get('PE_LIB') or os.path.join(HERE, 'libprecise_engine.so')
 
 PE_OK, PE_ERR_INVALID, PE_ERR_HIP, PE_ERR_UNSUPPORTED, PE_ERR_NOMEM, PE_ERR_EOF = range(6)
 ABI_VERSION = 2

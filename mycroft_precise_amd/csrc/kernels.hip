@@ -129,7 +129,10 @@ __global__ __launch_bounds__(256) void gru_mw_kernel(const GruArgs a) {
 // without the bound an innocent change to the MFCC code once pushed the allocation to 267 and the
 // launch from 21 to 30 us.)
 template <class R, int RG, bool MW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void fused_update_kernel(const MfccStreamArgs<R> m, const GruArgs g,
+#ifndef PE_FUSED_WPE
+#define PE_FUSED_WPE 2
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FUSED_WPE))) void fused_update_kernel(const MfccStreamArgs<R> m, const GruArgs g,
                                                            const int n_gru_blocks, const int n_tiles, const int nsel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
@@ -147,13 +150,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void f
     }
 }
 
-// Workgroups per tile for the MFCC role: while the machine is not full (<= 512 tiles), give every
-// frame an update can complete per stream its own workgroup (at most 4).
-// Workgroups per tile for the MFCC role.  Splitting the frames of one update over several
-// workgroups was measured (4096 streams, MI355X): 2 per tile makes the fused launch 31.6 us instead
-// of 22.9 us -- every workgroup of the launch reserves the 73 KB LDS image, so the third workgroup
-// per CU has to wait -- hence 1.  The kernels keep the (fsel, nsel) parameters for larger-chunk use.
-static int frame_split(const StreamGeom&, int, int) { return 1; }
+// Workgroups per tile for the MFCC role.  Splitting the frames of one update over two workgroups per
+// tile was measured twice (4096 streams, MI355X): 31.6 us vs 22.9 us with a 73 KB LDS image, 31.5 us vs
+// 22.1 us with the present 57 KB one (33 us with the kernel held to 3 waves per SIMD) -- hence 1.  The
+// kernels keep the (fsel, nsel) parameters for larger-chunk use; PE_FRAME_SPLIT is the build switch.
+#ifndef PE_FRAME_SPLIT
+#define PE_FRAME_SPLIT 1
+#endif
+static int frame_split(const StreamGeom&, int, int) { return PE_FRAME_SPLIT; }
 
 template <class R>
 static hipError_t launch_stream(const MfccStreamArgs<R>& a, hipStream_t s) {

@@ -450,6 +450,7 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
     // frames that would be overwritten before anyone reads them (huge chunks) are skipped
     const int f_first = (nnew > slots ? nnew - slots : 0) + fsel;
     const bool owner = fsel == 0;                            // moves the leftover and the counters
+    if (fsel > 0 && !__syncthreads_or(f_first < nnew)) return;   // no stream of the tile has a frame for this workgroup
 #ifndef PE_ABL_PCM
     if (f_first < nnew) fetch(f_first * hop, flen, cur);
     if (owner && active && qn > 0) fetch(nnew * hop, qn, left);   // read before any carry store
