@@ -313,6 +313,16 @@ def main():
                               'avg_launch_ms': mfcc_ms,
                               'algorithmic': '%.1f B/window x %d windows/launch' % (MFCC_BYTES_PER_WINDOW, B)},
         }
+        try:     # spin / streaming microbenchmarks of the same pool ("also report against measured peaks")
+            with open(os.path.join(REPO, 'profiles', 'measured_peaks.json')) as f:
+                mp = json.load(f)
+            m_mfma = mp['mfma_f32_16x16x4_tflops'] if args.gru_precision == 'f32' else mp['mfma_bf16_16x16x32_tflops']
+            line['measured_peaks'] = {'mfma_tflops': m_mfma, 'hbm_read_gbs': mp['hbm_read_gbs'], 'source': 'profiles/measured_peaks.json',
+                                      'roofline_frac': line['roofline']['achieved'] / m_mfma,
+                                      'roofline_gru_frac': line['roofline_gru']['achieved'] / m_mfma,
+                                      'roofline_mfcc_frac': line['roofline_mfcc']['achieved'] / mp['hbm_read_gbs']}
+        except (OSError, KeyError, ValueError):
+            pass
         if time_batched is not None:
             line['time_batched'] = time_batched
         if cpu is not None:
