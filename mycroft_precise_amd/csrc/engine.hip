@@ -863,6 +863,13 @@ int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samp
         if (rc) return rc;
     }
     if (!e->ke_hist || max_updates > e->max_updates) {
+        if (e->ke_hist) {
+            for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it)
+                if (*it == e->ke_hist) { e->allocs.erase(it); break; }
+            (void)hipFree(e->ke_hist);
+            e->device_bytes -= (int64_t)e->max_updates * e->n_padded * (int64_t)sizeof(uint32_t);
+            e->ke_hist = nullptr;
+        }
         int rc = dev_alloc(e, &e->ke_hist, (size_t)max_updates * e->n_padded);
         if (rc) return rc;
     }
