@@ -206,6 +206,27 @@ def test_update_many_equals_consecutive_updates(stock_weights, gru):
     eng.close()
 
 
+def test_update_many_large_launch_uses_one_wave_kernel(stock_weights):
+    """More than 1536 (update, tile) pairs per call switch the network launch of pe_update_many to one wave
+    per pair (fewer are served by the four-wave kernel): both must reproduce consecutive updates bit for bit."""
+    from mycroft_precise_amd._lib import HipEngine
+    n, depth, chunk = 1616, 16, 1024                       # 101 tiles x 16 updates = 1616 workgroups
+    rng = np.random.default_rng(5)
+    base = _stream_batch(['tone_noise'] * 16, 2 * depth, chunk)            # [32, 16, chunk]
+    pcm = np.ascontiguousarray(np.tile(base, (1, n // 16, 1)))
+    pcm[:, ::7] = np.roll(pcm[:, ::7], 3, axis=2)                       # not all tiles alike
+    a = HipEngine(P.pr, stock_weights, n_streams=n)
+    b = HipEngine(P.pr, stock_weights, n_streams=n)
+    b.reserve_updates(depth, chunk)
+    for u in range(0, 2 * depth, depth):
+        want = np.stack([a.update(pcm[u + i]) for i in range(depth)])
+        got = b.update_many(pcm[u:u + depth])
+        assert np.array_equal(got, want), u
+    for x, y in zip(a.stream_state(), b.stream_state()):
+        assert np.array_equal(x, y)
+    a.close(); b.close()
+
+
 def test_gru_kernel_shapes_agree_bitwise(stock_weights):
     """pe_set_gru_waves: one wave per tile vs four waves sharing a tile issue the same MFMAs in the
     same order per output element, so they must agree bit for bit (fused and unfused)."""
