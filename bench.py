@@ -225,7 +225,7 @@ def main():
     # at once.  Results are bit-identical to single updates; a caller pays 8 chunks of buffering latency.
     time_batched = None
     depth = 8
-    if (stock or args.gru_precision == 'bf16') and n_res >= 2 * depth:
+    if world == 1 and (stock or args.gru_precision == 'bf16') and n_res >= 2 * depth:      # N = 1 only: no collectives outside the timed region
         try:
             engine.reserve_updates(depth, CHUNK)
             many_out = torch.zeros((depth, B), dtype=torch.float32, device=device)
@@ -234,18 +234,12 @@ def main():
                 engine.update_many_device(pcm_base + ((i * depth) % max(1, n_res - depth)) * chunk_bytes, CHUNK, depth,
                                           many_out.data_ptr(), stream)
             torch.cuda.synchronize()
-            barrier()
             t1 = time.perf_counter()
             for i in range(rounds):
                 engine.update_many_device(pcm_base + ((i * depth) % max(1, n_res - depth)) * chunk_bytes, CHUNK, depth,
                                           many_out.data_ptr(), stream)
             torch.cuda.synchronize()
-            barrier()
             dt = time.perf_counter() - t1
-            if world > 1:
-                tt = torch.tensor([dt], dtype=torch.float64, device=device)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt = float(tt.item())
             time_batched = {'updates_per_call': depth, 'value': n_global * rounds * depth / dt, 'unit': 'windows/s',
                             'ms_per_update': 1e3 * dt / (rounds * depth),
                             'note': 'pe_update_many_device: same results, 2 launches per %d updates; not the headline' % depth}
