@@ -129,11 +129,19 @@ def main():
                      % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X (torch.cuda.is_available() is False)')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # PE_BENCH_SHARED_GPU=1 (test aid for 1-GPU boxes): every rank uses cuda:0 and the collectives run over gloo
+    # on host copies, so the N > 1 control flow can be exercised where RCCL (one device per rank) cannot run.
+    shared_gpu = os.environ.get('PE_BENCH_SHARED_GPU') == '1'
+    dev_index = 0 if shared_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
+    comm_device = torch.device('cpu') if shared_gpu else device
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if shared_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
 
     B = args.streams
     n_global = B * world
@@ -144,7 +152,7 @@ def main():
     weights = synth.make_weights(units=units)
     stock = units == (20,)
     flop_per_window = 2 * sum(29 * 3 * h * (f + h) for f, h in zip((13,) + units[:-1], units)) + 2 * units[-1]
-    engine = HipEngine(pr, weights, n_streams=B, device=local_rank, mfcc_precision=args.mfcc_precision,
+    engine = HipEngine(pr, weights, n_streams=B, device=dev_index, mfcc_precision=args.mfcc_precision,
                        gru_precision=args.gru_precision)
     pcm = synth_pcm_device(n_res, B, rank * B, device)
     probs = torch.zeros((steps, B), dtype=torch.float32, device=device)
@@ -167,7 +175,7 @@ def main():
     # ---- warm-up (fills the 29-row feature windows), untimed --------------------------------
     run(0, warmup, False)
     if world > 1:                                # warm the communicator too
-        gather_probabilities(probs, n_global, dst=0)          # same shape as the timed gather
+        gather_probabilities(probs.to(comm_device), n_global, dst=0)          # same shape as the timed gather
     torch.cuda.synchronize()
     barrier()
 
@@ -175,12 +183,12 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(warmup, steps, True)
-    gathered = gather_probabilities(probs, n_global, dst=0) if world > 1 else probs      # rank 0 only
+    gathered = gather_probabilities(probs.to(comm_device), n_global, dst=0) if world > 1 else probs      # rank 0 only
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
