@@ -137,25 +137,36 @@ struct LdsTab {
     int group_reals;        // LDS reals per 16-lane group
 };
 
-// Copy the blob with 16-byte loads (all of a thread's loads in flight before its first store), and
-// carve the pointers.  The caller issues __syncthreads() when it needs the tables.
+// Copy the blob with 16-byte loads, in two halves so that a kernel can put the loads at its very top (they
+// then return first: vmcnt retires in order) and the LDS stores after its other, longer-latency loads have
+// been issued.  The caller issues __syncthreads() when it needs the tables.
+struct TabRegs { uint4 v0, v1, v2, v3; };
+
 template <class R>
-__device__ __forceinline__ R* lds_setup(unsigned char* smem, const MfccTables<R>& g, int n_filt, int n_mfcc,
-                                        LdsTab<R>& t) {
+__device__ __forceinline__ TabRegs lds_issue(const MfccTables<R>& g) {
+    const int n16 = g.blob_bytes >> 4;
+    const uint4* src = reinterpret_cast<const uint4*>(g.blob);
+    const int tid = threadIdx.x;
+    TabRegs t;
+    t.v0 = t.v1 = t.v2 = t.v3 = uint4{0, 0, 0, 0};
+    if (tid < n16) t.v0 = src[tid];
+    if (tid + 256 < n16) t.v1 = src[tid + 256];
+    if (tid + 512 < n16) t.v2 = src[tid + 512];
+    if (tid + 768 < n16) t.v3 = src[tid + 768];
+    return t;
+}
+
+template <class R>
+__device__ __forceinline__ R* lds_commit(unsigned char* smem, const MfccTables<R>& g, const TabRegs& v, int n_filt, int n_mfcc,
+                                         LdsTab<R>& t) {
     const int n16 = g.blob_bytes >> 4;
     const uint4* src = reinterpret_cast<const uint4*>(g.blob);
     uint4* dst = reinterpret_cast<uint4*>(smem);
     const int tid = threadIdx.x;
-    const int i0 = tid, i1 = tid + 256, i2 = tid + 512, i3 = tid + 768;
-    uint4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
-    if (i0 < n16) v0 = src[i0];
-    if (i1 < n16) v1 = src[i1];
-    if (i2 < n16) v2 = src[i2];
-    if (i3 < n16) v3 = src[i3];
-    if (i0 < n16) dst[i0] = v0;
-    if (i1 < n16) dst[i1] = v1;
-    if (i2 < n16) dst[i2] = v2;
-    if (i3 < n16) dst[i3] = v3;
+    if (tid < n16) dst[tid] = v.v0;
+    if (tid + 256 < n16) dst[tid + 256] = v.v1;
+    if (tid + 512 < n16) dst[tid + 512] = v.v2;
+    if (tid + 768 < n16) dst[tid + 768] = v.v3;
     for (int i = tid + 1024; i < n16; i += 256) dst[i] = src[i];
     cplx<R>* tw = reinterpret_cast<cplx<R>*>(smem);
     cplx<R>* w5 = tw + 256;
@@ -167,6 +178,12 @@ __device__ __forceinline__ R* lds_setup(unsigned char* smem, const MfccTables<R>
     t.spare = g.mel_parts; t.group_reals = group_scratch_reals(g.mel_parts);
     t.tw256 = tw; t.w512 = w5; t.dct = dct; t.mel_w = mw; t.mel_flush = fl; t.mel_pstart = fl + kMelSteps * 16;
     return reinterpret_cast<R*>(smem + g.blob_bytes);
+}
+
+template <class R>
+__device__ __forceinline__ R* lds_setup(unsigned char* smem, const MfccTables<R>& g, int n_filt, int n_mfcc, LdsTab<R>& t) {
+    const TabRegs v = lds_issue<R>(g);
+    return lds_commit<R>(smem, g, v, n_filt, n_mfcc, t);
 }
 
 // One frame on one 16-lane group.  `load(c, xr, xi)` returns samples 32c+2r and 32c+2r+1 of the
@@ -405,6 +422,9 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
     using K = RealK<R>;
     const StreamGeom& geo = a.geo;
     PE_T(0);
+#ifndef PE_ABL_TABLES
+    const TabRegs tab_regs = lds_issue<R>(a.tab);           // first in the queue: back before the PCM is
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, r = lane & 15;
     const int j = wave * 4 + grp;                           // stream within the tile
@@ -479,7 +499,7 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
     none.blob_bytes = 0;
     R* scratch = lds_setup<R>(smem, none, geo.n_filt, geo.n_mfcc, tab) + a.tab.blob_bytes / sizeof(R);
 #else
-    R* scratch = lds_setup<R>(smem, a.tab, geo.n_filt, geo.n_mfcc, tab);
+    R* scratch = lds_commit<R>(smem, a.tab, tab_regs, geo.n_filt, geo.n_mfcc, tab);
 #endif
     __syncthreads();
     PE_T(1);
