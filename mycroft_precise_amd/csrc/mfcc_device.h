@@ -346,8 +346,10 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
         LM[f] = acc;
     }
     PE_T(18);
-    for (int f = r; f < n_filt; f += 16) {
-        const R acc = LM[f];
+    // one more "filter" rides along: the lane that would take filter n_filt takes the total power instead,
+    // so the log that replaces coefficient 0 is evaluated in the same pass as the filter logs
+    for (int f = r; f <= n_filt; f += 16) {
+        const R acc = f < n_filt ? LM[f] : psum;
 #ifndef PE_ABL_LOG
         LM[f] = real_log(acc > K::EPS ? acc : K::EPS);
 #else
@@ -364,10 +366,11 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
 #ifdef PE_ABL_DCT
         coeff = LM[r] + drow[0];
 #else
-        for (int j0 = 0; j0 < n_filt; j0 += 4) {
-            R dv[4], lv[4];
+        constexpr int CH = 10;                                  // reads of a chunk first, then its FMA chain
+        for (int j0 = 0; j0 < n_filt; j0 += CH) {
+            R dv[CH], lv[CH];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < CH; ++u) {
                 const int jf = j0 + u;
                 const int jc = jf < n_filt ? jf : n_filt - 1;
                 dv[u] = drow[jc];
@@ -375,10 +378,10 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
                 if (jf >= n_filt) dv[u] = R(0);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) coeff = real_fma(dv[u], lv[u], coeff);
+            for (int u = 0; u < CH; ++u) coeff = real_fma(dv[u], lv[u], coeff);
         }
 #endif
-        if (r == 0) coeff = real_log(psum > K::EPS ? psum : K::EPS);
+        if (r == 0) coeff = LM[n_filt];
     }
     group_sync();
     PE_T(9);
