@@ -102,11 +102,13 @@ int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples
                      float* raw_out_dev, void* hip_stream);
 
 /* n_updates consecutive pe_update calls in two launches (results bit-identical): chunk u of stream s at
- * pcm[(u * n_streams + s) * chunk_samples], raw_out[u * n_streams + s].  All MFCC updates run first
- * (one workgroup walks its 16 streams through the chunks), then the network for all
- * n_updates x n_streams windows at once -- for callers that can buffer a few chunks (catch-up, bulk
+ * pcm[(u * n_streams + s) * chunk_samples], raw_out[u * n_streams + s].  First one launch computes every
+ * MFCC frame the call completes (frame-parallel: which samples form which frame is closed-form over
+ * leftover ++ chunk 0 ++ ... ++ chunk n-1), then one launch runs the network for all
+ * n_updates x n_streams windows -- for callers that can buffer a few chunks (catch-up, bulk
  * replay, latency-tolerant servers) this fills the machine where a single update of a few thousand
- * streams cannot.  pe_reserve_updates sizes the feature ring for it (and restarts all streams). */
+ * streams cannot.  pe_reserve_updates sizes the feature ring, the second leftover buffer and the
+ * per-update counters for it (and restarts all streams); n_updates * chunk_samples < 2^30. */
 int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samples);
 int pe_update_many(pe_engine* e, const int16_t* pcm_host, int32_t chunk_samples, int32_t n_updates, float* raw_out_host);
 int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples, int32_t n_updates,
