@@ -277,8 +277,10 @@ def main():
 
         mfcc_name = 'double' if args.mfcc_precision == 'f64' else 'float'
         mfma_peak = MFMA_F32_PEAK_TFLOPS if args.gru_precision == 'f32' else MFMA_BF16_PEAK_TFLOPS
-        fused_name = ('fused_update_kernel<%s,5,true>' if args.gru_precision == 'f32' else 'fused_update_bf16_kernel<%s>') % mfcc_name
-        gru_name = 'gru_mw_kernel<5>' if args.gru_precision == 'f32' else 'gru_bf16_kernel<1>'
+        four_waves = (B + 15) // 16 <= torch.cuda.get_device_properties(device).multi_processor_count   # engine.hip: gru_args
+        fused_name = (('fused_update_kernel<%%s,5,%s>' % ('true' if four_waves else 'false')) if args.gru_precision == 'f32'
+                      else 'fused_update_bf16_kernel<%s>') % mfcc_name
+        gru_name = ('gru_mw_kernel<5>' if four_waves else 'gru_small_kernel<5,1>') if args.gru_precision == 'f32' else 'gru_bf16_kernel<1>'
         if not stock:
             fused_name = 'mfcc_stream_kernel<%s> + gru_wide_kernel<%d,1>' % (mfcc_name, units[0] // 64)
             gru_name = 'gru_wide_kernel<%d,1>' % (units[0] // 64)

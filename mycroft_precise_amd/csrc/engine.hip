@@ -47,7 +47,8 @@ struct pe_engine {
     uint32_t* st_ke[2] = {nullptr, nullptr};
     int cur = 0;
     bool fused = true;      // MFCC || GRU in one launch when the chunk size allows it
-    int gru_waves = 0;      // 0 = auto (4 waves per tile while tiles <= 1024, else 1), or forced 1 / 4
+    int gru_waves = 0;      // 0 = auto (4 waves per tile while tiles <= CUs, else 1), or forced 1 / 4
+    int n_cus = 256;        // compute units of the device (MI355X: 256)
     float* ring = nullptr;
     // several updates per call (pe_reserve_updates / pe_update_many*)
     int max_updates = 1;
@@ -434,7 +435,10 @@ GruArgs gru_args(const pe_engine* e) {
     a.bf16 = e->prm.gru_precision == 1;
     a.wx_bf16 = e->wx_bf16; a.wr_bf16 = e->wr_bf16; a.bias_bf16 = e->bias_bf16; a.wd_bf16 = e->wd_bf16;
     a.feats = nullptr; a.out = nullptr; a.row_stride = 0;
-    a.waves_per_tile = e->gru_waves ? e->gru_waves : (e->n_tiles <= 1024 ? 4 : 1);
+    // Four waves per tile cut the latency of a tile's chain; that only pays while every tile gets a CU of its
+    // own next to one MFCC workgroup.  Measured (fused, f64 front end; tools/gpu_policy.py): 4096 streams
+    // 21.9 us (4 waves) vs 32.0 (1); 8192: 41.5 vs 33.5; 16384: 76.0 vs 55.3; 65536: 284 vs 199.
+    a.waves_per_tile = e->gru_waves ? e->gru_waves : (e->n_tiles <= e->n_cus ? 4 : 1);
     if (e->prm.use_delta) a.waves_per_tile = 1;          // only the one-wave kernel carries the delta inputs
     return a;
 }
@@ -559,6 +563,10 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     pe_engine* e = new pe_engine();
     e->prm = *p;
     e->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->n_cus = cus;
+    }
     e->n_streams = n_streams;
     e->n_tiles = (n_streams + kTileStreams - 1) / kTileStreams;
     e->n_padded = e->n_tiles * kTileStreams;
