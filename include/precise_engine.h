@@ -140,6 +140,12 @@ int pe_predict_device(pe_engine* e, const float* feats_dev, int32_t n, float* ou
 int pe_vectorize_raw(pe_engine* e, const double* audio_host, int64_t n_samples,
                      double* feats_out_host, int64_t max_frames, int64_t* n_frames_out);
 
+/* The same buffer through the Vectorizer.mels entry (vectorization.py:32-35 -> sonopy.mel_spec): log of the
+ * mel filterbank energies, no DCT.  mels_out[max_frames][n_filt] float64.  Offline form only: a streaming
+ * engine whose network consumes mel features (feature_size = n_filt > 16) has no kernel. */
+int pe_vectorize_mels(pe_engine* e, const double* audio_host, int64_t n_samples,
+                      double* mels_out_host, int64_t max_frames, int64_t* n_frames_out);
+
 /* The reference's batched offline evaluation (precise/scripts/simulate.py:92-104, also
  * annoyance_estimator.py:114-130): MFCC of one whole recording, one network input per hop_frames
  * (= chunk_size // hop_samples) frames -- windows ending at frame i for i in range(n_features,

@@ -62,6 +62,8 @@ EXPORTS = {
     'pe_predict_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'pe_vectorize_raw': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                    C.POINTER(C.c_int64)]),
+    'pe_vectorize_mels': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                   C.POINTER(C.c_int64)]),
     'pe_evaluate': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
                               C.POINTER(C.c_int64)]),
     'pe_set_decoder': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
@@ -147,6 +149,7 @@ class HipEngine:
         self.n_streams = int(n_streams)
         self.n_features = int(params.n_features)
         self.n_mfcc = int(params.n_mfcc)
+        self.n_filt = int(params.n_filt)
         self.feature_size = int(params.n_mfcc) * (2 if params.use_delta else 1)
         prec = {'f64': 0, 'f32': 1}[mfcc_precision]
         p = PeParams(params.sample_rate, params.window_samples, params.hop_samples, params.n_fft,
@@ -262,6 +265,17 @@ class HipEngine:
         n = C.c_int64(0)
         self._check(self._lib.pe_vectorize_raw(self._h, audio.ctypes.data if audio.size else None, audio.size,
                                                out.ctypes.data if max_frames else None, max_frames, C.byref(n)))
+        return out[:n.value]
+
+    def vectorize_mels(self, audio) -> np.ndarray:
+        """float64 audio [n] -> log-mel frames float64 [1 + (n - window)//hop, n_filt] (stateless; Vectorizer.mels)."""
+        audio = np.ascontiguousarray(audio, dtype=np.float64).reshape(-1)
+        win, hop = self._win_hop
+        max_frames = 1 + (audio.size - win) // hop if audio.size >= win else 0
+        out = np.empty((max_frames, self.n_filt), dtype=np.float64)
+        n = C.c_int64(0)
+        self._check(self._lib.pe_vectorize_mels(self._h, audio.ctypes.data if audio.size else None, audio.size,
+                                                out.ctypes.data if max_frames else None, max_frames, C.byref(n)))
         return out[:n.value]
 
     def evaluate(self, audio, hop_frames: int) -> np.ndarray:

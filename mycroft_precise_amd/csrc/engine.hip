@@ -727,9 +727,10 @@ int pe_predict(pe_engine* e, const float* feats_host, int32_t n, float* out_host
     return PE_OK;
 }
 
-int pe_vectorize_raw(pe_engine* e, const double* audio_host, int64_t n_samples, double* feats_out_host,
-                     int64_t max_frames, int64_t* n_frames_out) {
-    if (!e || !n_frames_out) return fail(e, PE_ERR_INVALID, "null argument to pe_vectorize_raw");
+namespace {
+int vectorize_buffer(pe_engine* e, const double* audio_host, int64_t n_samples, double* feats_out_host,
+                     int64_t max_frames, int64_t* n_frames_out, bool mels) {
+    if (!e || !n_frames_out) return fail(e, PE_ERR_INVALID, "null argument to pe_vectorize_*");
     if (n_samples < 0 || (n_samples > 0 && !audio_host)) return fail(e, PE_ERR_INVALID, "bad audio buffer");
     const int64_t win = e->prm.window_samples, hop = e->prm.hop_samples;
     const int64_t n_frames = n_samples >= win ? 1 + (n_samples - win) / hop : 0;
@@ -738,19 +739,34 @@ int pe_vectorize_raw(pe_engine* e, const double* audio_host, int64_t n_samples, 
     if (!feats_out_host || max_frames < n_frames) return fail(e, PE_ERR_INVALID, "output holds %lld frames, need %lld", (long long)max_frames, (long long)n_frames);
     PE_HIP(e, hipSetDevice(e->device));
     int rc;
-    const size_t ab = (size_t)n_samples * sizeof(double), fb = (size_t)n_frames * e->prm.n_mfcc * sizeof(double);
+    const int width = mels ? e->prm.n_filt : e->prm.n_mfcc;
+    const size_t ab = (size_t)n_samples * sizeof(double), fb = (size_t)n_frames * width * sizeof(double);
     if ((rc = ensure(e, e->st_audio, ab))) return rc;
     if ((rc = ensure(e, e->st_mfcc, fb))) return rc;
     PE_HIP(e, hipMemcpy(e->st_audio.p, audio_host, ab, hipMemcpyHostToDevice));
+    double* dev_out = static_cast<double*>(e->st_mfcc.p);
     if (e->prm.mfcc_precision == 0) {
-        MfccOfflineArgs<double> a{geom(e), tables<double>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, static_cast<double*>(e->st_mfcc.p), nullptr};
+        MfccOfflineArgs<double> a{geom(e), tables<double>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames,
+                                  mels ? nullptr : dev_out, nullptr, mels ? dev_out : nullptr};
         PE_HIP(e, launch_mfcc_offline_f64(a, nullptr));
     } else {
-        MfccOfflineArgs<float> a{geom(e), tables<float>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, static_cast<double*>(e->st_mfcc.p), nullptr};
+        MfccOfflineArgs<float> a{geom(e), tables<float>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames,
+                                 mels ? nullptr : dev_out, nullptr, mels ? dev_out : nullptr};
         PE_HIP(e, launch_mfcc_offline_f32(a, nullptr));
     }
     PE_HIP(e, hipMemcpy(feats_out_host, e->st_mfcc.p, fb, hipMemcpyDeviceToHost));
     return PE_OK;
+}
+}  // namespace
+
+int pe_vectorize_raw(pe_engine* e, const double* audio_host, int64_t n_samples, double* feats_out_host,
+                     int64_t max_frames, int64_t* n_frames_out) {
+    return vectorize_buffer(e, audio_host, n_samples, feats_out_host, max_frames, n_frames_out, false);
+}
+
+int pe_vectorize_mels(pe_engine* e, const double* audio_host, int64_t n_samples, double* mels_out_host,
+                      int64_t max_frames, int64_t* n_frames_out) {
+    return vectorize_buffer(e, audio_host, n_samples, mels_out_host, max_frames, n_frames_out, true);
 }
 
 int pe_evaluate(pe_engine* e, const double* audio_host, int64_t n_samples, int32_t hop_frames, float* out_host,
@@ -774,10 +790,10 @@ int pe_evaluate(pe_engine* e, const double* audio_host, int64_t n_samples, int32
     if ((rc = ensure(e, e->st_out, (size_t)n_windows * sizeof(float)))) return rc;
     PE_HIP(e, hipMemcpy(e->st_audio.p, audio_host, ab, hipMemcpyHostToDevice));
     if (e->prm.mfcc_precision == 0) {
-        MfccOfflineArgs<double> a{geom(e), tables<double>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, nullptr, static_cast<float*>(e->st_feats.p)};
+        MfccOfflineArgs<double> a{geom(e), tables<double>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, nullptr, static_cast<float*>(e->st_feats.p), nullptr};
         PE_HIP(e, launch_mfcc_offline_f64(a, nullptr));
     } else {
-        MfccOfflineArgs<float> a{geom(e), tables<float>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, nullptr, static_cast<float*>(e->st_feats.p)};
+        MfccOfflineArgs<float> a{geom(e), tables<float>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, nullptr, static_cast<float*>(e->st_feats.p), nullptr};
         PE_HIP(e, launch_mfcc_offline_f32(a, nullptr));
     }
     GruArgs g = gru_args(e);

@@ -708,6 +708,8 @@ __device__ __forceinline__ void mfcc_offline_block(const MfccOfflineArgs<R>& a, 
     };
     const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load);
     if (a.out && r < geo.n_mfcc) a.out[fr * geo.n_mfcc + r] = (double)coeff;
+    if (a.out_mels)            // the log-mel energies are still in the group's scratch (lane f % 16 wrote entry f)
+        for (int f = r; f < geo.n_filt; f += 16) a.out_mels[fr * geo.n_filt + f] = (double)S[f];
     if (a.out_rows) a.out_rows[fr * kRowFloats + r] = (r < geo.n_mfcc) ? (float)coeff : 0.0f;
 }
 

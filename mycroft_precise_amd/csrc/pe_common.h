@@ -117,6 +117,7 @@ struct MfccOfflineArgs {
     long long n_frames;
     double* out;            // [n_frames][n_mfcc] float64, may be null
     float* out_rows;        // [n_frames][16] float32 rows (coefficients + zero padding), may be null
+    double* out_mels;       // [n_frames][n_filt] float64 log-mel energies (Vectorizer.mels), may be null
 };
 
 // ---------------------------------------------------------------------------------------

@@ -38,7 +38,19 @@ class Runner(metaclass=ABCMeta):
         """[T, F] -> scalar"""
 
 
+def _require_streamable(params):
+    """The streaming kernels carry MFCC rows (<= 16 coefficients per frame); mel rows (n_filt = 20 wide,
+    Vectorizer.mels) exist in the offline form only, the legacy speechpy front end not at all."""
+    from .params import Vectorizer
+    if params.vectorizer != Vectorizer.mfccs:
+        raise NotImplementedError('Vectorizer.%s cannot be streamed on the device: only Vectorizer.mfccs has '
+                                  'streaming kernels (mels: vectorization.vectorize / vectorize_raw)'
+                                  % {Vectorizer.mels: 'mels', Vectorizer.speechpy_mfccs: 'speechpy_mfccs'}.get(
+                                      params.vectorizer, str(params.vectorizer)))
+
+
 def _engine_params(use_delta=None):
+    _require_streamable(pr)
     snap = pr.copy()
     if use_delta is not None:
         snap.__dict__['use_delta'] = use_delta
@@ -177,6 +189,7 @@ class BatchedListener:
             weights = model
         self.n_streams = int(n_streams)
         self.weights = weights
+        _require_streamable(self.pr)
         self.engine = HipEngine(self.pr, weights, n_streams=self.n_streams, device=device,
                                 mfcc_precision=mfcc_precision, gru_precision=gru_precision)
         self.threshold_decoder = ThresholdDecoder(self.pr.threshold_config, self.pr.threshold_center)

@@ -1,8 +1,9 @@
 """
 Audio -> feature vectors: drop-in for ``precise.vectorization``
 (/root/reference/precise/vectorization.py:31-89).  The ``vectorizers`` dict is the reference's
-plug-in seam for the MFCC front end; its ``Vectorizer.mfccs`` entry is served by the HIP kernels
-(stateless whole-buffer form, ``pe_vectorize_raw``).  There is no CPU implementation here.
+plug-in seam for the front end; its ``Vectorizer.mfccs`` and ``Vectorizer.mels`` entries are served by
+the HIP kernels (stateless whole-buffer form, ``pe_vectorize_raw`` / ``pe_vectorize_mels``).  There is
+no CPU implementation here.
 """
 import numpy as np
 
@@ -58,15 +59,20 @@ def _mfccs_hip(audio: np.ndarray) -> np.ndarray:
     return _offline_engine().vectorize_raw(audio)
 
 
+def _mels_hip(audio: np.ndarray) -> np.ndarray:
+    """vectorization.py:32-35: log mel-filterbank energies [n, n_filt] -- the MFCC pipeline without its DCT."""
+    return _offline_engine().vectorize_mels(audio)
+
+
 def _no_kernel(name):
     def fn(audio):
-        raise NotImplementedError('Vectorizer.%s has no HIP kernel (only Vectorizer.mfccs does)' % name)
+        raise NotImplementedError('Vectorizer.%s has no HIP kernel (Vectorizer.mfccs and Vectorizer.mels do)' % name)
     return fn
 
 
 # audio frames -> vectors (vectorization.py:31-43)
 vectorizers = {
-    Vectorizer.mels: _no_kernel('mels'),
+    Vectorizer.mels: _mels_hip,
     Vectorizer.mfccs: _mfccs_hip,
     Vectorizer.speechpy_mfccs: _no_kernel('speechpy_mfccs'),
 }

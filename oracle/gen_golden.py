@@ -69,7 +69,33 @@ def run_listener(pcm: np.ndarray, chunk_bytes: int, weights):
             np.array(rings, dtype=np.float64), np.array(left, dtype=np.int64))
 
 
+def gen_mels():
+    """Vectorizer.mels through the reference's own dispatch (vectorization.py:31-35,46-50,62-84): the
+    process-global ``pr`` is switched to the mels vectorizer, so feature rows are n_filt wide."""
+    from precise.params import Vectorizer
+    import precise.params as rp
+    saved = rp.pr.vectorizer
+    try:
+        rp.pr.__dict__['vectorizer'] = Vectorizer.mels
+        assert rp.pr.feature_size == rp.pr.n_filt
+        vz = {}
+        for name, n in (('short', 5000), ('long', 40000), ('one_window', 1600)):
+            a = synth.stream_pcm(23, n, 'tone_noise').astype(np.float32) / np.float32(32768.0)
+            vz['audio_' + name] = a
+            vz['vec_' + name] = vectorize(a)
+            vz['raw_' + name] = vectorize_raw(a)
+        z = np.zeros(4000, dtype=np.float32)                       # eps clip in every filter
+        vz['audio_zeros'], vz['raw_zeros'] = z, vectorize_raw(z)
+        np.savez_compressed(os.path.join(OUT, 'vectorize_mels.npz'), **vz)
+    finally:
+        rp.pr.__dict__['vectorizer'] = saved
+
+
 def main():
+    if '--mels-only' in sys.argv:
+        gen_mels()
+        return
+    gen_mels()
     os.makedirs(OUT, exist_ok=True)
     weights = synth.make_weights()
 

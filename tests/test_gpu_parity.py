@@ -128,6 +128,28 @@ def test_vectorize_matches_reference_vectorize():
     assert np.abs(V.vectorize_delta(g['audio_exact']) - V.add_deltas(g['vec_exact'])).max() <= 1e-9
 
 
+def test_mels_vectorizer_matches_reference_dispatch():
+    """vectorizers[Vectorizer.mels] (vectorization.py:32-35) through pe_vectorize_mels: log-mel rows, n_filt wide,
+    against what the reference's own vectorize / vectorize_raw returned with pr.vectorizer = mels."""
+    from mycroft_precise_amd import vectorization as V
+    g = golden('vectorize_mels.npz')
+    saved = P.pr.vectorizer
+    try:
+        P.pr.__dict__['vectorizer'] = P.Vectorizer.mels
+        assert P.pr.feature_size == P.pr.n_filt == 20
+        for name in ('short', 'long', 'one_window'):
+            raw = V.vectorize_raw(g['audio_' + name])
+            assert raw.shape == g['raw_' + name].shape and raw.dtype == np.float64
+            assert np.abs(raw - g['raw_' + name]).max() <= 1e-9, name
+            v = V.vectorize(g['audio_' + name])
+            assert v.shape == (29, 20)
+            assert np.abs(v - g['vec_' + name]).max() <= 1e-9, name
+        assert np.array_equal(V.vectorize_raw(g['audio_zeros']), g['raw_zeros'])        # log(eps) exactly
+        assert V.vectorize_raw(np.zeros(1599)).shape == (0, 20)
+    finally:
+        P.pr.__dict__['vectorizer'] = saved
+
+
 # ---- oracle on seeded synthetic inputs -------------------------------------------------------------
 def _stream_batch(kinds, n_up, chunk=1024):
     return np.stack([synth.stream_pcm(s, n_up * chunk, k).reshape(n_up, chunk)

@@ -109,9 +109,17 @@ def test_vectorize_raw_rejects_empty_audio_and_unsupported_vectorizers():
     with pytest.raises(util.InvalidAudio):
         V.vectorize_raw(np.array([]))
     with pytest.raises(NotImplementedError):
-        V.vectorizers[P.Vectorizer.mels](np.zeros(2000))
-    with pytest.raises(NotImplementedError):
         V.vectorizers[P.Vectorizer.speechpy_mfccs](np.zeros(2000))
+    assert set(V.vectorizers) == {P.Vectorizer.mels, P.Vectorizer.mfccs, P.Vectorizer.speechpy_mfccs}
+
+
+def test_streaming_listeners_refuse_the_mels_vectorizer(stock_weights):
+    """mel rows are n_filt = 20 wide: there is no streaming kernel for them (offline vectorize only)."""
+    from mycroft_precise_amd.network_runner import BatchedListener
+    snap = P.pr.copy()
+    snap.__dict__['vectorizer'] = P.Vectorizer.mels
+    with pytest.raises(NotImplementedError):
+        BatchedListener(stock_weights, 4, params=snap)
 
 
 # ---- precise_runner drop-in ---------------------------------------------------------------

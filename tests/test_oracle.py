@@ -87,6 +87,20 @@ def test_vectorize_pad_crop_and_deltas():
         ol.vectorize_raw(np.array([]), pr)
 
 
+def test_mels_vectorizer_matches_reference_dispatch():
+    """Vectorizer.mels (vectorization.py:32-35): the fixture was produced by the reference's own
+    vectorize / vectorize_raw with pr.vectorizer = mels; rows are n_filt wide, no DCT."""
+    from oracle import sonopy_restated as so
+    g = golden('vectorize_mels.npz')
+    pr = ol.Params()
+    for name in ('short', 'long', 'one_window', 'zeros'):
+        raw = so.mel_spec(g['audio_' + name], pr.sample_rate, (pr.window_samples, pr.hop_samples),
+                          num_filt=pr.n_filt, fft_size=pr.n_fft)
+        assert raw.shape[1] == pr.n_filt
+        assert np.array_equal(raw, g['raw_' + name]), name
+    assert np.all(g['raw_zeros'] == np.log(np.finfo(float).eps))
+
+
 @pytest.mark.parametrize('name', ['default', 'two', 'narrow'])
 def test_threshold_decoder(name):
     g = golden('threshold_decoder.npz')
