@@ -248,7 +248,7 @@ static hipError_t launch_many_r(const GruArgs& a, int n_updates, int n_padded, h
     const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
     // up to ~1.5 windows per SIMD the four-wave kernel wins (4096 streams x 4 updates: 18.1 vs 20.1 us per
     // update), from 2 per SIMD on the one-wave kernel does (x 16: 12.5 vs 14.0)
-    if ((long long)tiles * n_updates <= 1536)
+    if ((long long)tiles * n_updates <= 1536 && !a.use_delta)      // (the delta inputs: one-wave kernel only)
         hipLaunchKernelGGL((gru_many_mw_kernel<R>), dim3(tiles * n_updates), dim3(256), 0, s, a, tiles, n_padded);
     else
         hipLaunchKernelGGL((gru_many_kernel<R>), dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);

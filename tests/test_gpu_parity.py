@@ -484,6 +484,14 @@ def test_use_delta_matches_reference_semantics(tmp_path):
         want = np.array([r.update_raw(pcm[u, j].tobytes()) for j, r in enumerate(refs)])
         for eng in engines:
             assert np.abs(eng.update(pcm[u]) - want).max() <= GUARD_RAW, u
+    # several updates per call must take the kernel that carries the delta inputs too
+    many = HipEngine(hpr, w, n_streams=n)
+    many.reserve_updates(4, 1024)
+    ref2 = HipEngine(hpr, w, n_streams=n)
+    for u in range(0, 16, 4):
+        want_many = np.stack([ref2.update(pcm[u + i]) for i in range(4)])
+        assert np.array_equal(many.update_many(pcm[u:u + 4]), want_many), u
+    many.close(); ref2.close()
     # explicit batch with its delta columns
     x = np.stack([ol.add_deltas(r.mfccs) for r in refs]).astype(np.float32)
     assert x.shape == (n, 29, 26)
