@@ -918,7 +918,8 @@ int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     // frames one stream can complete in this call: one workgroup row per frame, at most kMaxFrameRows rows
     const long long fmax = ((long long)(kCarryCap - 1) + (long long)n_updates * chunk - flen) / e->prm.hop_samples + 1;
-    const int rows = (int)(fmax < 1 ? 1 : fmax > kMaxFrameRows ? kMaxFrameRows : fmax);
+    if (fmax > kMaxFrameRows) return fail(e, PE_ERR_INVALID, "a call may complete at most %d frames per stream (%d updates of %d samples: %lld)", kMaxFrameRows, n_updates, chunk, fmax);
+    const int rows = (int)(fmax < 1 ? 1 : fmax);
     if (e->prm.mfcc_precision == 0) {
         MfccStreamArgs<double> a = mfcc_args<double>(e, pcm_dev, chunk);
         a.n_updates = n_updates; a.ke_hist = e->ke_hist; a.n_frame_rows = rows; a.carry_next = e->carry_alt;

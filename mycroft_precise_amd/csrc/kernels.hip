@@ -15,10 +15,17 @@ __global__ __launch_bounds__(256) void mfcc_stream_kernel(const MfccStreamArgs<R
     mfcc_stream_tile<R>(a, blockIdx.x / nsel, smem, blockIdx.x % nsel, nsel);
 }
 
+// (waves_per_eu(3): the frame rows need 134 VGPRs in float64; left to itself the allocator takes 231 and two
+// of these workgroups then fill a SIMD's register file, so that no network wave of a concurrent launch fits)
 template <class R>
-__global__ __launch_bounds__(16 * kThroughputGroups) void mfcc_many_kernel(const MfccStreamArgs<R> a) {
+__global__ __launch_bounds__(16 * kThroughputGroups) __attribute__((amdgpu_waves_per_eu(3))) void mfcc_many_kernel(const MfccStreamArgs<R> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    mfcc_many_tile<R>(a, smem);
+    mfcc_many_tile<R, false>(a, smem);
+}
+
+template <class R>
+__global__ __launch_bounds__(256) void mfcc_many_book_kernel(const MfccStreamArgs<R> a) {
+    mfcc_many_tile<R, true>(a, nullptr);
 }
 
 // network for a whole batch of updates: workgroup (one wave) b serves update b / n_tiles, tile b % n_tiles
@@ -196,9 +203,10 @@ template <class R>
 static hipError_t launch_many(const MfccStreamArgs<R>& a, hipStream_t s) {
     const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
     const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc, a.tab.mel_parts, kThroughputGroups);
-    const long long groups = (long long)tiles * (a.n_frame_rows + 1) * kTileStreams;
+    const long long groups = (long long)tiles * a.n_frame_rows * kTileStreams;
     hipLaunchKernelGGL(mfcc_many_kernel<R>, dim3((unsigned)((groups + kThroughputGroups - 1) / kThroughputGroups)),
                        dim3(16 * kThroughputGroups), lds, s, a);
+    hipLaunchKernelGGL(mfcc_many_book_kernel<R>, dim3(tiles), dim3(256), 0, s, a);     // reads what the rows read, writes elsewhere
     return hipGetLastError();
 }
 hipError_t launch_mfcc_many_f64(const MfccStreamArgs<double>& a, hipStream_t s) { return launch_many<double>(a, s); }

@@ -561,29 +561,32 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
 // which frame is closed-form integer arithmetic over the virtual stream
 //     [carry (q samples)] ++ chunk 0 ++ chunk 1 ++ ... ++ chunk n_updates-1,
 // so the frames of a call are independent tasks: the 16-lane group of task (tile, kb, stream) transforms
-// frames kb, kb + n_kb, ... of its stream (n_kb rows share a tile), and one more row (kb == n_kb) does the
+// frames kb, kb + n_kb, ... of its stream (n_kb rows share a tile), and a second, small launch does the
 // bookkeeping -- leftover samples to carry_next, counters to st_*_next, and the emitted-frame counter
 // after EVERY update (ke_hist) that tells the network launch which window each update saw.
 // carry_next must not alias carry: other rows still read the old carry.
-template <class R>
+template <class R, bool BOOK>
 __device__ __forceinline__ void mfcc_many_tile(const MfccStreamArgs<R>& a, unsigned char* smem) {
     using K = RealK<R>;
     const StreamGeom& geo = a.geo;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, r = lane & 15;
-    // task = (tile, row, stream of the tile), rows 0..n_kb-1 transform frames, row n_kb keeps the books
+    // Two launches share this body (so that each gets its own register allocation: the frame rows need
+    // ~130 VGPRs, with the bookkeeping code compiled in the allocation was 232 and nothing else fitted on a
+    // SIMD next to two of these workgroups):
+    //   BOOK = false: task = (tile, row kb < n_kb, stream of the tile) transforms frames kb, kb + n_kb, ...
+    //   BOOK = true:  task = (tile, stream) keeps the books of the call
     const int n_kb = a.n_frame_rows;
     const long long task = (long long)blockIdx.x * (blockDim.x >> 4) + wave * 4 + grp;
     const int j = (int)(task & 15);
-    const int kb = (int)((task >> 4) % (n_kb + 1));
-    const int tile = (int)((task >> 4) / (n_kb + 1));
+    const int kb = BOOK ? n_kb : (int)((task >> 4) % n_kb);
+    const int tile = BOOK ? (int)(task >> 4) : (int)((task >> 4) / n_kb);
     const long long s = (long long)tile * kTileStreams + j;
     const bool active = s < geo.n_streams;
-    const bool book = kb == n_kb;
+    constexpr bool book = BOOK;
     LdsTab<R> tab;
     R* scratch = nullptr;
-    // with 16 groups per workgroup a workgroup is exactly one row: bookkeeping workgroups need no tables
-    if (!(kThroughputGroups == 16 && book)) {
+    if (!BOOK) {
         scratch = lds_setup<R>(smem, a.tab, geo.n_filt, geo.n_mfcc, tab);
         __syncthreads();
     }
@@ -637,22 +640,17 @@ __device__ __forceinline__ void mfcc_many_tile(const MfccStreamArgs<R>& a, unsig
         R* S = scratch + (wave * 4 + grp) * tab.group_reals;
         float* ring_rows = a.ring + ((size_t)tile * slots * kTileStreams + j) * kRowFloats;
         const int f_first = nnew > slots ? nnew - slots : 0;   // older frames would be overwritten anyway
-        int k = kb;
-        if (k < f_first) k += ((f_first - k + n_kb - 1) / n_kb) * n_kb;
+        const int k = kb;                                      // one frame per task: the launch has a row per frame
+        if (k < f_first || k >= nnew) return;
         int cur[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) cur[c] = 0;
-        if (k < nnew) fetch(k * hop, flen, cur);
-        for (; k < nnew; k += n_kb) {                          // one trip unless the rows were capped (kMaxFrameRows)
-            auto load = [&](int c, R& xr, R& xi) {
-                xr = (R)(int)(short)(cur[c] & 0xffff);
-                xi = (R)(cur[c] >> 16);
-            };
-            const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load, K::PSCALE_I16);
-            const int slot = (int)((kc + (uint32_t)k) & (uint32_t)(slots - 1));
-            ring_rows[(size_t)slot * kTileStreams * kRowFloats + r] = (r < geo.n_mfcc) ? (float)coeff : 0.0f;
-            if (k + n_kb < nnew) fetch((k + n_kb) * hop, flen, cur);
-        }
+        fetch(k * hop, flen, cur);
+        auto load = [&](int c, R& xr, R& xi) {
+            xr = (R)(int)(short)(cur[c] & 0xffff);
+            xi = (R)(cur[c] >> 16);
+        };
+        const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load, K::PSCALE_I16);
+        const int slot = (int)((kc + (uint32_t)k) & (uint32_t)(slots - 1));
+        ring_rows[(size_t)slot * kTileStreams * kRowFloats + r] = (r < geo.n_mfcc) ? (float)coeff : 0.0f;
         return;
     }
 

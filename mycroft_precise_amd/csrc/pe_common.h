@@ -20,7 +20,7 @@ constexpr int kTrStride = 17;                       // padded row of the 16x16 L
 constexpr int kPowerPad = 16 * kTrStride + 2;       // power spectrum, bin b at b + (b >> 4)
 constexpr int kMelSteps = 17;                       // bins per lane in the mel pass: 16 r .. 16 r + 16
 constexpr int kMaxMelParts = 128;                   // partial filter sums per frame
-constexpr int kMaxFrameRows = 64;                   // pe_update_many: workgroup rows per tile sharing a call's frames
+constexpr int kMaxFrameRows = 4096;                 // pe_update_many: frames one stream may complete per call (= workgroup rows per tile)
 #ifndef PE_TG
 #define PE_TG 16
 #endif
