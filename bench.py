@@ -229,7 +229,7 @@ def main():
     mfcc_ms, gru_ms = timed_pass(False)
 
     # ---- extra (not the headline): the same updates issued 8 per call (pe_update_many_device) ----------
-    # Two launches per 8 updates: the MFCC chain of every stream, then the network for all 8 x B windows
+    # Three launches per 8 updates: every MFCC frame of the call, the per-stream bookkeeping, then the network for all 8 x B windows
     # at once.  Results are bit-identical to single updates; a caller pays 8 chunks of buffering latency.
     time_batched = None
     depth = 8
@@ -250,7 +250,7 @@ def main():
             dt = time.perf_counter() - t1
             time_batched = {'updates_per_call': depth, 'value': n_global * rounds * depth / dt, 'unit': 'windows/s',
                             'ms_per_update': 1e3 * dt / (rounds * depth),
-                            'note': 'pe_update_many_device: same results, 2 launches per %d updates; not the headline' % depth}
+                            'note': 'pe_update_many_device: same results, 3 launches per %d updates; not the headline' % depth}
         except (ValueError, NotImplementedError):
             time_batched = None
 
