@@ -64,9 +64,18 @@ def synth_pcm_device(n_updates, n_streams, first_stream, device):
     return out
 
 
+def _affinity_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def _cpu_worker(args):
-    """One host core's share of the cpu_baseline: the numpy oracle on a slice of streams."""
-    first, n_streams, n_updates, seed = args
+    """One host core's share of the cpu_baseline: the numpy oracle ("port") on its own slice of streams.
+    Import, weights and PCM synthesis happen BEFORE the start barrier; only the arithmetic is timed, and the
+    worker returns its own compute time."""
+    first, n_streams, n_updates, n_distinct, seed, barrier = args
     from oracle import listener as oracle_listener          # checker / baseline only
     try:
         from threadpoolctl import threadpool_limits
@@ -74,35 +83,100 @@ def _cpu_worker(args):
     except ImportError:
         pass
     weights = synth.make_weights(seed=seed)
-    pcm = synth.batch_pcm(n_streams, n_updates, CHUNK, first_stream=first)
+    base = synth.batch_pcm(min(n_streams, 64), n_distinct, CHUNK, first_stream=first)     # [n_distinct, <=64, CHUNK]
+    pcm = np.ascontiguousarray(np.tile(base, (1, (n_streams + base.shape[1] - 1) // base.shape[1], 1))[:, :n_streams])
     oracle = oracle_listener.BatchedOracle(weights, n_streams)
+    for u in range(5):                                       # first touches (page faults, allocator growth: the first
+        oracle.update_raw(pcm[u % n_distinct])               # updates of a 1024-stream batch run 10-20x slower), untimed
+    if barrier is not None:
+        barrier.wait()
     t0 = time.perf_counter()
     for u in range(n_updates):
-        oracle.update_raw(pcm[u])
+        oracle.update_raw(pcm[(u + 5) % n_distinct])
     return time.perf_counter() - t0
 
 
-def cpu_baseline(target_seconds=12.0):
-    """Oracle ("port" of the reference's sonopy + Keras arithmetic) on every host core, on a
-    bounded sample of the same workload: each core streams `per_core` streams for `n_updates`
-    updates.  Returns the cpu_baseline JSON object."""
+def cpu_baseline(target_seconds=8.0, streams_per_core=1024):
+    """Oracle ("port" of the reference's sonopy + Keras arithmetic, vectorised over streams) on every host core,
+    on a bounded sample of the same workload: every core steps `streams_per_core` streams through `n_updates`
+    updates.  All workers start their timed loops together (barrier after fork / import / synthesis); value =
+    windows / the longest worker's compute time."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
-    n_updates = 48
-    # calibrate on one core, then size the sample for ~target_seconds of wall time
-    probe = _cpu_worker((0, 16, n_updates, 42))
-    per_window = probe / (16 * n_updates)
-    per_core = int(max(16, min(96, target_seconds / (per_window * n_updates))))
-    jobs = [(c * per_core, per_core, n_updates, 42) for c in range(cores)]
+    cores = _affinity_cores()
+    n_distinct = 8
+    n_probe = 8
+    probe = _cpu_worker((0, streams_per_core, n_probe, n_distinct, 42, None))    # one core alone: calibration
+    per_update = probe / n_probe
+    # with every core busy the per-core rate drops (shared memory bandwidth, clocks): size for the target anyway
+    n_updates = int(max(8, min(2000, round(target_seconds / per_update))))
+    ctx = mp.get_context('fork')
+    barrier = ctx.Barrier(cores)
     t0 = time.perf_counter()
-    with mp.get_context('fork').Pool(cores) as pool:
-        pool.map(_cpu_worker, jobs)
+    procs, results = [], ctx.Queue()
+
+    def run(job):
+        results.put(_cpu_worker(job))
+
+    for c in range(cores):
+        pr_ = ctx.Process(target=run, args=((c * streams_per_core, streams_per_core, n_updates, n_distinct, 42, barrier),))
+        pr_.start()
+        procs.append(pr_)
+    times = [results.get() for _ in procs]
+    for pr_ in procs:
+        pr_.join()
     wall = time.perf_counter() - t0
-    windows = cores * per_core * n_updates
-    return {'value': windows / wall, 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d streams x %d updates of %d samples (%d windows) in %.1f s, numpy oracle '
-                      '(float64 MFCC + float32 GRU), one process per host core'
-                      % (cores * per_core, n_updates, CHUNK, windows, wall)}
+    windows = cores * streams_per_core * n_updates
+    compute = max(times)
+    single = streams_per_core * n_probe / probe
+    return {'value': windows / compute, 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
+            'compute_s': compute, 'wall_s': wall, 'per_core': windows / compute / cores,
+            'single_core_alone': single,
+            'sample': '%d cores x %d streams x %d updates of %d samples (%d windows); numpy oracle (float64 MFCC + '
+                      'float32 GRU), one process per core, timed loops start together after fork/import/synthesis; '
+                      'compute %.1f s (slowest worker), wall incl. set-up %.1f s; one core alone: %.0f windows/s'
+                      % (cores, streams_per_core, n_updates, CHUNK, windows, compute, wall, single)}
+
+
+def cpu_baseline_single_stream(seconds=3.0):
+    """ONE stream through Listener.update, the way the reference runs (batch 1, one chunk per
+    call).  With /root/reference present (the build container) it is the reference's own unmodified
+    precise.network_runner.Listener with the restated third-party arithmetic plugged into its two seams
+    (sonopy module, runner_cls); on the GPU box, where the reference does not exist, the oracle's
+    restatement of that class."""
+    from oracle import listener as oracle_listener, keras_gru, sonopy_restated
+    weights = synth.make_weights()
+    pcm = synth.stream_pcm(0, 64 * CHUNK)
+    chunks = [pcm[i * CHUNK:(i + 1) * CHUNK].tobytes() for i in range(64)]
+    kind, listener = 'port', None
+    ref_root = '/root/reference'
+    if os.path.isdir(os.path.join(ref_root, 'precise')):
+        try:
+            sys.dont_write_bytecode = True
+            import warnings
+            warnings.simplefilter('ignore', DeprecationWarning)
+            sys.modules.setdefault('sonopy', sonopy_restated)
+            if ref_root not in sys.path:
+                sys.path.insert(0, ref_root)
+            from precise.network_runner import Listener as RefListener
+            listener = RefListener('synthetic-model-not-on-disk', 2 * CHUNK, runner_cls=keras_gru.make_runner_cls(weights))
+            kind = 'reference-glue'
+        except Exception:                                    # noqa: BLE001  (any import problem: fall back, labelled)
+            listener = None
+    if listener is None:
+        listener = oracle_listener.OracleListener(weights)
+    for c in chunks[:40]:
+        listener.update(c)                                   # fill the feature window, untimed
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        listener.update(chunks[n % 64])
+        n += 1
+    dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'windows/s', 'cores': 1, 'kind': kind, 'ms_per_update': 1e3 * dt / n,
+            'realtime_factor': (n / dt) / REALTIME_WINDOWS_PER_S,
+            'sample': '%d Listener.update calls of one %d-sample chunk on one stream in %.1f s; %s'
+                      % (n, CHUNK, dt, "the reference's unmodified precise.network_runner.Listener with restated sonopy / "
+                         "Keras-GRU arithmetic in its seams" if kind == 'reference-glue' else
+                         "oracle.listener.OracleListener (the reference tree is not on this box)")}
 
 
 def main():
@@ -123,6 +197,7 @@ def main():
     rank, local_rank, world = env_world()
     # host-core baseline first, before this process owns a GPU context (it forks workers)
     cpu = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None
+    cpu_b1 = cpu_baseline_single_stream() if (world == 1 and not args.no_cpu_baseline) else None
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
@@ -154,7 +229,8 @@ def main():
     flop_per_window = 2 * sum(29 * 3 * h * (f + h) for f, h in zip((13,) + units[:-1], units)) + 2 * units[-1]
     engine = HipEngine(pr, weights, n_streams=B, device=dev_index, mfcc_precision=args.mfcc_precision,
                        gru_precision=args.gru_precision)
-    pcm = synth_pcm_device(n_res, B, rank * B, device)
+    first_stream = int(os.environ.get('PE_BENCH_FIRST_STREAM', '0')) + rank * B      # (test aid: shard offset of a solo run)
+    pcm = synth_pcm_device(n_res, B, first_stream, device)
     probs = torch.zeros((steps, B), dtype=torch.float32, device=device)
     scratch = torch.zeros((B,), dtype=torch.float32, device=device)
     stream = torch.cuda.current_stream().cuda_stream
@@ -194,6 +270,8 @@ def main():
     if rank == 0:
         assert gathered.shape == (steps, n_global)
     finite = bool(torch.isfinite(gathered if rank == 0 else probs).all().item())
+    if rank == 0 and os.environ.get('PE_BENCH_DUMP'):        # test aid: the timed region's probabilities, rank-ordered
+        np.save(os.environ['PE_BENCH_DUMP'], gathered.cpu().numpy())
 
     # ---- instrumented passes: HIP-event time per launch, on the launch stream --------------------
     def timed_pass(fused):
@@ -331,6 +409,8 @@ def main():
             line['time_batched'] = time_batched
         if cpu is not None:
             line['cpu_baseline'] = cpu
+        if cpu_b1 is not None:
+            line['cpu_baseline_single_stream'] = cpu_b1
         print(json.dumps(line), flush=True)
 
     engine.close()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PE_ABI_VERSION 2
+#define PE_ABI_VERSION 3
 
 typedef enum pe_status {
     PE_OK = 0,
@@ -55,6 +55,15 @@ typedef struct pe_params {
     int32_t gru_precision;   /* 0 = float32 matrix cores (reference precision, tol 1e-4);
                                 1 = bf16 operands / float32 accumulate (BASELINE configs[4],
                                 tol 1e-2)                                                    */
+    int32_t vectorizer;      /* params.py:121-132: 2 = mfccs (sonopy, the default; also serves the
+                                offline mels entry), 3 = speechpy_mfccs (legacy .params files without
+                                a `vectorizer` key, params.py:147,155): one frame fewer per buffer
+                                (a frame is emitted one hop later), exact zeros -- not small values --
+                                replaced by eps before the log; the caller supplies that library's
+                                filterbank as mel_filters.  0 is read as 2.                     */
+    int32_t ring_precision;  /* 0 = float32 feature rows (64 B per frame and stream);
+                                1 = bf16 feature rows (32 B), rounded to nearest even where the row is
+                                stored -- needs gru_precision = 1 (BASELINE configs[4])         */
 } pe_params;
 
 /* One Keras GRU layer (precise/model.py:77-81), Keras weight layout, gate order z|r|h. */
@@ -90,7 +99,9 @@ int pe_destroy(pe_engine* e);
 const char* pe_last_error(const pe_engine* e);
 
 /* Listener.clear (network_runner.py:121-123).  mask: n_streams bytes, non-zero = clear that
- * stream; NULL = clear all. */
+ * stream; NULL = clear all.  Runs on the NULL stream and synchronises: a caller that drives the
+ * *_device entry points on a non-blocking stream must synchronise that stream first (the same holds for
+ * pe_get_vectors / pe_set_vectors / pe_get_stream_state). */
 int pe_clear(pe_engine* e, const uint8_t* mask);
 
 /* Listener.update up to, not including, ThresholdDecoder.decode (network_runner.py:148-152):
@@ -124,6 +135,12 @@ int pe_update_vectors_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk
 /* Listener.mfccs (network_runner.py:104,144): copy out the current feature windows,
  * feats_out[n_streams][n_features][n_mfcc] float32, oldest row first; consumes no audio. */
 int pe_get_vectors(pe_engine* e, float* feats_out_host);
+
+/* Assignment to Listener.mfccs / a Listener whose runner is replaced after construction
+ * (scripts/train_incremental.py:87-88): every stream restarts (pe_clear) with the given feature window
+ * already emitted and no leftover audio; feats[n_streams][n_features][n_mfcc] float32, oldest row
+ * first.  Feed the leftover samples back with pe_update_vectors to restore a whole Listener state. */
+int pe_set_vectors(pe_engine* e, const float* feats_host);
 
 /* Run the network on the current feature windows without consuming audio. */
 int pe_run_device(pe_engine* e, float* raw_out_dev, void* hip_stream);
@@ -161,7 +178,10 @@ int pe_evaluate(pe_engine* e, const double* audio_host, int64_t n_samples, int32
  * threshold_decoder.py:42,68-70), min_out / out_range / center as the Python object holds them.
  * pe_set_trigger: (re)arms one TriggerDetector per stream (chunk_size in BYTES as in runner.py:122).
  * pe_decode*: raw[n_streams] float32 -> conf[n_streams] float64 (may be NULL) and, when a trigger is
- * set, fired[n_streams] (1 = this prediction caused an activation; may be NULL). */
+ * set, fired[n_streams] (1 = this prediction caused an activation; may be NULL).  The logit follows the
+ * reference's evaluation on the runner's float32 scalar (functions.py:99-101: `1 / x - 1` rounds twice in
+ * float32, the logarithm is taken in float64), so the table bin -- and with it the decoded value -- is the
+ * one Listener.update returns, not the one a float64 logit would give. */
 int pe_set_decoder(pe_engine* e, const double* cd, int32_t cd_len, int32_t min_out, int32_t out_range, double center);
 int pe_set_trigger(pe_engine* e, int32_t chunk_size_bytes, double sensitivity, int32_t trigger_level);
 int pe_decode_device(pe_engine* e, const float* raw_dev, double* conf_out_dev, unsigned char* fired_out_dev, void* hip_stream);
@@ -185,7 +205,8 @@ int pe_get_stream_state(pe_engine* e, int32_t* q_out, uint32_t* computed_out, ui
 int pe_set_fused(pe_engine* e, int32_t enabled);
 
 /* Network kernel shape: 0 (default) = automatic (four waves share each 16-stream tile while the
- * engine has <= 1024 tiles, one wave per tile beyond), 1 / 4 = forced.  Results are identical. */
+ * engine has no more tiles than the device has compute units -- 256 on MI355X, i.e. 4096 streams -- one wave
+ * per tile beyond; use_delta networks always take the one-wave kernel), 1 / 4 = forced.  Results are identical. */
 int pe_set_gru_waves(pe_engine* e, int32_t waves_per_tile);
 
 /* HIP-event timing of the kernels launched by the last *_device/host update on this engine

@@ -14,13 +14,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PE_LIB') or os.path.join(HERE, 'libprecise_engine.so')
 
 PE_OK, PE_ERR_INVALID, PE_ERR_HIP, PE_ERR_UNSUPPORTED, PE_ERR_NOMEM, PE_ERR_EOF = range(6)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class PeParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'sample_rate', 'window_samples', 'hop_samples', 'n_fft', 'n_filt', 'n_mfcc', 'n_features',
-        'use_delta', 'mfcc_precision', 'gru_precision')]
+        'use_delta', 'mfcc_precision', 'gru_precision', 'vectorizer', 'ring_precision')]
 
 
 class PeGruLayer(C.Structure):
@@ -57,6 +57,7 @@ EXPORTS = {
     'pe_update_vectors': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     'pe_update_vectors_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'pe_get_vectors': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'pe_set_vectors': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pe_run_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'pe_predict': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     'pe_predict_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -142,8 +143,9 @@ class HipEngine:
     """
 
     def __init__(self, params, weights, n_streams=1, device=0, mfcc_precision='f64', mel_filters=None,
-                 gru_precision='f32'):
-        from .vectorization import mel_filterbank
+                 gru_precision='f32', ring_precision='f32'):
+        from .vectorization import mel_filterbank, speechpy_filterbank
+        from .params import Vectorizer
         self._lib = load()
         self._h = C.c_void_p()
         self.n_streams = int(n_streams)
@@ -152,11 +154,15 @@ class HipEngine:
         self.n_filt = int(params.n_filt)
         self.feature_size = int(params.n_mfcc) * (2 if params.use_delta else 1)
         prec = {'f64': 0, 'f32': 1}[mfcc_precision]
+        vec = int(getattr(params, 'vectorizer', Vectorizer.mfccs))
+        if vec == Vectorizer.mels:          # the mels entry is the mfccs pipeline without its DCT (offline form)
+            vec = Vectorizer.mfccs
         p = PeParams(params.sample_rate, params.window_samples, params.hop_samples, params.n_fft,
                      params.n_filt, params.n_mfcc, params.n_features, int(bool(params.use_delta)), prec,
-                     {'f32': 0, 'bf16': 1}[gru_precision])
+                     {'f32': 0, 'bf16': 1}[gru_precision], vec, {'f32': 0, 'bf16': 1}[ring_precision])
         if mel_filters is None:
-            mel_filters = mel_filterbank(params.sample_rate, params.n_filt, params.n_fft // 2 + 1)
+            bank = speechpy_filterbank if vec == Vectorizer.speechpy_mfccs else mel_filterbank
+            mel_filters = bank(params.sample_rate, params.n_filt, params.n_fft // 2 + 1)
         mel = np.ascontiguousarray(mel_filters, dtype=np.float64)
         if mel.shape != (params.n_filt, params.n_fft // 2 + 1):
             raise ValueError('mel filterbank has shape %r' % (mel.shape,))
@@ -247,6 +253,13 @@ class HipEngine:
         feats = np.empty((self.n_streams, self.n_features, self.n_mfcc), dtype=np.float32)
         self._check(self._lib.pe_get_vectors(self._h, feats.ctypes.data))
         return feats
+
+    def set_vectors(self, feats):
+        """Restart every stream with the given feature windows [n_streams, T, F] already emitted."""
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        if feats.shape != (self.n_streams, self.n_features, self.n_mfcc):
+            raise ValueError('expected [%d, %d, %d] features, got %r' % (self.n_streams, self.n_features, self.n_mfcc, feats.shape))
+        self._check(self._lib.pe_set_vectors(self._h, feats.ctypes.data))
 
     def predict(self, feats) -> np.ndarray:
         feats = np.ascontiguousarray(feats, dtype=np.float32)

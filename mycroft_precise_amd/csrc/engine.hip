@@ -118,6 +118,15 @@ int dev_upload(pe_engine* e, T** out, const std::vector<T>& host) {
     return PE_OK;
 }
 
+// release one dev_alloc'ed buffer before pe_destroy (tables that are replaced: decoder LUT, ring, ke_hist)
+void dev_free(pe_engine* e, void* p, size_t bytes) {
+    if (!p) return;
+    for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it)
+        if (*it == p) { e->allocs.erase(it); break; }
+    (void)hipFree(p);
+    e->device_bytes -= (int64_t)bytes;
+}
+
 int ensure(pe_engine* e, DeviceBuf& b, size_t bytes) {
     if (b.bytes >= bytes) return PE_OK;
     if (b.p) { (void)hipFree(b.p); e->device_bytes -= (int64_t)b.bytes; b.p = nullptr; b.bytes = 0; }
@@ -369,10 +378,25 @@ int pack_gru_weights_wide(pe_engine* e, const pe_weights* w) {
     return dev_upload(e, &e->wide_wd, wd);
 }
 
+// Samples of the virtual stream that must have arrived, counted from a frame's first sample, before the
+// reference's Listener has that frame in its window: the whole analysis window (sonopy emits one frame per
+// full window), plus one hop for the legacy speechpy front end, whose stack_frames returns
+// floor((len - window) / hop) frames -- one fewer.
+int emit_window(const pe_params& p) { return p.window_samples + (p.vectorizer == 3 ? p.hop_samples : 0); }
+int frame_len_of(const pe_params& p) { return p.window_samples < kNfft ? p.window_samples : kNfft; }
+// frames computed (first frame_len samples arrived) but not yet emitted: at most this many exist at any time
+int pending_frames(const pe_params& p) { return (emit_window(p) - frame_len_of(p) + p.hop_samples - 1) / p.hop_samples; }
+// vectorize_raw on a whole buffer (vectorization.py:46-50): frames the vectorizer returns for n samples
+int64_t frames_of_buffer(const pe_params& p, int64_t n) {
+    const int64_t ew = emit_window(p);
+    return n >= ew ? 1 + (n - ew) / p.hop_samples : 0;
+}
+
 StreamGeom geom(const pe_engine* e) {
     StreamGeom g;
     g.n_streams = e->n_streams;
-    g.window = e->prm.window_samples;
+    g.log_mode = e->prm.vectorizer == 3 ? 1 : 0;
+    g.window = emit_window(e->prm);
     g.hop = e->prm.hop_samples;
     g.frame_len = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
     g.n_filt = e->prm.n_filt;
@@ -430,8 +454,8 @@ GruArgs gru_args(const pe_engine* e) {
     a.predict_ke = 0;
     a.st_q = e->st_q[e->cur]; a.st_kc = e->st_kc[e->cur];
     a.chunk = 0;
-    a.window = e->prm.window_samples; a.hop = e->prm.hop_samples;
-    a.frame_len = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
+    a.window = emit_window(e->prm); a.hop = e->prm.hop_samples;
+    a.frame_len = frame_len_of(e->prm);
     a.bf16 = e->prm.gru_precision == 1;
     a.wx_bf16 = e->wx_bf16; a.wr_bf16 = e->wr_bf16; a.bias_bf16 = e->bias_bf16; a.wd_bf16 = e->wd_bf16;
     a.feats = nullptr; a.out = nullptr; a.row_stride = 0;
@@ -484,8 +508,7 @@ int check_chunk(pe_engine* e, const void* pcm, int chunk) {
 // True when no frame computed by an update of `chunk` samples can become visible in that same
 // update (it needs window - frame_len more samples), so the network does not depend on it.
 bool can_fuse(const pe_engine* e, int chunk) {
-    const int flen = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
-    return e->fused && !e->wide && chunk <= e->prm.window_samples - flen;
+    return e->fused && !e->wide && chunk <= emit_window(e->prm) - frame_len_of(e->prm);
 }
 
 int do_update(pe_engine* e, const int16_t* pcm_dev, int chunk, float* raw_out_dev, float* feats_out_dev,
@@ -539,6 +562,10 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     if (p->use_delta && p->gru_precision != 0) return fail(nullptr, PE_ERR_UNSUPPORTED, "use_delta has no bf16 kernel");
     if (p->mfcc_precision != 0 && p->mfcc_precision != 1) return fail(nullptr, PE_ERR_INVALID, "mfcc_precision must be 0 (f64) or 1 (f32)");
     if (p->gru_precision != 0 && p->gru_precision != 1) return fail(nullptr, PE_ERR_INVALID, "gru_precision must be 0 (f32) or 1 (bf16 operands)");
+    if (p->vectorizer != 0 && p->vectorizer != 2 && p->vectorizer != 3)
+        return fail(nullptr, PE_ERR_UNSUPPORTED, "vectorizer must be 2 (mfccs) or 3 (speechpy_mfccs); Vectorizer.mels (1) exists in the offline form only (pe_vectorize_mels), got %d", p->vectorizer);
+    if (p->ring_precision != 0 && p->ring_precision != 1) return fail(nullptr, PE_ERR_INVALID, "ring_precision must be 0 (f32 rows) or 1 (bf16 rows)");
+    if (p->ring_precision == 1) return fail(nullptr, PE_ERR_UNSUPPORTED, "bf16 feature rows are not built yet");
     if (w->n_layers < 1 || w->n_layers > 2 || !w->layers) return fail(nullptr, PE_ERR_UNSUPPORTED, "networks of 1 or 2 GRU layers have kernels (got %d layers)", w->n_layers);
     const pe_gru_layer& L = w->layers[0];
     const bool wide = w->n_layers == 2 || L.units > 32;
@@ -572,11 +599,10 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     e->n_padded = e->n_tiles * kTileStreams;
     e->units = L.units; e->n_in = p->n_mfcc; e->n_layers = w->n_layers; e->wide = wide;
     e->dense_bias = w->dense_bias;
-    const int flen = p->window_samples < kNfft ? p->window_samples : kNfft;
+    if (e->prm.vectorizer == 0) e->prm.vectorizer = 2;
     // frames computed (first flen samples arrived) but not yet emitted (whole window arrived):
     // at most ceil((window - flen) / hop) of them exist at any time; T + that many rows are live
-    const int pending = (p->window_samples - flen + p->hop_samples - 1) / p->hop_samples;
-    e->ring_slots = next_pow2(p->n_features + pending);
+    e->ring_slots = next_pow2(p->n_features + pending_frames(e->prm));
 
     int rc = PE_OK;
     do {
@@ -642,6 +668,7 @@ int pe_clear(pe_engine* e, const uint8_t* mask_host) {
 int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, float* raw_out_dev, void* stream) {
     int rc = check_chunk(e, pcm_dev, chunk);
     if (rc) return rc;
+    PE_HIP(e, hipSetDevice(e->device));
     if (!raw_out_dev) return fail(e, PE_ERR_INVALID, "raw_out_dev is null");
     return do_update(e, pcm_dev, chunk, raw_out_dev, nullptr, static_cast<hipStream_t>(stream));
 }
@@ -649,11 +676,13 @@ int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, float*
 int pe_update_vectors_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, float* feats_out_dev, void* stream) {
     int rc = check_chunk(e, pcm_dev, chunk);
     if (rc) return rc;
+    PE_HIP(e, hipSetDevice(e->device));
     return do_update(e, pcm_dev, chunk, nullptr, feats_out_dev, static_cast<hipStream_t>(stream));
 }
 
 int pe_run_device(pe_engine* e, float* raw_out_dev, void* stream) {
     if (!e || !raw_out_dev) return fail(e, PE_ERR_INVALID, "null argument to pe_run_device");
+    PE_HIP(e, hipSetDevice(e->device));
     return launch_gru_ring(e, raw_out_dev, static_cast<hipStream_t>(stream));
 }
 
@@ -699,10 +728,25 @@ int pe_get_vectors(pe_engine* e, float* feats_out_host) {
     return PE_OK;
 }
 
+int pe_set_vectors(pe_engine* e, const float* feats_host) {
+    if (!e || !feats_host) return fail(e, PE_ERR_INVALID, "null argument to pe_set_vectors");
+    PE_HIP(e, hipSetDevice(e->device));
+    int rc;
+    if ((rc = pe_clear(e, nullptr))) return rc;
+    const size_t feat_bytes = (size_t)e->n_streams * e->prm.n_features * e->prm.n_mfcc * sizeof(float);
+    if ((rc = ensure(e, e->st_feats, feat_bytes))) return rc;
+    PE_HIP(e, hipMemcpy(e->st_feats.p, feats_host, feat_bytes, hipMemcpyHostToDevice));
+    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->ring, e->st_ke[e->cur], static_cast<float*>(e->st_feats.p)};
+    PE_HIP(e, launch_scatter(g, e->st_q[e->cur], e->st_kc[e->cur], nullptr));
+    PE_HIP(e, hipStreamSynchronize(nullptr));
+    return PE_OK;
+}
+
 int pe_predict_device(pe_engine* e, const float* feats_dev, int32_t n, float* out_dev, void* stream) {
     if (!e) return PE_ERR_INVALID;
     if (n < 0 || (n > 0 && (!feats_dev || !out_dev))) return fail(e, PE_ERR_INVALID, "bad arguments to pe_predict_device");
     if (n == 0) return PE_OK;
+    PE_HIP(e, hipSetDevice(e->device));
     GruArgs a = gru_args(e);
     a.n_streams = n;
     a.waves_per_tile = 1;
@@ -732,8 +776,7 @@ int vectorize_buffer(pe_engine* e, const double* audio_host, int64_t n_samples, 
                      int64_t max_frames, int64_t* n_frames_out, bool mels) {
     if (!e || !n_frames_out) return fail(e, PE_ERR_INVALID, "null argument to pe_vectorize_*");
     if (n_samples < 0 || (n_samples > 0 && !audio_host)) return fail(e, PE_ERR_INVALID, "bad audio buffer");
-    const int64_t win = e->prm.window_samples, hop = e->prm.hop_samples;
-    const int64_t n_frames = n_samples >= win ? 1 + (n_samples - win) / hop : 0;
+    const int64_t n_frames = frames_of_buffer(e->prm, n_samples);
     *n_frames_out = n_frames;
     if (n_frames == 0) return PE_OK;
     if (!feats_out_host || max_frames < n_frames) return fail(e, PE_ERR_INVALID, "output holds %lld frames, need %lld", (long long)max_frames, (long long)n_frames);
@@ -774,8 +817,8 @@ int pe_evaluate(pe_engine* e, const double* audio_host, int64_t n_samples, int32
     if (!e || !n_windows_out) return fail(e, PE_ERR_INVALID, "null argument to pe_evaluate");
     if (hop_frames < 1) return fail(e, PE_ERR_INVALID, "hop_frames must be >= 1 (chunk_size // hop_samples)");
     if (n_samples < 0 || (n_samples > 0 && !audio_host)) return fail(e, PE_ERR_INVALID, "bad audio buffer");
-    const int64_t win = e->prm.window_samples, hop = e->prm.hop_samples, T = e->prm.n_features;
-    const int64_t n_frames = n_samples >= win ? 1 + (n_samples - win) / hop : 0;
+    const int64_t T = e->prm.n_features;
+    const int64_t n_frames = frames_of_buffer(e->prm, n_samples);
     // simulate.py:96-99: windows end at frame i for i in range(T, n_frames, hop_frames)
     const int64_t n_windows = n_frames > T ? (n_frames - T + hop_frames - 1) / hop_frames : 0;
     *n_windows_out = n_windows;
@@ -811,6 +854,9 @@ int pe_set_decoder(pe_engine* e, const double* cd, int32_t cd_len, int32_t min_o
     if (!e || cd_len < 0 || (cd_len > 0 && !cd)) return fail(e, PE_ERR_INVALID, "bad decoder table");
     if (out_range != 0 && cd_len < 1) return fail(e, PE_ERR_INVALID, "decoder needs a non-empty table when out_range != 0");
     PE_HIP(e, hipSetDevice(e->device));
+    PE_HIP(e, hipDeviceSynchronize());                    // no decode launch may still read the old table
+    dev_free(e, e->cd, (size_t)(e->cd_len ? e->cd_len : 1) * sizeof(double));
+    e->cd = nullptr; e->cd_len = 0;
     std::vector<double> host(cd, cd + cd_len);
     int rc = dev_upload(e, &e->cd, host);
     if (rc) return rc;
@@ -838,6 +884,7 @@ int pe_decode_device(pe_engine* e, const float* raw_dev, double* conf_out_dev, u
     if (!e || !raw_dev) return fail(e, PE_ERR_INVALID, "null argument to pe_decode_device");
     if (!e->cd && e->dec_out_range != 0) return fail(e, PE_ERR_INVALID, "pe_set_decoder has not been called");
     if (!e->cd_len && !e->cd) return fail(e, PE_ERR_INVALID, "pe_set_decoder has not been called");
+    PE_HIP(e, hipSetDevice(e->device));
     DecodeArgs a{};
     a.n_streams = e->n_streams; a.raw = raw_dev; a.cd = e->cd; a.cd_len = e->cd_len;
     a.min_out = e->dec_min_out; a.out_range = e->dec_out_range; a.center = e->dec_center;
@@ -872,15 +919,11 @@ int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samp
     if (e->wide) return fail(e, PE_ERR_UNSUPPORTED, "pe_update_many has no wide-GRU path");
     PE_HIP(e, hipSetDevice(e->device));
     PE_HIP(e, hipDeviceSynchronize());
-    const int flen = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
-    const int pending = (e->prm.window_samples - flen + e->prm.hop_samples - 1) / e->prm.hop_samples;
+    const int pending = pending_frames(e->prm);
     const long long frames = ((long long)max_updates * max_chunk_samples + e->prm.hop_samples - 1) / e->prm.hop_samples + 1;
     const int slots = next_pow2((int)(e->prm.n_features + pending + frames));
     if (slots != e->ring_slots) {
-        for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it)
-            if (*it == e->ring) { e->allocs.erase(it); break; }
-        (void)hipFree(e->ring);
-        e->device_bytes -= (int64_t)e->n_tiles * e->ring_slots * kTileStreams * kRowFloats * (int64_t)sizeof(float);
+        dev_free(e, e->ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kRowFloats * sizeof(float));
         e->ring = nullptr;
         e->ring_slots = slots;
         int rc = dev_alloc(e, &e->ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kRowFloats);
@@ -888,10 +931,7 @@ int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samp
     }
     if (!e->ke_hist || max_updates > e->max_updates) {
         if (e->ke_hist) {
-            for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it)
-                if (*it == e->ke_hist) { e->allocs.erase(it); break; }
-            (void)hipFree(e->ke_hist);
-            e->device_bytes -= (int64_t)e->max_updates * e->n_padded * (int64_t)sizeof(uint32_t);
+            dev_free(e, e->ke_hist, (size_t)e->max_updates * e->n_padded * sizeof(uint32_t));
             e->ke_hist = nullptr;
         }
         int rc = dev_alloc(e, &e->ke_hist, (size_t)max_updates * e->n_padded);
@@ -910,8 +950,9 @@ int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, i
     if (rc) return rc;
     if (!raw_out_dev || n_updates < 1) return fail(e, PE_ERR_INVALID, "bad arguments to pe_update_many_device");
     if (n_updates > e->max_updates || !e->ke_hist) return fail(e, PE_ERR_INVALID, "call pe_reserve_updates(e, >= %d, >= %d) first", n_updates, chunk);
-    const int flen = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
-    const int pending = (e->prm.window_samples - flen + e->prm.hop_samples - 1) / e->prm.hop_samples;
+    PE_HIP(e, hipSetDevice(e->device));
+    const int flen = frame_len_of(e->prm);
+    const int pending = pending_frames(e->prm);
     const long long frames = ((long long)n_updates * chunk + e->prm.hop_samples - 1) / e->prm.hop_samples + 1;
     if ((long long)n_updates * chunk >= (1ll << 30)) return fail(e, PE_ERR_INVALID, "n_updates * chunk_samples must stay below 2^30");
     if (e->prm.n_features + pending + frames > e->ring_slots) return fail(e, PE_ERR_INVALID, "reserved ring too small for %d updates of %d samples", n_updates, chunk);

@@ -337,6 +337,33 @@ __global__ void gather_kernel(const GatherArgs a) {
     a.out[idx] = a.ring[(((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kRowFloats + f];
 }
 
+__global__ void scatter_kernel(const GatherArgs a, int32_t* st_q, uint32_t* st_kc) {
+    // inverse of gather_kernel: the stream restarts with the given [T][F] window already emitted
+    // (frames 0..T-1 in slots 0..T-1, nothing held toward the next frame)
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)a.n_streams * a.n_features * kRowFloats;
+    if (idx >= total) return;
+    const int f = (int)(idx % kRowFloats);
+    const int t = (int)((idx / kRowFloats) % a.n_features);
+    const long long s = idx / ((long long)kRowFloats * a.n_features);
+    const long long tile = s / kTileStreams;
+    const int j = (int)(s % kTileStreams);
+    const float v = f < a.n_mfcc ? a.out[(s * a.n_features + t) * a.n_mfcc + f] : 0.0f;
+    const_cast<float*>(a.ring)[(((size_t)tile * a.ring_slots + t) * kTileStreams + j) * kRowFloats + f] = v;
+    if (f == 0 && t == 0) {
+        st_q[s] = 0;
+        st_kc[s] = (uint32_t)a.n_features;
+        const_cast<uint32_t*>(a.st_ke)[s] = (uint32_t)a.n_features;
+    }
+}
+
+hipError_t launch_scatter(const GatherArgs& a, int32_t* st_q, uint32_t* st_kc, hipStream_t s) {
+    const long long total = (long long)a.n_streams * a.n_features * kRowFloats;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, st_q, st_kc);
+    return hipGetLastError();
+}
+
 __global__ void clear_kernel(const ClearArgs a) {
     // one workgroup per stream: zero its counters and every ring row
     const long long s = blockIdx.x;
@@ -354,14 +381,18 @@ __global__ void clear_kernel(const ClearArgs a) {
 __global__ void decode_kernel(const DecodeArgs a) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= a.n_streams) return;
-    const double raw = (double)a.raw[s];
+    const float rawf = a.raw[s];
+    const double raw = (double)rawf;
     double conf = raw;
     if (raw != 1.0 && raw != 0.0) {                       // saturated sigmoid passes through (:46-47)
         double cp;
         if (a.out_range == 0) {
             cp = raw > (double)a.min_out ? 1.0 : 0.0;
         } else {
-            double ratio = (-log(1.0 / raw - 1.0) - (double)a.min_out) / (double)a.out_range;
+            // asigmoid (functions.py:99-101) on the runner's float32 scalar: numpy evaluates `1 / x - 1` in
+            // float32 (two correctly rounded operations), math.log then takes that value as a double
+            const float odds = __fsub_rn(__fdiv_rn(1.0f, rawf), 1.0f);
+            double ratio = (-log((double)odds) - (double)a.min_out) / (double)a.out_range;
             ratio = fmin(fmax(ratio, 0.0), 1.0);
             cp = a.cd[(int)(ratio * (double)(a.cd_len - 1) + 0.5)];
         }

@@ -191,7 +191,7 @@ __device__ __forceinline__ R* lds_setup(unsigned char* smem, const MfccTables<R>
 // Returns coefficient r in lane r (lanes >= n_mfcc return 0).  S: this group's LDS scratch.
 template <class R, class Load>
 __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_filt, int n_mfcc, Load load,
-                                        const R pscale = RealK<R>::INV_FFT) {
+                                        const R pscale = RealK<R>::INV_FFT, const int log_mode = 0) {
     using K = RealK<R>;
     R re[16], im[16];
 #pragma unroll
@@ -351,7 +351,8 @@ __device__ __forceinline__ R mfcc_frame(const LdsTab<R>& t, R* S, int r, int n_f
     for (int f = r; f <= n_filt; f += 16) {
         const R acc = f < n_filt ? LM[f] : psum;
 #ifndef PE_ABL_LOG
-        LM[f] = real_log(acc > K::EPS ? acc : K::EPS);
+        // sonopy clips at eps (safe_log); speechpy replaces exact zeros only (zero_handling): 0 < x < eps stays x
+        LM[f] = real_log(log_mode == 0 ? (acc > K::EPS ? acc : K::EPS) : (acc == R(0) ? K::EPS : acc));
 #else
         LM[f] = acc + K::EPS;
 #endif
@@ -517,7 +518,7 @@ __device__ __forceinline__ void mfcc_stream_tile(const MfccStreamArgs<R>& a, con
             xr = (R)(int)(short)(cur[c] & 0xffff);
             xi = (R)(cur[c] >> 16);
         };
-        const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load, K::PSCALE_I16);
+        const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load, K::PSCALE_I16, geo.log_mode);
         const uint32_t k = kc + (uint32_t)f;
         const int slot = (int)(k & (uint32_t)(slots - 1));
         const float row = (r < geo.n_mfcc) ? (float)coeff : 0.0f;
@@ -648,7 +649,7 @@ __device__ __forceinline__ void mfcc_many_tile(const MfccStreamArgs<R>& a, unsig
             xr = (R)(int)(short)(cur[c] & 0xffff);
             xi = (R)(cur[c] >> 16);
         };
-        const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load, K::PSCALE_I16);
+        const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load, K::PSCALE_I16, geo.log_mode);
         const int slot = (int)((kc + (uint32_t)k) & (uint32_t)(slots - 1));
         ring_rows[(size_t)slot * kTileStreams * kRowFloats + r] = (r < geo.n_mfcc) ? (float)coeff : 0.0f;
         return;
@@ -704,7 +705,7 @@ __device__ __forceinline__ void mfcc_offline_block(const MfccOfflineArgs<R>& a, 
         xr = (n < flen) ? (R)x[n] : R(0);
         xi = (n + 1 < flen) ? (R)x[n + 1] : R(0);
     };
-    const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load);
+    const R coeff = mfcc_frame<R>(tab, S, r, geo.n_filt, geo.n_mfcc, load, RealK<R>::INV_FFT, geo.log_mode);
     if (a.out && r < geo.n_mfcc) a.out[fr * geo.n_mfcc + r] = (double)coeff;
     if (a.out_mels)            // the log-mel energies are still in the group's scratch (lane f % 16 wrote entry f)
         for (int f = r; f < geo.n_filt; f += 16) a.out_mels[fr * geo.n_filt + f] = (double)S[f];

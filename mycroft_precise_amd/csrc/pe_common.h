@@ -73,7 +73,8 @@ struct MfccTables {
 
 struct StreamGeom {
     int n_streams;
-    int window;       // window_samples
+    int window;       // samples past a frame's start that make it visible: window_samples (+ hop for speechpy)
+    int log_mode;     // 0: log(max(x, eps)) (sonopy safe_log);  1: log(x == 0 ? eps : x) (speechpy zero_handling)
     int hop;          // hop_samples
     int frame_len;    // min(window, n_fft): samples of a window that reach the FFT
     int n_filt;
@@ -231,6 +232,7 @@ int gru_wide_waves(int units);                  // waves per workgroup of the wi
 int gru_small_tiles(int units);                 // NT = ceil(3R/4)
 hipError_t launch_gru_wide(const WideArgs& a, int input_mode, hipStream_t s);      // units 64..256, 1-2 layers
 hipError_t launch_gather(const GatherArgs& a, hipStream_t s);
+hipError_t launch_scatter(const GatherArgs& a, int32_t* st_q, uint32_t* st_kc, hipStream_t s);   // a.out is read
 hipError_t launch_clear(const ClearArgs& a, hipStream_t s);
 
 }  // namespace pe

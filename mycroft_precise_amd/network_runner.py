@@ -20,10 +20,10 @@ import numpy as np
 
 from ._lib import HipEngine
 from .model import load_weights
-from .params import inject_params, pr
+from .params import inject_params, pr, Vectorizer
 from .threshold_decoder import ThresholdDecoder
 from .util import pcm16_from
-from .vectorization import add_deltas
+from .vectorization import add_deltas, vectorize_raw
 
 
 class Runner(metaclass=ABCMeta):
@@ -39,14 +39,13 @@ class Runner(metaclass=ABCMeta):
 
 
 def _require_streamable(params):
-    """The streaming kernels carry MFCC rows (<= 16 coefficients per frame); mel rows (n_filt = 20 wide,
-    Vectorizer.mels) exist in the offline form only, the legacy speechpy front end not at all."""
-    from .params import Vectorizer
-    if params.vectorizer != Vectorizer.mfccs:
-        raise NotImplementedError('Vectorizer.%s cannot be streamed on the device: only Vectorizer.mfccs has '
-                                  'streaming kernels (mels: vectorization.vectorize / vectorize_raw)'
-                                  % {Vectorizer.mels: 'mels', Vectorizer.speechpy_mfccs: 'speechpy_mfccs'}.get(
-                                      params.vectorizer, str(params.vectorizer)))
+    """The streaming kernels carry MFCC rows (<= 16 coefficients per frame) of the sonopy (``mfccs``) or the
+    legacy speechpy (``speechpy_mfccs``) front end; mel rows (n_filt = 20 wide, Vectorizer.mels) exist in the
+    offline form only -- the reference's own Listener cannot stream them either (network_runner.py:104,144)."""
+    if params.vectorizer not in (Vectorizer.mfccs, Vectorizer.speechpy_mfccs):
+        raise NotImplementedError('Vectorizer.%s cannot be streamed on the device: Vectorizer.mfccs and '
+                                  'Vectorizer.speechpy_mfccs have streaming kernels (mels: vectorization.vectorize '
+                                  '/ vectorize_raw)' % {Vectorizer.mels: 'mels'}.get(params.vectorizer, str(params.vectorizer)))
 
 
 def _engine_params(use_delta=None):
@@ -99,16 +98,39 @@ class Listener:
         self.pr = inject_params(model_name)
         self.chunk_size = chunk_size
         runner_cls = runner_cls or self.find_runner(model_name)
-        self.runner = runner_cls(model_name)
         self.threshold_decoder = ThresholdDecoder(self.pr.threshold_config, pr.threshold_center)
-        self._fused = isinstance(self.runner, HipRunner) and self.runner.engine.n_streams == 1
-        if self._fused:
-            self._engine = self.runner.engine
-        else:       # a foreign Runner plugged into the reference's seam: the GPU still does the MFCC
-            self._engine = HipEngine(_engine_params(use_delta=False), _placeholder_weights(self.pr.n_mfcc))
         self.window_audio = np.array([])
         self._mfccs = None
+        self._engine = None
+        self._front = None          # MFCC-only engine behind a foreign runner, created on first need
+        self._float_mode = False
+        self.runner = runner_cls(model_name)
         self.clear()
+
+    @property
+    def runner(self):
+        return self._runner
+
+    @runner.setter
+    def runner(self, runner):
+        """The reference lets callers swap the runner of a live Listener (scripts/train_incremental.py:87-88):
+        predictions must come from the new runner from the next update on, the stream state stays."""
+        self._runner = runner
+        fused = isinstance(runner, HipRunner) and runner.engine.n_streams == 1
+        if fused:
+            engine = runner.engine
+        else:       # a foreign Runner plugged into the reference's seam: the GPU still does the MFCC
+            if self._front is None:
+                self._front = HipEngine(_engine_params(use_delta=False), _placeholder_weights(self.pr.n_mfcc))
+            engine = self._front
+        old = self._engine
+        self._fused, self._engine = fused, engine
+        if old is not None and old is not engine and not getattr(self, '_float_mode', False):
+            # carry the stream over: the feature window as it stands, then the leftover samples
+            engine.set_vectors(old.get_vectors())
+            if len(self.window_audio):
+                left = np.rint(np.asarray(self.window_audio, dtype=np.float64) * 32768.0).astype('<i2')
+                engine.update_vectors(left.reshape(1, -1), want_features=False)
 
     @staticmethod
     def find_runner(model_name: str):
@@ -122,6 +144,7 @@ class Listener:
         self.window_audio = np.array([])
         self._engine.clear()
         self._mfccs = np.zeros((self.pr.n_features, self.pr.n_mfcc))
+        self._float_mode = False
 
     @property
     def mfccs(self) -> np.ndarray:
@@ -130,46 +153,84 @@ class Listener:
             self._mfccs = self._engine.get_vectors()[0].astype(np.float64)
         return self._mfccs
 
-    def _read(self, stream) -> np.ndarray:
+    def _read(self, stream):
+        """What the reference appends to ``window_audio`` (network_runner.py:126-137) as a pair
+        (int16 PCM or None, float samples): bytes and file-like streams are little-endian int16 PCM
+        (``buffer_to_audio``); an ndarray IS the samples, whatever its dtype -- it is PCM for the device path
+        only when every sample is exactly k/32768."""
         if isinstance(stream, np.ndarray):
-            return pcm16_from(stream)
+            audio = stream.reshape(-1)
+            scaled = audio.astype(np.float64) * 32768.0
+            if scaled.size == 0 or (np.all(np.rint(scaled) == scaled) and scaled.min() >= -32768 and scaled.max() <= 32767):
+                return scaled.astype('<i2'), audio
+            return None, audio
         chunk = stream if isinstance(stream, (bytes, bytearray)) else stream.read(self.chunk_size)
         if len(chunk) == 0:
             raise EOFError
-        return pcm16_from(chunk)
+        pcm = pcm16_from(chunk)
+        return pcm, pcm.astype(np.float32) / np.float32(32768.0)
 
-    def _track_leftover(self, pcm: np.ndarray):
+    def _frames_in(self, n: int) -> int:
+        """Frames the vectorizer returns for ``n`` buffered samples (speechpy drops the last full window)."""
+        if n < self.pr.window_samples:
+            return 0
+        full = 1 + (n - self.pr.window_samples) // self.pr.hop_samples
+        return full - 1 if self.pr.vectorizer == Vectorizer.speechpy_mfccs else full
+
+    def _track_leftover(self, audio: np.ndarray):
         # host mirror of the reference's ``window_audio`` attribute (sample bookkeeping only)
-        self.window_audio = np.concatenate((self.window_audio, pcm.astype(np.float32) / 32768.0))
-        n = len(self.window_audio)
-        if n >= self.pr.window_samples:
-            frames = 1 + (n - self.pr.window_samples) // self.pr.hop_samples
-            self.window_audio = self.window_audio[frames * self.pr.hop_samples:]
+        self.window_audio = np.concatenate((self.window_audio, audio))
+        self.window_audio = self.window_audio[self._frames_in(len(self.window_audio)) * self.pr.hop_samples:]
+
+    def _update_vectors_float(self, audio: np.ndarray) -> np.ndarray:
+        """Arbitrary float samples (scaled, resampled or mixed audio, e.g. ``load_audio`` output, which is
+        k/32767): the reference's own bookkeeping (network_runner.py:137-144) on the host, float64 like its
+        ``window_audio``; the MFCC of the buffered samples is the device's stateless kernel (``vectorize_raw``).
+        Once a stream has taken such samples its leftover is no longer int16, so it stays on this path until
+        ``clear()``."""
+        if not self._float_mode:
+            self._mfccs = self.mfccs                   # pull the device's feature window over once
+            self._float_mode = True
+        self.window_audio = np.concatenate((self.window_audio, audio))
+        if len(self.window_audio) >= self.pr.window_samples:
+            new = vectorize_raw(self.window_audio)
+            self.window_audio = self.window_audio[len(new) * self.pr.hop_samples:]
+            if len(new) > len(self._mfccs):
+                new = new[-len(self._mfccs):]
+            self._mfccs = np.concatenate((self._mfccs[len(new):], new))
+        return self._mfccs
 
     def update_vectors(self, stream) -> np.ndarray:
-        pcm = self._read(stream)
-        if pcm.size == 0:
-            raise EOFError
-        self._track_leftover(pcm)
+        pcm, audio = self._read(stream)
+        if self._float_mode or pcm is None:
+            return self._update_vectors_float(audio)
+        if pcm.size == 0:                              # an empty ndarray: nothing to append (no EOFError, :126-127)
+            return self.mfccs
+        self._track_leftover(audio)
         self._mfccs = self._engine.update_vectors(pcm.reshape(1, -1))[0].astype(np.float64)
         return self._mfccs
 
-    def update_raw(self, stream) -> float:
-        """``update`` without the ThresholdDecoder: the raw network output."""
-        if self._fused:
-            pcm = self._read(stream)
-            if pcm.size == 0:
-                raise EOFError
-            self._track_leftover(pcm)
+    def _update_raw32(self, stream):
+        """The network output as the runner hands it over: a numpy float32 scalar on the HIP path, exactly
+        what ``TensorFlowRunner.run`` returns in the reference (network_runner.py:73-74)."""
+        pcm, audio = self._read(stream)
+        if self._fused and not self._float_mode and pcm is not None and pcm.size:
+            self._track_leftover(audio)
             self._mfccs = None                     # fetched from the device on demand
-            return float(self._engine.update(pcm.reshape(1, -1))[0])
-        mfccs = self.update_vectors(stream)
+            return self._engine.update(pcm.reshape(1, -1))[0]
+        mfccs = self.update_vectors(audio if pcm is None or self._float_mode or not pcm.size else pcm.astype(np.float32) / np.float32(32768.0))
         if self.pr.use_delta:
             mfccs = add_deltas(mfccs)
         return self.runner.run(mfccs)
 
+    def update_raw(self, stream) -> float:
+        """``update`` without the ThresholdDecoder: the raw network output."""
+        return float(self._update_raw32(stream))
+
     def update(self, stream) -> float:
-        return float(self.threshold_decoder.decode(self.update_raw(stream)))
+        # the decoder sees the runner's own scalar type: with a float32 network output the reference's
+        # ``1 / x - 1`` (functions.py:99-101) is float32 arithmetic, and the table bin follows from that
+        return float(self.threshold_decoder.decode(self._update_raw32(stream)))
 
 
 class BatchedListener:

@@ -9,9 +9,12 @@ largest ``mu + max_z*std`` (both truncated to int), are accumulated into the loo
 raw output is mapped to its logit, to a table index (rounded to nearest), to a cumulative probability,
 and finally stretched so that ``center`` lands on 0.5.
 
-Host-side scalar float64 work on ONE number per prediction (``decode``); ``pe_decode`` runs the same
-arithmetic for every stream on the device.  It is a step function of logit(raw), so parity tests
-compare the raw output and allow one table bin on the decoded value.
+Host-side scalar work on ONE number per prediction (``decode``); ``pe_decode`` runs the same arithmetic for
+every stream on the device.  The logit is evaluated in the scalar type of the argument, exactly as the
+reference's ``asigmoid`` (functions.py:99-101) does: the runners return a numpy float32 scalar, for which
+``1 / x - 1`` is float32 arithmetic, and only the logarithm is taken in float64.  ``decode(np.float32(p))``
+and the device decoder therefore return what ``Listener.update`` returns in the reference; ``decode(float(p))``
+is the float64 evaluation and can land in the neighbouring table bin.
 """
 import numpy as np
 
@@ -51,7 +54,9 @@ class ThresholdDecoder:
         return self._stretch(self._cumulative(raw_output))
 
     def decode_many(self, raw) -> np.ndarray:
-        return np.array([self.decode(float(v)) for v in np.asarray(raw).reshape(-1)], dtype=np.float64)
+        """Element-wise ``decode``; every element keeps the array's scalar type (a float32 array decodes as
+        the reference decodes a float32 network output, see ``decode``)."""
+        return np.array([self.decode(v) for v in np.asarray(raw).reshape(-1)], dtype=np.float64)
 
     def encode(self, threshold: float) -> float:
         """Inverse direction: the raw network output whose decoded confidence is ``threshold``."""

@@ -1,9 +1,9 @@
 """
 Audio -> feature vectors: drop-in for ``precise.vectorization``
 (/root/reference/precise/vectorization.py:31-89).  The ``vectorizers`` dict is the reference's
-plug-in seam for the front end; its ``Vectorizer.mfccs`` and ``Vectorizer.mels`` entries are served by
-the HIP kernels (stateless whole-buffer form, ``pe_vectorize_raw`` / ``pe_vectorize_mels``).  There is
-no CPU implementation here.
+plug-in seam for the front end; all three entries (``mfccs``, ``mels``, and the legacy ``speechpy_mfccs`` that
+old ``.params`` files select) are served by the HIP kernels (stateless whole-buffer form, ``pe_vectorize_raw`` /
+``pe_vectorize_mels``).  There is no CPU implementation here.
 """
 import numpy as np
 
@@ -37,17 +37,43 @@ def mel_filterbank(sample_rate: int, num_filt: int, n_bins: int) -> np.ndarray:
     return bank
 
 
+def speechpy_filterbank(sample_rate: int, num_filt: int, n_bins: int) -> np.ndarray:
+    """
+    The filterbank of the legacy vectorizer (vectorization.py:40-42 -> speechpy-fast 2.4 ``feature.filterbanks``
+    as ``feature.mfe`` calls it with low_frequency=0, high_frequency=None): num_filt+2 points equally spaced on
+    the mel scale m(f) = 1127 ln(1 + f/700) between 300 Hz -- that library reads a lower edge of 0 as "unset" --
+    and sample_rate/2, mapped to bins with floor((n_bins + 1) * hz / sample_rate); filter i is the triangle
+    over [left, right] that is zero AT both ends and 1.0 at ``middle``.
+    """
+    lo = 1127.0 * np.log(1.0 + 300.0 / 700.0)
+    hi = 1127.0 * np.log(1.0 + (sample_rate / 2) / 700.0)
+    hz = 700.0 * (np.exp(np.linspace(lo, hi, num_filt + 2) / 1127.0) - 1.0)
+    pts = np.floor((n_bins + 1) * hz / sample_rate).astype(int)
+    bank = np.zeros((num_filt, n_bins), dtype=np.float64)
+    for f in range(num_filt):
+        left, mid, right = int(pts[f]), int(pts[f + 1]), int(pts[f + 2])
+        x = np.linspace(left, right, num=right - left + 1)
+        tri = np.zeros(x.shape)
+        up = np.logical_and(left < x, x <= mid)
+        tri[up] = (x[up] - left) / (mid - left)
+        down = np.logical_and(mid <= x, x < right)
+        tri[down] = (right - x[down]) / (right - mid)
+        bank[f, left:right + 1] = tri
+    return bank
+
+
 _offline = {}
 
 
-def _offline_engine():
+def _offline_engine(vectorizer=Vectorizer.mfccs):
     """One stateless engine per parameter set, created on first use."""
     from ._lib import HipEngine
-    key = (pr.sample_rate, pr.window_samples, pr.hop_samples, pr.n_fft, pr.n_filt, pr.n_mfcc)
+    key = (pr.sample_rate, pr.window_samples, pr.hop_samples, pr.n_fft, pr.n_filt, pr.n_mfcc, int(vectorizer))
     eng = _offline.get(key)
     if eng is None:
         snap = pr.copy()
         snap.__dict__['use_delta'] = False
+        snap.__dict__['vectorizer'] = vectorizer
         f = snap.n_mfcc
         dummy = {'gru': [(np.zeros((f, 3), np.float32), np.zeros((1, 3), np.float32), np.zeros(3, np.float32))],
                  'dense_kernel': np.zeros((1, 1), np.float32), 'dense_bias': np.zeros(1, np.float32)}
@@ -64,17 +90,17 @@ def _mels_hip(audio: np.ndarray) -> np.ndarray:
     return _offline_engine().vectorize_mels(audio)
 
 
-def _no_kernel(name):
-    def fn(audio):
-        raise NotImplementedError('Vectorizer.%s has no HIP kernel (Vectorizer.mfccs and Vectorizer.mels do)' % name)
-    return fn
+def _speechpy_hip(audio: np.ndarray) -> np.ndarray:
+    """vectorization.py:40-42: the legacy front end -- its own filterbank, one frame fewer per buffer, exact zeros
+    (only) replaced by eps before the logarithms; same kernels."""
+    return _offline_engine(Vectorizer.speechpy_mfccs).vectorize_raw(audio)
 
 
 # audio frames -> vectors (vectorization.py:31-43)
 vectorizers = {
     Vectorizer.mels: _mels_hip,
     Vectorizer.mfccs: _mfccs_hip,
-    Vectorizer.speechpy_mfccs: _no_kernel('speechpy_mfccs'),
+    Vectorizer.speechpy_mfccs: _speechpy_hip,
 }
 
 

@@ -20,6 +20,7 @@ from math import exp, log, sqrt, pi, floor
 import numpy as np
 
 from . import sonopy_restated as sonopy
+from . import speechpy_restated as speechpy
 from . import keras_gru
 
 
@@ -68,9 +69,12 @@ def buffer_to_audio(buffer: bytes) -> np.ndarray:
 
 
 def vectorize_raw(audio, pr: Params):
-    """vectorization.py:46-50 with the ``Vectorizer.mfccs`` entry (:36-39)."""
+    """vectorization.py:46-50 with the ``Vectorizer.mfccs`` entry (:36-39), or -- ``pr.vectorizer == 3`` -- the
+    legacy ``Vectorizer.speechpy_mfccs`` entry (:40-42)."""
     if len(audio) == 0:
         raise ValueError('Cannot vectorize empty audio!')
+    if pr.vectorizer == 3:
+        return speechpy.feature.mfcc(np.asarray(audio), pr.sample_rate, pr.window_t, pr.hop_t, pr.n_mfcc, pr.n_filt, pr.n_fft)
     return sonopy.mfcc_spec(audio, pr.sample_rate, (pr.window_samples, pr.hop_samples),
                             num_filt=pr.n_filt, fft_size=pr.n_fft, num_coeffs=pr.n_mfcc)
 
@@ -163,15 +167,18 @@ class OracleListener:
             self.mfccs = np.concatenate((self.mfccs[len(new):], new))
         return self.mfccs
 
-    def update_raw(self, stream) -> float:
-        """update() up to, not including, the ThresholdDecoder: the raw network output."""
+    def update_raw32(self, stream):
+        """update() up to, not including, the ThresholdDecoder: the runner's numpy float32 scalar (:152)."""
         mfccs = self.update_vectors(stream)
         if self.pr.use_delta:
             mfccs = add_deltas(mfccs)
-        return float(keras_gru.predict(mfccs[np.newaxis], self.weights)[0][0])
+        return keras_gru.predict(mfccs[np.newaxis], self.weights)[0][0]
 
-    def update(self, stream) -> float:            # :148-153
-        return self.threshold_decoder.decode(self.update_raw(stream))
+    def update_raw(self, stream) -> float:
+        return float(self.update_raw32(stream))
+
+    def update(self, stream) -> float:            # :148-153: the decoder is handed the float32 scalar
+        return self.threshold_decoder.decode(self.update_raw32(stream))
 
 
 class BatchedOracle:
@@ -200,9 +207,11 @@ class BatchedOracle:
         length = self.window_audio.shape[1]
         if length >= pr.window_samples:
             starts = sonopy.frame_starts(length, pr.window_samples, pr.hop_samples)
-            idx = starts[:, None] + np.arange(pr.n_fft)[None, :]            # Q2 crop
-            new = sonopy.mfcc_from_frames(self.window_audio[:, idx], pr.sample_rate, pr.n_fft,
-                                          pr.n_filt, pr.n_mfcc)           # [B, n, F]
+            if pr.vectorizer == 3:
+                starts = starts[:speechpy.n_frames(length, pr.window_samples, pr.hop_samples)]     # S1: one fewer
+            idx = starts[:, None] + np.arange(pr.n_fft)[None, :]            # Q2 / S2 crop
+            front = speechpy.mfcc_from_frames if pr.vectorizer == 3 else sonopy.mfcc_from_frames
+            new = front(self.window_audio[:, idx], pr.sample_rate, pr.n_fft, pr.n_filt, pr.n_mfcc)   # [B, n, F]
             n_new = new.shape[1]
             self.window_audio = self.window_audio[:, n_new * pr.hop_samples:]
             if n_new > pr.n_features:

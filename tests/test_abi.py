@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_struct_layouts_match_header():
-    assert ctypes.sizeof(_lib.PeParams) == 10 * 4
+    assert ctypes.sizeof(_lib.PeParams) == 12 * 4
     assert ctypes.sizeof(_lib.PeGruLayer) == 8 + 3 * ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(_lib.PeInfo) == 9 * 4 + 4 + 8
 

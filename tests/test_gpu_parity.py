@@ -422,9 +422,13 @@ def test_device_threshold_decoder_and_trigger(stock_weights):
         eng = HipEngine(P.pr, stock_weights, n_streams=grid.size)
         eng.set_decoder(dec)
         got = eng.decode(grid)
-        want = np.array([dec.decode(float(v)) for v in grid])
-        assert np.abs(got - want).max() <= TOL_DECODE, name
-        assert np.mean(got == want) > 0.9, name
+        # index work: the device must land in the SAME table bin as the reference's own decode of the float32
+        # scalar (fixture decode32_*, produced by /root/reference/precise/threshold_decoder.py); the only licence
+        # is a last-bit difference of log() exactly at a bin edge, and each such grid point is listed
+        want = g['decode32_' + name]
+        assert np.array_equal(want, dec.decode_many(grid))                 # host mirror == reference, bit for bit
+        edge = [(float(v), float(a), float(b)) for v, a, b in zip(grid, got, want) if a != b]
+        assert edge == [], (name, 'device decoder left the reference bin at', edge)
         eng.close()
     # streaming: decode + trigger on the device == host decode + host TriggerDetector per stream
     n, n_up = 40, 60
@@ -603,6 +607,140 @@ def test_bf16_network_other_widths(units):
     eng.close()
 
 
+# ---- legacy speechpy vectorizer (vectorization.py:40-42; what old .params files select, params.py:147,155) ---------
+def _write_model(tmp_path, weights, params=None, name='legacy.npz'):
+    import json
+    from mycroft_precise_amd.model import save_weights
+    path = str(tmp_path / name)
+    save_weights(path, weights)
+    if params is not None:
+        with open(path + '.params', 'w') as f:
+            json.dump(params, f)
+    return path
+
+
+LEGACY_PARAMS = dict(window_t=0.1, hop_t=0.05, buffer_t=1.5, sample_rate=16000, sample_depth=2, n_mfcc=13, n_filt=20,
+                     n_fft=512)          # an old file: no `vectorizer`, no `use_delta`, no threshold keys
+
+
+def test_legacy_params_file_selects_speechpy_and_matches_reference(tmp_path, stock_weights):
+    """Listener on a model whose .params lacks the `vectorizer` key: the reference falls back to the speechpy
+    front end; fixture = the reference's own Listener on that setting (oracle/gen_golden.py: gen_speechpy)."""
+    from mycroft_precise_amd.network_runner import Listener
+    from mycroft_precise_amd import vectorization as V
+    g = golden('speechpy.npz')
+    saved = dict(P.pr.__dict__)
+    try:
+        path = _write_model(tmp_path, stock_weights, LEGACY_PARAMS)
+        for i in range(len(g['kinds'])):
+            lis = Listener(path, 2048)
+            assert lis.pr.vectorizer == P.Vectorizer.speechpy_mfccs
+            data = g['pcm'][i].tobytes()
+            worst = 0.0
+            for u, off in enumerate(range(0, len(data), 2048)):
+                raw = lis.update_raw(data[off:off + 2048])
+                worst = max(worst, abs(raw - float(g['raw'][i][u])))
+                assert len(lis.window_audio) == g['leftover'][i][u]
+                if u == 7:
+                    assert np.abs(lis.mfccs - g['ring_u7'][i]).max() <= TOL_FEAT32
+            assert np.abs(lis.mfccs - g['ring_last'][i]).max() <= TOL_FEAT32
+            assert worst <= GUARD_RAW, (str(g['kinds'][i]), worst)
+        data = g['odd_pcm'].tobytes()
+        for cb in (1000, 3200, 6400, 96000):
+            lis = Listener(path, cb)
+            raws = [lis.update_raw(data[off:off + cb]) for off in range(0, len(data) - cb + 1, cb)]
+            assert np.abs(np.array(raws) - g['odd_raw_%d' % cb]).max() <= GUARD_RAW, cb
+            assert np.abs(lis.mfccs - g['odd_ring_last_%d' % cb]).max() <= TOL_FEAT32
+            assert len(lis.window_audio) == g['odd_leftover_%d' % cb][-1]
+        # the vectorizers dict entry and vectorize / vectorize_raw under that setting, float64 end to end
+        for name in ('short', 'exact', 'long', 'one_window', 'window_plus_hop', 'zeros'):
+            raw = V.vectorize_raw(g['audio_' + name])
+            assert raw.shape == g['raw_' + name].shape, name
+            if raw.size:
+                assert np.abs(raw - g['raw_' + name]).max() <= 1e-9, name
+        for name in ('short', 'exact', 'long'):
+            assert np.abs(V.vectorize(g['audio_' + name]) - g['vec_' + name]).max() <= 1e-9, name
+        assert np.abs(V.vectorizers[P.Vectorizer.speechpy_mfccs](g['audio_long']) - g['raw_long']).max() <= 1e-9
+    finally:
+        P.pr.__dict__.clear(); P.pr.__dict__.update(saved)
+
+
+def test_speechpy_batched_streams_match_oracle(stock_weights):
+    """The same front end for B lock-step streams (fused and two-launch, pe_update_many), vs the oracle."""
+    from mycroft_precise_amd.network_runner import BatchedListener
+    snap = P.pr.copy()
+    snap.__dict__['vectorizer'] = P.Vectorizer.speechpy_mfccs
+    kinds = (['tone_noise'] * 30) + ['zeros', 'square', 'square', 'quiet', 'quiet', 'zeros', 'tone_noise']
+    n_up = 40
+    pcm = _stream_batch(kinds, n_up)
+    hip = BatchedListener(stock_weights, len(kinds), params=snap)
+    two = BatchedListener(stock_weights, len(kinds), params=snap)
+    two.engine.set_fused(False)
+    many = BatchedListener(stock_weights, len(kinds), params=snap)
+    many.engine.reserve_updates(8, 1024)
+    ref = ol.BatchedOracle(stock_weights, len(kinds), ol.Params(vectorizer=3))
+    outs = []
+    for u in range(n_up):
+        raw = hip.update_raw(pcm[u])
+        want = ref.update_raw(pcm[u])
+        assert np.abs(raw.astype(np.float64) - want).max() <= GUARD_RAW, u
+        assert np.array_equal(raw, two.update_raw(pcm[u])), u
+        assert np.abs(hip.engine.get_vectors().astype(np.float64) - ref.mfccs).max() <= TOL_FEAT32, u
+        outs.append(raw)
+    for u in range(0, n_up, 8):
+        assert np.array_equal(many.engine.update_many(pcm[u:u + 8]), np.stack(outs[u:u + 8])), u
+    q, kc, ke = hip.engine.stream_state()
+    assert np.all(q + 800 * (kc - ke).astype(np.int64) == ref.window_audio.shape[1])
+
+
+# ---- arbitrary float samples into Listener.update (network_runner.py:126-127) --------------------------------------
+def test_listener_accepts_any_float_ndarray_audio(model_file):
+    """load_audio-style k/32767 samples and a mixed / rescaled float64 signal, fed as ndarrays the way
+    scripts/train_incremental.py does; fixture = the reference's own Listener on the same arrays."""
+    from mycroft_precise_amd.network_runner import Listener
+    g = golden('listener_float_audio.npz')
+    for name in ('div32767', 'mixed64'):
+        audio = g['audio_' + name]
+        lis = Listener(model_file, 2048)
+        raws = [lis.update_raw(audio[off:off + 1024]) for off in range(0, len(audio) - 1023, 1024)]
+        assert np.abs(np.array(raws) - g['raw_' + name]).max() <= GUARD_RAW, name
+        assert np.abs(lis.mfccs - g['ring_last_' + name]).max() <= 1e-9, name      # float64 path end to end
+        assert len(lis.window_audio) == int(g['leftover_' + name])
+    # a stream that starts as PCM bytes (device-resident state) and continues with float samples
+    lis = Listener(model_file, 2048)
+    pcm, audio = g['pcm'], g['pcm'].astype(np.float32) / np.float32(32767.0)
+    raws = []
+    for u in range(30):
+        raws.append(lis.update_raw(pcm[u * 1024:(u + 1) * 1024].tobytes() if u < 12 else audio[u * 1024:(u + 1) * 1024]))
+    assert np.abs(np.array(raws) - g['raw_bytes_then_float']).max() <= GUARD_RAW
+    # exact k/32768 floats (buffer_to_audio output) stay on the int16 device path; an empty ndarray appends nothing
+    lis2 = Listener(model_file, 2048)
+    a = lis2.update_raw(pcm[:1024].astype(np.float32) / np.float32(32768.0))
+    lis3 = Listener(model_file, 2048)
+    assert a == lis3.update_raw(pcm[:1024].tobytes()) and not lis2._float_mode
+    assert lis3.update_raw(np.array([], dtype=np.float32)) == a
+
+
+def test_listener_runner_can_be_replaced_after_construction(model_file, stock_weights):
+    """scripts/train_incremental.py:87-88 assigns ``listener.runner`` on a live Listener: predictions must come
+    from the new runner, the stream state (leftover audio + feature window) stays."""
+    from mycroft_precise_amd.network_runner import Listener, HipRunner
+    other = synth.make_weights(seed=77)
+    pcm = synth.stream_pcm(3, 40 * 1024)
+    a = Listener(model_file, 2048)                                     # stock weights, then swapped at update 17
+    want_stock, want_other = ol.OracleListener(stock_weights), ol.OracleListener(other)
+    for u in range(40):
+        chunk = pcm[u * 1024:(u + 1) * 1024].tobytes()
+        if u == 17:
+            a.runner = HipRunner(weights=other)
+        if u == 29:
+            a.runner = keras_gru.make_runner_cls(stock_weights)('x')   # a foreign runner: MFCC stays on the GPU
+        got = a.update_raw(chunk)
+        ws, wo = want_stock.update_raw(chunk), want_other.update_raw(chunk)
+        assert abs(got - (wo if 17 <= u < 29 else ws)) <= GUARD_RAW, u
+    assert np.abs(a.mfccs - want_stock.mfccs).max() <= TOL_FEAT32
+
+
 # ---- full-size properties (BASELINE configs[1]: 4096 streams on one GPU) ----------------------------
 def test_full_batch_4096_streams_properties(stock_weights):
     from mycroft_precise_amd.network_runner import BatchedListener
@@ -630,6 +768,105 @@ def test_full_batch_4096_streams_properties(stock_weights):
         assert np.array_equal(hip.update_raw(base[u][owner]), first_pass[u]), u
     info = hip.engine.info()
     assert info.n_streams == B and info.ring_slots == 32 and info.device_bytes > B * 2048
+
+
+def _full_size_run(weights, B, n_up, n_check, tol, guard_equal_positions=True, **listener_kw):
+    """Size-independent properties at a BASELINE batch size: every stream is a copy of one of n_check seeded
+    streams (shuffled), so (a) the seeded ones are checked against the oracle, (b) identical input must give
+    bit-identical output wherever it sits in the batch, (c) clear + replay is bit-identical."""
+    from mycroft_precise_amd.network_runner import BatchedListener
+    rng = np.random.default_rng(B + n_check)
+    base = synth.batch_pcm(n_check, n_up)
+    owner = rng.integers(0, n_check, B)
+    owner[:n_check] = np.arange(n_check)
+    hip = BatchedListener(weights, B, **listener_kw)
+    ref = ol.BatchedOracle(weights, n_check)
+    first, worst = [], 0.0
+    for u in range(n_up):
+        raw = hip.update_raw(base[u][owner])
+        want = ref.update_raw(base[u])
+        assert raw.shape == (B,) and np.all(np.isfinite(raw))
+        worst = max(worst, float(np.abs(raw[:n_check] - want).max()))
+        assert np.array_equal(raw, raw[:n_check][owner]), u
+        first.append(raw)
+    assert worst <= tol, worst
+    hip.clear()
+    for u in range(n_up):
+        assert np.array_equal(hip.update_raw(base[u][owner]), first[u]), u
+    return hip, base, owner, first
+
+
+def test_full_batch_wide_gru_4096_streams_properties():
+    """BASELINE configs[3]: 256 x 2 layers at 4096 streams = 256 workgroups sharing one L2-resident weight
+    stream -- where a stale read or an ordering slip between workgroups would show."""
+    w = synth.make_weights(units=(256, 256), seed=5)
+    hip, base, owner, first = _full_size_run(w, 4096, 31, 16, GUARD_RAW)
+    # Runner.predict on the windows the streams hold now == the streaming output, bit for bit
+    feats = hip.engine.get_vectors()
+    assert np.array_equal(hip.engine.predict(feats)[:, 0], first[-1])
+
+
+@pytest.mark.parametrize('B', [8192, 65536])
+def test_full_batch_bf16_properties(stock_weights, B):
+    """BASELINE configs[4] per-GPU shapes: 8192 and 65536 streams, bf16 network + float32 front end; the
+    launch policy differs between the two (tiles <= / > compute units)."""
+    hip, base, owner, first = _full_size_run(stock_weights, B, 32, 24, TOL_BF16, mfcc_precision='f32', gru_precision='bf16')
+    # both launch shapes of the network agree bit for bit at this size too
+    hip.engine.set_fused(False)
+    hip.clear()
+    for u in range(8):
+        assert np.array_equal(hip.update_raw(base[u][owner]), first[u]), u
+
+
+def test_full_batch_update_many_4096_streams_x8(stock_weights):
+    """pe_update_many at the bench's shape (4096 streams x 8 updates per call) == single updates, bit for bit."""
+    from mycroft_precise_amd._lib import HipEngine
+    B, depth, n_check = 4096, 8, 32
+    rng = np.random.default_rng(99)
+    base = synth.batch_pcm(n_check, 5 * depth)
+    owner = rng.integers(0, n_check, B)
+    owner[:n_check] = np.arange(n_check)
+    a = HipEngine(P.pr, stock_weights, n_streams=B)
+    b = HipEngine(P.pr, stock_weights, n_streams=B)
+    b.reserve_updates(depth, 1024)
+    ref = ol.BatchedOracle(stock_weights, n_check)
+    for r in range(5):
+        pcm = np.ascontiguousarray(base[r * depth:(r + 1) * depth][:, owner])
+        want = np.stack([a.update(pcm[i]) for i in range(depth)])
+        got = b.update_many(pcm)
+        assert np.array_equal(got, want), r
+        for i in range(depth):
+            assert np.abs(got[i][:n_check] - ref.update_raw(base[r * depth + i])).max() <= GUARD_RAW
+    for x, y in zip(a.stream_state(), b.stream_state()):
+        assert np.array_equal(x, y)
+    a.close(); b.close()
+
+
+def test_bench_two_ranks_on_one_gpu_shards_streams_correctly():
+    """bench.py --gpus 2 under torch.distributed.run with both ranks on cuda:0 (PE_BENCH_SHARED_GPU=1, gloo): the
+    N > 1 control flow with the REAL engine -- global stream count, rank-ordered gather, and rank 1's
+    probabilities equal to a single-rank run over streams 512..1023."""
+    import json
+    env = dict(os.environ, PE_BENCH_SHARED_GPU='1', PE_BENCH_DUMP=os.path.join(REPO, 'gpurun_out', 'bench2_probs.npy'),
+               PYTHONPATH=REPO + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
+    common = ['--steps', '6', '--warmup', '30', '--streams', '512', '--no-cpu-baseline']
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', '29517', os.path.join(REPO, 'bench.py'),
+                          '--gpus', '2'] + common, env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['global_streams'] == 1024 and line['scaling'] == 'weak'
+    assert line['outputs_finite'] and line['value'] > 0
+    both = np.load(env['PE_BENCH_DUMP'])                     # [steps, 1024] gathered on rank 0
+    assert both.shape == (6, 1024)
+    env1 = dict(env, PE_BENCH_DUMP=os.path.join(REPO, 'gpurun_out', 'bench1_probs.npy'), PE_BENCH_FIRST_STREAM='512')
+    one = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1'] + common, env=env1, cwd=REPO,
+                         capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    solo = np.load(env1['PE_BENCH_DUMP'])
+    assert solo.shape == (6, 512) and np.array_equal(both[:, 512:], solo)
+    assert not np.array_equal(both[:, :512], both[:, 512:])          # the two shards really are different streams
 
 
 # ---- BASELINE configs[0]: one stream through the engine executable (plumbing) ------------------------

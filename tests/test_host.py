@@ -89,6 +89,8 @@ def test_threshold_decoder_matches_reference(name):
     dec = np.array([d.decode(float(v)) for v in g['grid']])
     assert np.array_equal(dec, g['decode_' + name])
     assert np.array_equal(d.decode_many(g['grid']), g['decode_' + name])
+    # float32 scalars (what the runners return and what pe_decode takes): the reference's float32 `1 / x - 1`
+    assert np.array_equal(d.decode_many(g['grid'].astype(np.float32)), g['decode32_' + name])
     with warnings.catch_warnings():
         warnings.simplefilter('ignore', RuntimeWarning)
         enc = np.array([d.encode(float(v)) for v in g['thr']])
@@ -100,16 +102,21 @@ def test_add_deltas_matches_reference():
     assert np.array_equal(V.add_deltas(g['raw_feats_8000']), g['deltas_8000'])
 
 
+def test_speechpy_filterbank_table_equals_oracle():
+    from oracle import speechpy_restated as sp
+    assert np.array_equal(V.speechpy_filterbank(16000, 20, 257), sp.filterbanks(20, 257, 16000, 0, None))
+    assert np.array_equal(V.speechpy_filterbank(16000, 40, 257), sp.filterbanks(40, 257, 16000, 0, None))
+    assert int((V.speechpy_filterbank(16000, 20, 257) != 0).sum(0).max()) <= 2
+
+
 def test_mel_filterbank_table_equals_oracle():
     assert np.array_equal(V.mel_filterbank(16000, 20, 257), so.filterbanks(16000, 20, 257))
     assert np.array_equal(V.mel_filterbank(8000, 26, 257), so.filterbanks(8000, 26, 257))
 
 
-def test_vectorize_raw_rejects_empty_audio_and_unsupported_vectorizers():
+def test_vectorize_raw_rejects_empty_audio_and_serves_every_vectorizer():
     with pytest.raises(util.InvalidAudio):
         V.vectorize_raw(np.array([]))
-    with pytest.raises(NotImplementedError):
-        V.vectorizers[P.Vectorizer.speechpy_mfccs](np.zeros(2000))
     assert set(V.vectorizers) == {P.Vectorizer.mels, P.Vectorizer.mfccs, P.Vectorizer.speechpy_mfccs}
 
 

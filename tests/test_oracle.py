@@ -43,7 +43,7 @@ def test_listener_stream_chunk2048(stock_weights):
         data = g['pcm'][i].tobytes()
         raws, decs = [], []
         for u, off in enumerate(range(0, len(data), 2048)):
-            raw = lis.update_raw(data[off:off + 2048])
+            raw = lis.update_raw32(data[off:off + 2048])
             raws.append(raw)
             decs.append(lis.threshold_decoder.decode(raw))
             assert len(lis.window_audio) == g['leftover'][i][u]
@@ -61,7 +61,7 @@ def test_listener_odd_chunk_sizes(stock_weights, cb):
     lis = ol.OracleListener(stock_weights)
     raws, decs, left = [], [], []
     for off in range(0, len(data) - cb + 1, cb):
-        raws.append(lis.update_raw(data[off:off + cb]))
+        raws.append(lis.update_raw32(data[off:off + cb]))
         decs.append(lis.threshold_decoder.decode(raws[-1]))
         left.append(len(lis.window_audio))
     assert np.array_equal(np.array(raws, dtype=np.float32), g['raw_%d' % cb])
@@ -109,6 +109,9 @@ def test_threshold_decoder(name):
     assert d.min_out == int(g['min_out_' + name]) and d.out_range == int(g['out_range_' + name])
     dec = np.array([d.decode(float(v)) for v in g['grid']])
     assert np.array_equal(dec, g['decode_' + name])
+    # the scalar type the runners return (numpy float32): `1 / x - 1` is then float32 arithmetic
+    dec32 = np.array([d.decode(v) for v in g['grid'].astype(np.float32)])
+    assert np.array_equal(dec32, g['decode32_' + name])
     with warnings.catch_warnings():
         warnings.simplefilter('ignore', RuntimeWarning)
         enc = np.array([d.encode(float(v)) for v in g['thr']])
@@ -146,3 +149,80 @@ def test_frame_crop_quirk_q2():
     b[512:800] = 7.0          # inside window 0, beyond the crop, before window 1
     b[800 + 512:1600] = -3.0
     assert np.array_equal(so.mfcc_spec(a, 16000, (1600, 800)), so.mfcc_spec(b, 16000, (1600, 800)))
+
+
+# ---- legacy speechpy vectorizer (vectorization.py:40-42; params.py:147,155) ---------------------------------------
+def test_speechpy_vectorize_matches_reference_dispatch():
+    g = golden('speechpy.npz')
+    pr = ol.Params(vectorizer=3)
+    for name in ('short', 'exact', 'long', 'one_window', 'window_plus_hop'):
+        assert np.array_equal(ol.vectorize_raw(g['audio_' + name], pr), g['raw_' + name]), name
+        assert np.array_equal(ol.vectorize(g['audio_' + name], pr), g['vec_' + name]), name
+    assert g['raw_one_window'].shape == (0, 13)           # S1: exactly one window yields no frame
+    assert g['raw_window_plus_hop'].shape == (1, 13)
+    assert np.array_equal(ol.vectorize_raw(g['audio_zeros'], pr), g['raw_zeros'])
+
+
+def test_speechpy_listener_streams(stock_weights):
+    g = golden('speechpy.npz')
+    pr = ol.Params(vectorizer=3)
+    for i in range(len(g['kinds'])):
+        lis = ol.OracleListener(stock_weights, pr)
+        data = g['pcm'][i].tobytes()
+        raws, decs = [], []
+        for u, off in enumerate(range(0, len(data), 2048)):
+            raws.append(lis.update_raw32(data[off:off + 2048]))
+            decs.append(lis.threshold_decoder.decode(raws[-1]))
+            assert len(lis.window_audio) == g['leftover'][i][u]
+            if u == 7:
+                assert np.array_equal(lis.mfccs, g['ring_u7'][i])
+        assert np.array_equal(lis.mfccs, g['ring_last'][i])
+        assert np.array_equal(np.array(raws, dtype=np.float32), g['raw'][i])
+        assert np.array_equal(np.array(decs), g['decoded'][i])
+    data = g['odd_pcm'].tobytes()
+    for cb in (1000, 3200, 6400, 96000):
+        lis = ol.OracleListener(stock_weights, pr)
+        raws, left = [], []
+        for off in range(0, len(data) - cb + 1, cb):
+            raws.append(lis.update_raw32(data[off:off + cb]))
+            left.append(len(lis.window_audio))
+        assert np.array_equal(np.array(raws, dtype=np.float32), g['odd_raw_%d' % cb])
+        assert np.array_equal(lis.mfccs, g['odd_ring_last_%d' % cb])
+        assert np.array_equal(np.array(left), g['odd_leftover_%d' % cb])
+
+
+def test_speechpy_batched_oracle_equals_single_stream(stock_weights):
+    pr = ol.Params(vectorizer=3)
+    n_up = 36
+    pcm = synth.batch_pcm(3, n_up)
+    bo = ol.BatchedOracle(stock_weights, 3, pr)
+    singles = [ol.OracleListener(stock_weights, pr) for _ in range(3)]
+    for u in range(n_up):
+        raw_b = bo.update_raw(pcm[u])
+        for j, lis in enumerate(singles):
+            assert abs(lis.update_raw(pcm[u, j].tobytes()) - raw_b[j]) < 2e-6
+            assert np.allclose(lis.mfccs, bo.mfccs[j], rtol=0, atol=1e-10)
+
+
+# ---- arbitrary float samples into Listener.update (network_runner.py:126-127) --------------------------------------
+def test_listener_float_ndarray_audio(stock_weights):
+    g = golden('listener_float_audio.npz')
+    for name in ('div32767', 'mixed64'):
+        audio = g['audio_' + name]
+        lis = ol.OracleListener(stock_weights)
+        raws = [lis.update_raw32(audio[off:off + 1024]) for off in range(0, len(audio) - 1023, 1024)]
+        assert np.array_equal(np.array(raws, dtype=np.float32), g['raw_' + name])
+        assert np.array_equal(lis.mfccs, g['ring_last_' + name])
+        assert len(lis.window_audio) == int(g['leftover_' + name])
+
+
+def test_golden_fixtures_carry_their_provenance(capsys):
+    """Every fixture says which third-party arithmetic produced it (real package or restatement)."""
+    import os
+    from conftest import GOLDEN
+    for f in sorted(os.listdir(GOLDEN)):
+        g = golden(f)
+        prov = [str(x) for x in g['provenance']]
+        assert any(p.startswith('sonopy:') for p in prov) and any(p.startswith('keras:') for p in prov), f
+        assert any(p.startswith('glue: reference code, unmodified') for p in prov), f
+        print(f, '|', '; '.join(p for p in prov if not p.startswith('glue')))
