@@ -73,9 +73,10 @@ def _affinity_cores():
 
 def _cpu_worker(args):
     """One host core's share of the cpu_baseline: the numpy oracle ("port") on its own slice of streams.
-    Import, weights and PCM synthesis happen BEFORE the start barrier; only the arithmetic is timed, and the
-    worker returns its own compute time."""
-    first, n_streams, n_updates, n_distinct, seed, barrier = args
+    Import, weights and PCM synthesis happen BEFORE the start barrier; only the arithmetic is timed.  The loop
+    runs until `seconds` have passed (so the sample is bounded whatever the loaded per-core rate turns out to
+    be); returns (updates done, own compute time)."""
+    first, n_streams, seconds, n_distinct, seed, barrier = args
     from oracle import listener as oracle_listener          # checker / baseline only
     try:
         from threadpoolctl import threadpool_limits
@@ -90,51 +91,59 @@ def _cpu_worker(args):
         oracle.update_raw(pcm[u % n_distinct])               # updates of a 1024-stream batch run 10-20x slower), untimed
     if barrier is not None:
         barrier.wait()
-    t0 = time.perf_counter()
-    for u in range(n_updates):
-        oracle.update_raw(pcm[(u + 5) % n_distinct])
-    return time.perf_counter() - t0
+    n, t0 = 0, time.perf_counter()
+    while True:
+        oracle.update_raw(pcm[(n + 5) % n_distinct])
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            return n, dt
 
 
-def cpu_baseline(target_seconds=8.0, streams_per_core=1024):
-    """Oracle ("port" of the reference's sonopy + Keras arithmetic, vectorised over streams) on every host core,
-    on a bounded sample of the same workload: every core steps `streams_per_core` streams through `n_updates`
-    updates.  All workers start their timed loops together (barrier after fork / import / synthesis); value =
-    windows / the longest worker's compute time."""
+def _cpu_round(cores, streams_per_core, seconds):
     import multiprocessing as mp
-    cores = _affinity_cores()
-    n_distinct = 8
-    n_probe = 8
-    probe = _cpu_worker((0, streams_per_core, n_probe, n_distinct, 42, None))    # one core alone: calibration
-    per_update = probe / n_probe
-    # with every core busy the per-core rate drops (shared memory bandwidth, clocks): size for the target anyway
-    n_updates = int(max(8, min(2000, round(target_seconds / per_update))))
     ctx = mp.get_context('fork')
     barrier = ctx.Barrier(cores)
-    t0 = time.perf_counter()
     procs, results = [], ctx.Queue()
 
     def run(job):
         results.put(_cpu_worker(job))
 
+    t0 = time.perf_counter()
     for c in range(cores):
-        pr_ = ctx.Process(target=run, args=((c * streams_per_core, streams_per_core, n_updates, n_distinct, 42, barrier),))
+        pr_ = ctx.Process(target=run, args=((c * streams_per_core, streams_per_core, seconds, 8, 42, barrier),))
         pr_.start()
         procs.append(pr_)
-    times = [results.get() for _ in procs]
+    done = [results.get() for _ in procs]
     for pr_ in procs:
         pr_.join()
     wall = time.perf_counter() - t0
-    windows = cores * streams_per_core * n_updates
-    compute = max(times)
-    single = streams_per_core * n_probe / probe
-    return {'value': windows / compute, 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
-            'compute_s': compute, 'wall_s': wall, 'per_core': windows / compute / cores,
-            'single_core_alone': single,
-            'sample': '%d cores x %d streams x %d updates of %d samples (%d windows); numpy oracle (float64 MFCC + '
-                      'float32 GRU), one process per core, timed loops start together after fork/import/synthesis; '
-                      'compute %.1f s (slowest worker), wall incl. set-up %.1f s; one core alone: %.0f windows/s'
-                      % (cores, streams_per_core, n_updates, CHUNK, windows, compute, wall, single)}
+    windows = sum(n for n, _ in done) * streams_per_core
+    compute = max(dt for _, dt in done)
+    return {'streams_per_core': streams_per_core, 'windows': windows, 'compute_s': compute, 'wall_s': wall,
+            'value': windows / compute}
+
+
+def cpu_baseline(seconds=6.0):
+    """Oracle ("port" of the reference's sonopy + Keras arithmetic, vectorised over streams) on every host core,
+    on a bounded sample of the same workload.  All workers start their timed loops together (barrier after fork /
+    import / synthesis) and run for `seconds`; rate = windows of all workers / the longest worker's compute time.
+    Two batch shapes per core are timed -- 1024 streams (the GPU's own regime; on a many-core host its float64
+    temporaries fall out of cache and the cores queue on memory) and 128 streams (cache-resident) -- and the
+    FASTER one is reported as the baseline."""
+    cores = _affinity_cores()
+    n_alone, t_alone = _cpu_worker((0, 1024, 1.0, 8, 42, None))                 # one core, nothing else running
+    rounds = [_cpu_round(cores, spc, seconds) for spc in (1024, 128)]
+    best = max(rounds, key=lambda r: r['value'])
+    return {'value': best['value'], 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
+            'compute_s': best['compute_s'], 'wall_s': sum(r['wall_s'] for r in rounds),
+            'per_core': best['value'] / cores, 'single_core_alone': 1024 * n_alone / t_alone,
+            'rounds': rounds,
+            'sample': 'numpy oracle (float64 MFCC + float32 GRU), one process per core on %d cores, timed loops start '
+                      'together after fork/import/synthesis and run %.0f s; %s; one core alone at 1024 streams: %.0f windows/s'
+                      % (cores, seconds, '; '.join('%d streams/core: %d windows in %.1f s = %.0f windows/s'
+                                                    % (r['streams_per_core'], r['windows'], r['compute_s'], r['value']) for r in rounds),
+                         1024 * n_alone / t_alone)}
 
 
 def cpu_baseline_single_stream(seconds=3.0):

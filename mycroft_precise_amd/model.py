@@ -10,8 +10,9 @@ so this module defines the weights as plain arrays in Keras layout:
     {'gru': [(kernel[F,3H], recurrent_kernel[H,3H], bias[3H]), ...],   gate order z | r | h
      'dense_kernel': [H,1], 'dense_bias': [1]}
 
-stored as ``<model>.npz`` next to the usual ``<model>.npz.params`` JSON, or read straight from the
-reference's frozen-graph ``<model>.pb`` (``pb_model.py``: a protobuf wire reader, no TensorFlow).
+stored as ``<model>.npz`` next to the usual ``<model>.npz.params`` JSON, read straight from the
+reference's frozen-graph ``<model>.pb`` (``pb_model.py``: a protobuf wire reader, no TensorFlow), or -- for a
+Keras ``<model>.net`` -- from the side-car ``<model>.net.npz`` that ``tools/export_net_to_npz.py`` writes.
 """
 import numpy as np
 
@@ -49,9 +50,14 @@ def load_weights(model_name: str) -> dict:
         from .pb_model import weights_from_pb
         return weights_from_pb(model_name)
     if model_name.endswith('.net'):
-        raise NotImplementedError(
-            'importing %s needs an HDF5 reader (no h5py on the target); freeze it with precise-convert '
-            'to .pb, or export the arrays to .npz (mycroft_precise_amd.model.save_weights)' % model_name)
+        # Keras HDF5: the engine has no HDF5 reader and the GPU box no h5py; the weights travel as the side-car
+        # that tools/export_net_to_npz.py writes next to the file (run where h5py exists)
+        from os.path import isfile
+        if not isfile(model_name + '.npz'):
+            raise NotImplementedError(
+                'importing %s needs its exported weights %s.npz: run `python tools/export_net_to_npz.py %s` on a '
+                'machine with h5py, or freeze the model with precise-convert to .pb' % (model_name, model_name, model_name))
+        model_name = model_name + '.npz'
     with np.load(model_name, allow_pickle=False) as z:
         n = int(z['n_layers'])
         layers = [(z['kernel_%d' % i], z['recurrent_kernel_%d' % i], z['bias_%d' % i]) for i in range(n)]

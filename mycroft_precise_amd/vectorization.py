@@ -5,10 +5,17 @@ plug-in seam for the front end; all three entries (``mfccs``, ``mels``, and the 
 old ``.params`` files select) are served by the HIP kernels (stateless whole-buffer form, ``pe_vectorize_raw`` /
 ``pe_vectorize_mels``).  There is no CPU implementation here.
 """
+import warnings
+
 import numpy as np
 
 from .params import pr, Vectorizer
 from .util import InvalidAudio
+
+
+class UnverifiedFilterbank(UserWarning):
+    """The requested (n_filt, n_fft) makes mel grid points collide: a case the restated sonopy algorithm could not
+    be checked on (see ``mel_filterbank``)."""
 
 
 def mel_filterbank(sample_rate: int, num_filt: int, n_bins: int) -> np.ndarray:
@@ -24,6 +31,14 @@ def mel_filterbank(sample_rate: int, num_filt: int, n_bins: int) -> np.ndarray:
     mels = np.linspace(0.0, top, num_filt + 2, True)
     hz = 700.0 * (np.exp(mels / 1127.0) - 1.0)
     raw = (hz * n_bins / sample_rate).astype(int).tolist()
+    if len(set(raw)) != len(raw):
+        # Colliding grid points (e.g. n_filt = 40 at n_fft = 512) are where the two recollections of sonopy 0.1.2
+        # differ: its ``correct_grid`` is written to push duplicates forward -- what is built below -- but it may
+        # receive an ndarray, for which ``[x[0] - 1] + x`` broadcasts and the correction never fires.  The stock
+        # 20 filters have no collision and are unaffected; anything else is served but flagged.
+        warnings.warn('mel grid of %d filters over %d bins has repeated points: the filterbank for this '
+                      'setting is UNVERIFIED against sonopy 0.1.2 (its duplicate handling could not be '
+                      'checked)' % (num_filt, n_bins), UnverifiedFilterbank, stacklevel=2)
     pts, shift, last = [], 0, raw[0] - 1
     for v in raw:
         shift = max(0, shift + last + 1 - v)

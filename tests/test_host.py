@@ -110,8 +110,11 @@ def test_speechpy_filterbank_table_equals_oracle():
 
 
 def test_mel_filterbank_table_equals_oracle():
-    assert np.array_equal(V.mel_filterbank(16000, 20, 257), so.filterbanks(16000, 20, 257))
-    assert np.array_equal(V.mel_filterbank(8000, 26, 257), so.filterbanks(8000, 26, 257))
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                       # the stock grid has no colliding points: no flag
+        assert np.array_equal(V.mel_filterbank(16000, 20, 257), so.filterbanks(16000, 20, 257))
+    with pytest.warns(V.UnverifiedFilterbank):               # 40 filters over 257 bins: low grid points collide
+        assert np.array_equal(V.mel_filterbank(16000, 40, 257), so.filterbanks(16000, 40, 257))
 
 
 def test_vectorize_raw_rejects_empty_audio_and_serves_every_vectorizer():
@@ -311,8 +314,66 @@ def test_pb_roundtrip_and_load_weights(tmp_path, stock_weights):
     save_weights(npz, stock_weights)
     w2 = load_weights(npz)
     assert np.array_equal(w2['gru'][0][1], stock_weights['gru'][0][1])
-    with pytest.raises(NotImplementedError):
+    # Keras .net: refused (no HDF5 reader) unless the exporter's side-car sits next to it
+    with pytest.raises(NotImplementedError) as ei:
         load_weights(str(tmp_path / 'model.net'))
+    assert 'export_net_to_npz.py' in str(ei.value)
+    save_weights(str(tmp_path / 'model.net.npz'), stock_weights)
+    w3 = load_weights(str(tmp_path / 'model.net'))
+    assert np.array_equal(w3['gru'][0][0], stock_weights['gru'][0][0])
+
+
+@pytest.mark.parametrize('packed', [True, False])
+def test_pb_reader_against_an_independent_protobuf_encoder(tmp_path, packed, stock_weights):
+    """GraphDef files serialised by google.protobuf itself from TensorFlow's public field numbers (tests/
+    tf_graphdef.py) -- not by pb_model's own writer: tensor_content, packed and one-tag-per-element float_val,
+    splat constants, 'import/' prefixes, foreign nodes and attributes, map entries in any order."""
+    pytest.importorskip('google.protobuf')
+    from mycroft_precise_amd import pb_model as pm
+    from tf_graphdef import graphdef_classes, add_const, DT_FLOAT, DT_INT32
+    G = graphdef_classes(packed_floats=packed)
+    (k, rk, b), = stock_weights['gru']
+    for prefix, encodings in (('', ('content', 'float_val', 'content')), ('import/', ('float_val', 'content', 'splat'))):
+        graph = G.GraphDef()
+        graph.versions.producer = 27
+        ph = graph.node.add(); ph.name, ph.op = prefix + 'net_input', 'Placeholder'
+        ph.attr['dtype'].type = DT_FLOAT
+        ph.attr['shape'].shape.dim.add().size = -1
+        bias = np.full_like(b, 0.125) if encodings[2] == 'splat' else b
+        add_const(G, graph, 'net/kernel', k, encodings[0], prefix)
+        it = graph.node.add(); it.name, it.op = prefix + 'net/while/maximum_iterations', 'Const'     # an int tensor in between
+        it.attr['dtype'].type = DT_INT32
+        it.attr['value'].tensor.dtype = DT_INT32
+        it.attr['value'].tensor.int_val.append(29)
+        add_const(G, graph, 'net/recurrent_kernel', rk, encodings[1], prefix)
+        add_const(G, graph, 'net/bias', bias, encodings[2], prefix).attr['_output_shapes'].s = b'x'
+        mm = graph.node.add(); mm.name, mm.op = prefix + 'net/while/MatMul', 'MatMul'
+        mm.input.extend([prefix + 'net/while/Identity', prefix + 'net/while/MatMul/Enter'])
+        mm.attr['transpose_a'].b = False
+        mm.attr['T'].type = DT_FLOAT
+        add_const(G, graph, 'dense_3/kernel', stock_weights['dense_kernel'], 'float_val', prefix)
+        add_const(G, graph, 'dense_3/bias', stock_weights['dense_bias'], 'content', prefix)
+        out = graph.node.add(); out.name, out.op = prefix + 'net_output', 'Identity'
+        out.input.append(prefix + 'dense_3/Sigmoid')
+        path = str(tmp_path / ('tf_%d_%s.pb' % (packed, prefix.strip('/'))))
+        open(path, 'wb').write(graph.SerializeToString())
+        # google.protobuf parses its own bytes back (the file is a valid GraphDef) ...
+        assert len(G.GraphDef.FromString(open(path, 'rb').read()).node) == 9
+        # ... and the wire reader recovers exactly the arrays
+        w = pm.weights_from_pb(path)
+        (gk, grk, gb), = w['gru']
+        assert gk.dtype == np.float32 and np.array_equal(gk, k) and np.array_equal(grk, rk) and np.array_equal(gb, bias)
+        assert np.array_equal(w['dense_kernel'], stock_weights['dense_kernel'].reshape(-1, 1))
+        assert np.array_equal(w['dense_bias'], stock_weights['dense_bias'])
+    # and the other direction: pb_model's writer emits bytes google.protobuf accepts, with the same content
+    path = str(tmp_path / 'ours.pb')
+    pm.write_frozen_pb(path, stock_weights)
+    theirs = G.GraphDef.FromString(open(path, 'rb').read())
+    named = {n.name: n for n in theirs.node}
+    t = named['net/recurrent_kernel'].attr['value'].tensor
+    assert [d.size for d in t.tensor_shape.dim] == list(rk.shape) and t.dtype == DT_FLOAT
+    assert np.array_equal(np.frombuffer(t.tensor_content, '<f4').reshape(rk.shape), rk)
+    assert named['net_output'].op == 'Identity' and named['net_input'].op == 'Placeholder'
 
 
 def test_pb_reader_handles_tf_encodings(tmp_path):
