@@ -1,6 +1,6 @@
 // C ABI of libprecise_engine.so (declared in include/precise_engine.h): host-side state,
 // constant tables, weight packing and kernel sequencing for the MI355X wake-word hot path.
-// The arithmetic lives in mfcc_kernels.hip / gru_kernels.hip; nothing here computes on the CPU
+// The arithmetic lives in kernels.hip (mfcc_wave_device.h, gru_*_device.h); nothing here computes on the CPU
 // beyond building constant tables once per engine.
 #include "../../include/precise_engine.h"
 #include "pe_common.h"
@@ -40,7 +40,8 @@ struct pe_engine {
     int64_t device_bytes = 0;
     // streaming state
     int16_t* carry = nullptr;
-    int16_t* carry_alt = nullptr;            // pe_update_many writes the leftover here, then the two swap
+    int16_t* carry_alt = nullptr;            // the bookkeeping role writes the leftover here (frame tasks of the same launch
+                                             // still read the old one), then the two swap
     // per-stream counters, ping-pong: [cur] is the state now, [cur ^ 1] receives the next update's
     int32_t* st_q[2] = {nullptr, nullptr};
     uint32_t* st_kc[2] = {nullptr, nullptr};
@@ -53,10 +54,9 @@ struct pe_engine {
     // several updates per call (pe_reserve_updates / pe_update_many*)
     int max_updates = 1;
     uint32_t* ke_hist = nullptr;
-    // tables (both precisions share the int tables)
+    // constant tables of the MFCC frame kernel, laid out as they sit in LDS (mfcc_wave_tables.h)
     unsigned char* table_blob = nullptr;
-    int table_blob_bytes = 0;
-    int mel_parts = 0;                       // partial-sum slots of the mel pass (build_tables)
+    pe_wave::Layout table_layout{};
     // packed network
     float* wxd = nullptr;
     float* wx = nullptr; float* wr1 = nullptr; float* wr2 = nullptr; float* bias = nullptr; float* wd = nullptr;
@@ -141,93 +141,10 @@ int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 template <class R>
 int build_tables(pe_engine* e, const double* mel_filters) {
-    const double PI = 3.14159265358979323846;
-    const int n_filt = e->prm.n_filt, n_mfcc = e->prm.n_mfcc;
-    std::vector<cplx<R>> tw(256), w5(129);
-    for (int k1 = 0; k1 < 16; ++k1)
-        for (int r = 0; r < 16; ++r) {
-            const double ang = -2.0 * PI * (double)(r * k1) / 256.0;
-            tw[k1 * 16 + r] = {(R)std::cos(ang), (R)std::sin(ang)};
-        }
-    for (int p = 0; p <= 128; ++p) {
-        const double ang = -2.0 * PI * (double)p / 512.0;
-        w5[p] = {(R)std::cos(ang), (R)std::sin(ang)};
-    }
-    // scipy.fftpack.dct(type=2, norm='ortho') as a matrix: y[k] = s_k sum_n x[n] cos(pi k (2n+1) / (2N))
-    std::vector<R> dct((size_t)n_mfcc * n_filt);
-    for (int k = 0; k < n_mfcc; ++k) {
-        const double sk = (k == 0) ? std::sqrt(1.0 / n_filt) : std::sqrt(2.0 / n_filt);
-        for (int n = 0; n < n_filt; ++n)
-            dct[(size_t)k * n_filt + n] = (R)(sk * std::cos(PI * k * (2 * n + 1) / (2.0 * n_filt)));
-    }
-    // Mel pass tables (see mfcc_frame): lane r walks bins 16r + i, i = 0..16 (bin 256 only on lane
-    // 15); per bin the 1st / 2nd non-zero filter ("streams"); a run of equal filter ids under one
-    // stream of one lane ends in a flush to a partial-sum slot; slots are numbered filter by filter.
-    struct Run { int f, lane, stream, last_step; };
-    std::vector<Run> runs;
-    std::vector<R> mw((size_t)2 * kMelSteps * 16, R(0));
-    std::vector<int> fid((size_t)2 * kMelSteps * 16, -1);
-    for (int r = 0; r < 16; ++r)
-        for (int i = 0; i < kMelSteps; ++i) {
-            const int b = 16 * r + i;
-            if (b >= kBins || (i == 16 && r != 15)) continue;     // bin 16r+16 belongs to lane r+1
-            int cnt = 0;
-            for (int f = 0; f < n_filt; ++f) {
-                const double w = mel_filters[(size_t)f * kBins + b];
-                if (w == 0.0) continue;
-                if (cnt == 2) return fail(e, PE_ERR_UNSUPPORTED, "mel filterbank: bin %d feeds more than two filters", b);
-                mw[((size_t)cnt * kMelSteps + i) * 16 + r] = (R)w;
-                fid[((size_t)cnt * kMelSteps + i) * 16 + r] = f;
-                ++cnt;
-            }
-        }
-    for (int r = 0; r < 16; ++r)
-        for (int st = 0; st < 2; ++st) {
-            int cur = -1;
-            for (int i = 0; i <= kMelSteps; ++i) {
-                const int f = i < kMelSteps ? fid[((size_t)st * kMelSteps + i) * 16 + r] : -1;
-                if (f != cur) {
-                    if (cur >= 0) runs.push_back({cur, r, st, i - 1});
-                    cur = f;
-                }
-            }
-        }
-    std::stable_sort(runs.begin(), runs.end(), [](const Run& x, const Run& y) {
-        if (x.f != y.f) return x.f < y.f;
-        if (x.lane != y.lane) return x.lane < y.lane;
-        if (x.last_step != y.last_step) return x.last_step < y.last_step;
-        return x.stream < y.stream;
-    });
-    if ((int)runs.size() > kMaxMelParts - 1) return fail(e, PE_ERR_UNSUPPORTED, "mel filterbank needs %zu partial sums, limit %d", runs.size(), kMaxMelParts);
-    e->mel_parts = (int)runs.size();
-    std::vector<int> flush((size_t)kMelSteps * 16, (int)0xffffffff), pstart(n_filt + 1, 0);
-    for (size_t slot = 0; slot < runs.size(); ++slot) {
-        const Run& q = runs[slot];
-        int& word = flush[(size_t)q.last_step * 16 + q.lane];
-        if (q.stream == 0) word = (word & (int)0xffff0000) | (int)slot;
-        else word = (word & 0xffff) | ((int)slot << 16);
-        pstart[q.f + 1] += 1;
-    }
-    for (int f = 0; f < n_filt; ++f) pstart[f + 1] += pstart[f];
-    // pack the blob in LDS order
-    const size_t total = table_blob_bytes(sizeof(R), n_filt, n_mfcc);
-    std::vector<unsigned char> blob(total, 0);
-    size_t off = 0;
-    auto put = [&](const void* src, size_t bytes) { if (bytes) std::memcpy(blob.data() + off, src, bytes); off += bytes; };
-    put(tw.data(), 256 * sizeof(cplx<R>));
-    put(w5.data(), 129 * sizeof(cplx<R>));
-    off += sizeof(cplx<R>);                               // w512 is padded to 130 entries
-    put(dct.data(), dct.size() * sizeof(R));
-    put(mw.data(), mw.size() * sizeof(R));
-    off = (off + 15) & ~(size_t)15;
-    put(flush.data(), flush.size() * sizeof(int));
-    put(pstart.data(), pstart.size() * sizeof(int));
-    off = (off + 15) & ~(size_t)15;
-    if (off != total) return fail(e, PE_ERR_INVALID, "internal: table blob layout mismatch (%zu vs %zu)", off, total);
-    int rc;
-    if ((rc = dev_upload(e, &e->table_blob, blob))) return rc;
-    e->table_blob_bytes = (int)total;
-    return PE_OK;
+    std::vector<unsigned char> blob;
+    const std::string err = pe_wave::build<R>(mel_filters, e->prm.n_filt, e->prm.n_mfcc, blob, e->table_layout);
+    if (!err.empty()) return fail(e, PE_ERR_UNSUPPORTED, "%s", err.c_str());
+    return dev_upload(e, &e->table_blob, blob);
 }
 
 // Arrange the Keras matrices as MFMA A-operands (see the layout comment in gru_kernels.hip).
@@ -407,19 +324,23 @@ StreamGeom geom(const pe_engine* e) {
 }
 
 template <class R>
-MfccTables<R> tables(const pe_engine* e) {
-    MfccTables<R> t;
+WaveTables<R> tables(const pe_engine* e) {
+    WaveTables<R> t;
     t.blob = e->table_blob;
-    t.blob_bytes = e->table_blob_bytes;
-    t.mel_parts = e->mel_parts;
+    t.L = e->table_layout;
     return t;
+}
+
+// the most frames one stream can complete in a call of n_updates chunks (a full carry plus the new samples)
+int max_frames_per_call(const pe_engine* e, long long new_samples) {
+    const long long fmax = ((long long)(kCarryCap - 1) + new_samples - frame_len_of(e->prm)) / e->prm.hop_samples + 1;
+    return (int)(fmax < 1 ? 1 : fmax);
 }
 
 template <class R>
 MfccStreamArgs<R> mfcc_args(const pe_engine* e, const int16_t* pcm_dev, int chunk) {
     MfccStreamArgs<R> a;
     a.geo = geom(e);
-    a.tab = tables<R>(e);
     a.pcm = pcm_dev;
     a.chunk = chunk;
     a.pcm_pairs_ok = ((chunk & 1) == 0) && ((reinterpret_cast<uintptr_t>(pcm_dev) & 3u) == 0);
@@ -429,15 +350,23 @@ MfccStreamArgs<R> mfcc_args(const pe_engine* e, const int16_t* pcm_dev, int chun
     a.st_q_next = e->st_q[n]; a.st_kc_next = e->st_kc[n]; a.st_ke_next = e->st_ke[n];
     a.ring = e->ring;
     a.n_updates = 1; a.ke_hist = nullptr; a.n_padded = e->n_padded;
-    a.n_frame_rows = 1; a.carry_next = e->carry;
+    a.n_frame_rows = max_frames_per_call(e, chunk); a.carry_next = e->carry_alt;
     return a;
+}
+
+// after a call's MFCC launches: the other counter set and the other carry buffer are the current ones
+void flip_state(pe_engine* e) {
+    e->cur ^= 1;
+    std::swap(e->carry, e->carry_alt);
 }
 
 // MFCC alone: consumes state[cur], publishes state[cur ^ 1], then flips.
 int launch_mfcc(pe_engine* e, const int16_t* pcm_dev, int chunk, hipStream_t s) {
-    if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_mfcc_stream_f64(mfcc_args<double>(e, pcm_dev, chunk), s));
-    else PE_HIP(e, launch_mfcc_stream_f32(mfcc_args<float>(e, pcm_dev, chunk), s));
-    e->cur ^= 1;
+    if (max_frames_per_call(e, chunk) > kMaxFrameRows)
+        return fail(e, PE_ERR_INVALID, "a call may complete at most %d frames per stream (chunk of %d samples)", kMaxFrameRows, chunk);
+    if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_mfcc_f64(mfcc_args<double>(e, pcm_dev, chunk), tables<double>(e), e->n_cus, s));
+    else PE_HIP(e, launch_mfcc_f32(mfcc_args<float>(e, pcm_dev, chunk), tables<float>(e), e->n_cus, s));
+    flip_state(e);
     return PE_OK;
 }
 
@@ -521,9 +450,9 @@ int do_update(pe_engine* e, const int16_t* pcm_dev, int chunk, float* raw_out_de
         g.predict_ke = 1;
         g.chunk = chunk;
         g.out = raw_out_dev;
-        if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_fused_f64(mfcc_args<double>(e, pcm_dev, chunk), g, s));
-        else PE_HIP(e, launch_fused_f32(mfcc_args<float>(e, pcm_dev, chunk), g, s));
-        e->cur ^= 1;
+        if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_fused_f64(mfcc_args<double>(e, pcm_dev, chunk), tables<double>(e), g, e->n_cus, s));
+        else PE_HIP(e, launch_fused_f32(mfcc_args<float>(e, pcm_dev, chunk), tables<float>(e), g, e->n_cus, s));
+        flip_state(e);
         if (t) { PE_HIP(e, hipEventRecord(e->ev[1], s)); PE_HIP(e, hipEventRecord(e->ev[2], s)); e->ev_valid = true; e->ev_has_gru = false; }
     } else {
         if ((rc = launch_mfcc(e, pcm_dev, chunk, s))) return rc;
@@ -607,6 +536,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     int rc = PE_OK;
     do {
         if ((rc = dev_alloc(e, &e->carry, (size_t)e->n_padded * kCarryCap))) break;
+        if ((rc = dev_alloc(e, &e->carry_alt, (size_t)e->n_padded * kCarryCap))) break;
         for (int b = 0; b < 2 && !rc; ++b) {
             if ((rc = dev_alloc(e, &e->st_q[b], (size_t)e->n_padded))) break;
             if ((rc = dev_alloc(e, &e->st_kc[b], (size_t)e->n_padded))) break;
@@ -622,8 +552,8 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         for (auto& ev : e->ev)
             if (hipEventCreate(&ev) != hipSuccess) { rc = fail(e, PE_ERR_HIP, "hipEventCreate failed"); break; }
         if (rc) break;
-        const size_t lds = lds_layout_bytes(p->mfcc_precision == 0 ? 8 : 4, p->n_filt, p->n_mfcc, e->mel_parts, kThroughputGroups);
-        if (lds > 160 * 1024) { rc = fail(e, PE_ERR_UNSUPPORTED, "MFCC kernel would need %zu bytes of LDS", lds); break; }
+        const size_t lds = (size_t)e->table_layout.total + (size_t)kFrameWaves * pe_wave::kScratchReals * (p->mfcc_precision == 0 ? 8 : 4);
+        if (lds > 64 * 1024) { rc = fail(e, PE_ERR_UNSUPPORTED, "MFCC kernel would need %zu bytes of LDS per workgroup", lds); break; }
         if ((rc = pe_clear(e, nullptr))) break;
         hipError_t se = hipDeviceSynchronize();
         if (se != hipSuccess) { rc = fail(e, PE_ERR_HIP, "device sync after init failed: %s", hipGetErrorString(se)); break; }
@@ -789,13 +719,13 @@ int vectorize_buffer(pe_engine* e, const double* audio_host, int64_t n_samples, 
     PE_HIP(e, hipMemcpy(e->st_audio.p, audio_host, ab, hipMemcpyHostToDevice));
     double* dev_out = static_cast<double*>(e->st_mfcc.p);
     if (e->prm.mfcc_precision == 0) {
-        MfccOfflineArgs<double> a{geom(e), tables<double>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames,
+        MfccOfflineArgs<double> a{geom(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames,
                                   mels ? nullptr : dev_out, nullptr, mels ? dev_out : nullptr};
-        PE_HIP(e, launch_mfcc_offline_f64(a, nullptr));
+        PE_HIP(e, launch_mfcc_offline_f64(a, tables<double>(e), e->n_cus, nullptr));
     } else {
-        MfccOfflineArgs<float> a{geom(e), tables<float>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames,
+        MfccOfflineArgs<float> a{geom(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames,
                                  mels ? nullptr : dev_out, nullptr, mels ? dev_out : nullptr};
-        PE_HIP(e, launch_mfcc_offline_f32(a, nullptr));
+        PE_HIP(e, launch_mfcc_offline_f32(a, tables<float>(e), e->n_cus, nullptr));
     }
     PE_HIP(e, hipMemcpy(feats_out_host, e->st_mfcc.p, fb, hipMemcpyDeviceToHost));
     return PE_OK;
@@ -833,11 +763,11 @@ int pe_evaluate(pe_engine* e, const double* audio_host, int64_t n_samples, int32
     if ((rc = ensure(e, e->st_out, (size_t)n_windows * sizeof(float)))) return rc;
     PE_HIP(e, hipMemcpy(e->st_audio.p, audio_host, ab, hipMemcpyHostToDevice));
     if (e->prm.mfcc_precision == 0) {
-        MfccOfflineArgs<double> a{geom(e), tables<double>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, nullptr, static_cast<float*>(e->st_feats.p), nullptr};
-        PE_HIP(e, launch_mfcc_offline_f64(a, nullptr));
+        MfccOfflineArgs<double> a{geom(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, nullptr, static_cast<float*>(e->st_feats.p), nullptr};
+        PE_HIP(e, launch_mfcc_offline_f64(a, tables<double>(e), e->n_cus, nullptr));
     } else {
-        MfccOfflineArgs<float> a{geom(e), tables<float>(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, nullptr, static_cast<float*>(e->st_feats.p), nullptr};
-        PE_HIP(e, launch_mfcc_offline_f32(a, nullptr));
+        MfccOfflineArgs<float> a{geom(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, nullptr, static_cast<float*>(e->st_feats.p), nullptr};
+        PE_HIP(e, launch_mfcc_offline_f32(a, tables<float>(e), e->n_cus, nullptr));
     }
     GruArgs g = gru_args(e);
     g.n_streams = (int)n_windows;
@@ -937,10 +867,6 @@ int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samp
         int rc = dev_alloc(e, &e->ke_hist, (size_t)max_updates * e->n_padded);
         if (rc) return rc;
     }
-    if (!e->carry_alt) {
-        int rc = dev_alloc(e, &e->carry_alt, (size_t)e->n_padded * kCarryCap);
-        if (rc) return rc;
-    }
     e->max_updates = max_updates;
     return pe_clear(e, nullptr);          // the ring was re-laid out: streams restart
 }
@@ -957,21 +883,20 @@ int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, i
     if ((long long)n_updates * chunk >= (1ll << 30)) return fail(e, PE_ERR_INVALID, "n_updates * chunk_samples must stay below 2^30");
     if (e->prm.n_features + pending + frames > e->ring_slots) return fail(e, PE_ERR_INVALID, "reserved ring too small for %d updates of %d samples", n_updates, chunk);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // frames one stream can complete in this call: one workgroup row per frame, at most kMaxFrameRows rows
-    const long long fmax = ((long long)(kCarryCap - 1) + (long long)n_updates * chunk - flen) / e->prm.hop_samples + 1;
-    if (fmax > kMaxFrameRows) return fail(e, PE_ERR_INVALID, "a call may complete at most %d frames per stream (%d updates of %d samples: %lld)", kMaxFrameRows, n_updates, chunk, fmax);
-    const int rows = (int)(fmax < 1 ? 1 : fmax);
+    // frames one stream can complete in this call: one task row per frame, at most kMaxFrameRows rows
+    const int rows = max_frames_per_call(e, (long long)n_updates * chunk);
+    if (rows > kMaxFrameRows) return fail(e, PE_ERR_INVALID, "a call may complete at most %d frames per stream (%d updates of %d samples: %d)", kMaxFrameRows, n_updates, chunk, rows);
+    (void)flen;
     if (e->prm.mfcc_precision == 0) {
         MfccStreamArgs<double> a = mfcc_args<double>(e, pcm_dev, chunk);
-        a.n_updates = n_updates; a.ke_hist = e->ke_hist; a.n_frame_rows = rows; a.carry_next = e->carry_alt;
-        PE_HIP(e, launch_mfcc_many_f64(a, s));
+        a.n_updates = n_updates; a.ke_hist = e->ke_hist; a.n_frame_rows = rows;
+        PE_HIP(e, launch_mfcc_f64(a, tables<double>(e), e->n_cus, s));
     } else {
         MfccStreamArgs<float> a = mfcc_args<float>(e, pcm_dev, chunk);
-        a.n_updates = n_updates; a.ke_hist = e->ke_hist; a.n_frame_rows = rows; a.carry_next = e->carry_alt;
-        PE_HIP(e, launch_mfcc_many_f32(a, s));
+        a.n_updates = n_updates; a.ke_hist = e->ke_hist; a.n_frame_rows = rows;
+        PE_HIP(e, launch_mfcc_f32(a, tables<float>(e), e->n_cus, s));
     }
-    std::swap(e->carry, e->carry_alt);
-    e->cur ^= 1;
+    flip_state(e);
     GruArgs g = gru_args(e);
     g.st_ke = e->ke_hist;
     g.out = raw_out_dev;

@@ -1,31 +1,27 @@
 // Every __global__ entry point of libprecise_engine.so and its launcher.  The device code lives
-// in mfcc_device.h (MFCC front end) and gru_device.h (GRU + Dense on the f32 matrix cores).
+// in mfcc_wave_device.h / mfcc_device.h (MFCC front end: frames / bookkeeping) and gru_*_device.h (GRU + Dense
+// on the matrix cores).
 #include "mfcc_device.h"
+#include "mfcc_wave_device.h"
 #include "gru_device.h"
 #include "gru_bf16_device.h"
 #include "gru_wide_device.h"
 
 namespace pe {
 
-// ---- MFCC, streaming: one workgroup per 16-stream tile ---------------------------------------
-// Grid = n_tiles * nsel workgroups; workgroup b serves tile b / nsel, frame subset b % nsel.
+// ---- MFCC: one frame task per wave (mfcc_wave_device.h), bookkeeping per stream (mfcc_device.h) ------------------
+#ifndef PE_FRAME_WPE
+#define PE_FRAME_WPE 4          // waves per SIMD the frame role is compiled for (<= 128 VGPRs)
+#endif
 template <class R>
-__global__ __launch_bounds__(256) void mfcc_stream_kernel(const MfccStreamArgs<R> a, const int nsel) {
+__global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void mfcc_frames_kernel(const MfccStreamArgs<R> a, const WaveTables<R> t) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    mfcc_stream_tile<R>(a, blockIdx.x / nsel, smem, blockIdx.x % nsel, nsel);
-}
-
-// (waves_per_eu(3): the frame rows need 134 VGPRs in float64; left to itself the allocator takes 231 and two
-// of these workgroups then fill a SIMD's register file, so that no network wave of a concurrent launch fits)
-template <class R>
-__global__ __launch_bounds__(16 * kThroughputGroups) __attribute__((amdgpu_waves_per_eu(3))) void mfcc_many_kernel(const MfccStreamArgs<R> a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    mfcc_many_tile<R, false>(a, smem);
+    mfcc_frame_tasks<R>(a, t, smem, (long long)blockIdx.x * kFrameWaves, (long long)gridDim.x * kFrameWaves);
 }
 
 template <class R>
-__global__ __launch_bounds__(256) void mfcc_many_book_kernel(const MfccStreamArgs<R> a) {
-    mfcc_many_tile<R, true>(a, nullptr);
+__global__ __launch_bounds__(256) void mfcc_book_kernel(const MfccStreamArgs<R> a) {
+    mfcc_book_tile<R>(a, blockIdx.x);
 }
 
 // network for a whole batch of updates: workgroup (one wave) b serves update b / n_tiles, tile b % n_tiles
@@ -62,9 +58,9 @@ __global__ __launch_bounds__(64) void gru_many_bf16_kernel(const GruArgs a, cons
 }
 
 template <class R>
-__global__ __launch_bounds__(16 * kThroughputGroups) void mfcc_offline_kernel(const MfccOfflineArgs<R> a) {
+__global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void mfcc_offline_kernel(const MfccOfflineArgs<R> a, const WaveTables<R> t) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    mfcc_offline_block<R>(a, smem);
+    mfcc_offline_frames<R>(a, t, smem);
 }
 
 // ---- GRU: one wave per 16-stream tile ----------------------------------------------------------
@@ -120,15 +116,17 @@ __global__ __launch_bounds__(64) void gru_bf16_kernel(const GruArgs a) {
 
 // fused update with the bf16 network role (four tiles per GRU workgroup, one wave each)
 template <class R>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void fused_update_bf16_kernel(const MfccStreamArgs<R> m, const GruArgs g,
-                                                                const int n_gru_blocks, const int n_tiles) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_bf16_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
+                                                                const int n_gru_blocks, const int n_frame_blocks, const int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
     if (b < n_gru_blocks) {
         const int tile = b * 4 + (threadIdx.x >> 6);
         if (tile < n_tiles) gru_tile_bf16<kRing>(g, tile, threadIdx.x & 63);
+    } else if (b < n_gru_blocks + n_frame_blocks) {
+        mfcc_frame_tasks<R>(m, t, smem, (long long)(b - n_gru_blocks) * kFrameWaves, (long long)n_frame_blocks * kFrameWaves);
     } else {
-        mfcc_stream_tile<R>(m, b - n_gru_blocks, smem);
+        mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
     }
 }
 
@@ -140,20 +138,14 @@ __global__ __launch_bounds__(256) void gru_mw_kernel(const GruArgs a) {
     gru_tile_mw_any<R>(a, blockIdx.x, wave, threadIdx.x & 63, S);
 }
 
-// ---- fused update: GRU role || MFCC role in ONE launch ------------------------------------------
-// Workgroups [0, n_gru_blocks) run the network on the feature windows as they will stand after this
-// update; workgroups after them compute this update's MFCC frames.  The GRU workgroups are
-// dispatched first: they are the long pole.  MW = true: one GRU workgroup per tile, its four waves
-// share the tile (gru_tile_mw); MW = false: four tiles per GRU workgroup, one wave each.
-// (waves_per_eu(2): a GRU and an MFCC workgroup must fit one CU together, i.e. <= 256 registers per lane;
-// without the bound an innocent change to the MFCC code once pushed the allocation to 267 and the
-// launch from 21 to 30 us.)
+// ---- fused update: GRU role || MFCC frame role || bookkeeping role in ONE launch -------------------------------
+// Workgroups [0, n_gru_blocks) run the network on the feature windows as they will stand after this update (they
+// are dispatched first: the long pole); the next n_frame_blocks compute this update's MFCC frames, one frame task
+// per wave; the last n_tiles move the leftover samples and the counters.  MW = true: one GRU workgroup per tile,
+// its four waves share the tile (gru_tile_mw); MW = false: four tiles per GRU workgroup, one wave each.
 template <class R, int RG, bool MW>
-#ifndef PE_FUSED_WPE
-#define PE_FUSED_WPE 2
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FUSED_WPE))) void fused_update_kernel(const MfccStreamArgs<R> m, const GruArgs g,
-                                                           const int n_gru_blocks, const int n_tiles, const int nsel) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
+                                                           const int n_gru_blocks, const int n_frame_blocks, const int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
     if (b < n_gru_blocks) {
@@ -164,56 +156,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FUSED_WP
             const int tile = b * 4 + wave;
             if (tile < n_tiles) gru_tile<RG, kRing>(g, tile, threadIdx.x & 63);
         }
+    } else if (b < n_gru_blocks + n_frame_blocks) {
+        mfcc_frame_tasks<R>(m, t, smem, (long long)(b - n_gru_blocks) * kFrameWaves, (long long)n_frame_blocks * kFrameWaves);
     } else {
-        const int mb = b - n_gru_blocks;
-        mfcc_stream_tile<R>(m, mb / nsel, smem, mb % nsel, nsel);
+        mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
     }
 }
 
-// Workgroups per tile for the MFCC role.  Splitting the frames of one update over two workgroups per
-// tile was measured twice (4096 streams, MI355X): 31.6 us vs 22.9 us with a 73 KB LDS image, 31.5 us vs
-// 22.1 us with the present 57 KB one (33 us with the kernel held to 3 waves per SIMD) -- hence 1.  The
-// kernels keep the (fsel, nsel) parameters for larger-chunk use; PE_FRAME_SPLIT is the build switch.
-#ifndef PE_FRAME_SPLIT
-#define PE_FRAME_SPLIT 1
-#endif
-static int frame_split(const StreamGeom&, int, int) { return PE_FRAME_SPLIT; }
-
-template <class R>
-static hipError_t launch_stream(const MfccStreamArgs<R>& a, hipStream_t s) {
-    const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
-    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc, a.tab.mel_parts, 16);
-    const int nsel = frame_split(a.geo, a.chunk, tiles);
-    hipLaunchKernelGGL(mfcc_stream_kernel<R>, dim3(tiles * nsel), dim3(256), lds, s, a, nsel);
-    return hipGetLastError();
+// Workgroups of the frame role: one wave per task while that fits the machine (4 workgroups of 4 waves per compute
+// unit are resident: LDS and a 128-register budget), more tasks per wave beyond.
+static int frame_blocks(long long n_tasks, int n_cus) {
+    const long long need = (n_tasks + kFrameWaves - 1) / kFrameWaves;
+    const long long cap = (long long)n_cus * 4;
+    return (int)(need < cap ? (need < 1 ? 1 : need) : cap);
 }
 
 template <class R>
-static hipError_t launch_offline(const MfccOfflineArgs<R>& a, hipStream_t s) {
+static size_t frame_lds(const WaveTables<R>& t) { return wave_lds_bytes(sizeof(R), t.L.total, kFrameWaves); }
+
+template <class R>
+static hipError_t launch_mfcc(const MfccStreamArgs<R>& a, const WaveTables<R>& t, int n_cus, hipStream_t s) {
+    const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
+    const long long n_tasks = (long long)tiles * kTileStreams * a.n_frame_rows;
+    hipLaunchKernelGGL(mfcc_frames_kernel<R>, dim3(frame_blocks(n_tasks, n_cus)), dim3(64 * kFrameWaves), frame_lds(t), s, a, t);
+    hipLaunchKernelGGL(mfcc_book_kernel<R>, dim3(tiles), dim3(256), 0, s, a);      // reads what the frames read, writes elsewhere
+    return hipGetLastError();
+}
+hipError_t launch_mfcc_f64(const MfccStreamArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s) { return launch_mfcc<double>(a, t, n_cus, s); }
+hipError_t launch_mfcc_f32(const MfccStreamArgs<float>& a, const WaveTables<float>& t, int n_cus, hipStream_t s) { return launch_mfcc<float>(a, t, n_cus, s); }
+
+template <class R>
+static hipError_t launch_offline(const MfccOfflineArgs<R>& a, const WaveTables<R>& t, int n_cus, hipStream_t s) {
     if (a.n_frames <= 0) return hipSuccess;
-    const long long blocks = (a.n_frames + kThroughputGroups - 1) / kThroughputGroups;
-    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc, a.tab.mel_parts, kThroughputGroups);
-    hipLaunchKernelGGL(mfcc_offline_kernel<R>, dim3((unsigned)blocks), dim3(16 * kThroughputGroups), lds, s, a);
+    hipLaunchKernelGGL(mfcc_offline_kernel<R>, dim3(frame_blocks(a.n_frames, n_cus)), dim3(64 * kFrameWaves), frame_lds(t), s, a, t);
     return hipGetLastError();
 }
-
-hipError_t launch_mfcc_stream_f64(const MfccStreamArgs<double>& a, hipStream_t s) { return launch_stream<double>(a, s); }
-hipError_t launch_mfcc_stream_f32(const MfccStreamArgs<float>& a, hipStream_t s) { return launch_stream<float>(a, s); }
-template <class R>
-static hipError_t launch_many(const MfccStreamArgs<R>& a, hipStream_t s) {
-    const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
-    const size_t lds = lds_layout_bytes(sizeof(R), a.geo.n_filt, a.geo.n_mfcc, a.tab.mel_parts, kThroughputGroups);
-    const long long groups = (long long)tiles * a.n_frame_rows * kTileStreams;
-    hipLaunchKernelGGL(mfcc_many_kernel<R>, dim3((unsigned)((groups + kThroughputGroups - 1) / kThroughputGroups)),
-                       dim3(16 * kThroughputGroups), lds, s, a);
-    hipLaunchKernelGGL(mfcc_many_book_kernel<R>, dim3(tiles), dim3(256), 0, s, a);     // reads what the rows read, writes elsewhere
-    return hipGetLastError();
-}
-hipError_t launch_mfcc_many_f64(const MfccStreamArgs<double>& a, hipStream_t s) { return launch_many<double>(a, s); }
-hipError_t launch_mfcc_many_f32(const MfccStreamArgs<float>& a, hipStream_t s) { return launch_many<float>(a, s); }
-
-hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, hipStream_t s) { return launch_offline<double>(a, s); }
-hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, hipStream_t s) { return launch_offline<float>(a, s); }
+hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s) { return launch_offline<double>(a, t, n_cus, s); }
+hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, const WaveTables<float>& t, int n_cus, hipStream_t s) { return launch_offline<float>(a, t, n_cus, s); }
 
 int gru_small_regs(int units) { return (units + 3) / 4; }
 int gru_small_tiles(int units) { return (3 * gru_small_regs(units) + 3) / 4; }
@@ -284,43 +263,43 @@ hipError_t launch_gru_many(const GruArgs& a, int n_updates, int n_padded, hipStr
 }
 
 template <class R, int RG>
-static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const GruArgs& g, hipStream_t s) {
+static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R>& t, const GruArgs& g, int n_cus, hipStream_t s) {
     const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
-    const size_t lds = lds_layout_bytes(sizeof(R), m.geo.n_filt, m.geo.n_mfcc, m.tab.mel_parts, 16);
-    const int nsel = frame_split(m.geo, m.chunk, tiles);
+    const size_t lds = frame_lds(t);
+    const int fb = frame_blocks((long long)tiles * kTileStreams * m.n_frame_rows, n_cus);
     if (g.waves_per_tile == 4) {
-        hipLaunchKernelGGL((fused_update_kernel<R, RG, true>), dim3(tiles + tiles * nsel), dim3(256), lds, s, m, g, tiles, tiles, nsel);
+        hipLaunchKernelGGL((fused_update_kernel<R, RG, true>), dim3(tiles + fb + tiles), dim3(256), lds, s, m, t, g, tiles, fb, tiles);
     } else {
         const int gru_blocks = (tiles + 3) / 4;
-        hipLaunchKernelGGL((fused_update_kernel<R, RG, false>), dim3(gru_blocks + tiles * nsel), dim3(256), lds, s, m, g, gru_blocks, tiles, nsel);
+        hipLaunchKernelGGL((fused_update_kernel<R, RG, false>), dim3(gru_blocks + fb + tiles), dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
     }
     return hipGetLastError();
 }
 
 template <class R>
-static hipError_t launch_fused(const MfccStreamArgs<R>& m, const GruArgs& g, hipStream_t s) {
+static hipError_t launch_fused(const MfccStreamArgs<R>& m, const WaveTables<R>& t, const GruArgs& g, int n_cus, hipStream_t s) {
     if (g.bf16) {
         const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
         const int gru_blocks = (tiles + 3) / 4;
-        const size_t lds = lds_layout_bytes(sizeof(R), m.geo.n_filt, m.geo.n_mfcc, m.tab.mel_parts, 16);
-        hipLaunchKernelGGL((fused_update_bf16_kernel<R>), dim3(gru_blocks + tiles), dim3(256), lds, s, m, g, gru_blocks, tiles);
+        const int fb = frame_blocks((long long)tiles * kTileStreams * m.n_frame_rows, n_cus);
+        hipLaunchKernelGGL((fused_update_bf16_kernel<R>), dim3(gru_blocks + fb + tiles), dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles);
         return hipGetLastError();
     }
     switch (gru_small_regs(g.units)) {
-        case 1: return launch_fused_rg<R, 1>(m, g, s);
-        case 2: return launch_fused_rg<R, 2>(m, g, s);
-        case 3: return launch_fused_rg<R, 3>(m, g, s);
-        case 4: return launch_fused_rg<R, 4>(m, g, s);
-        case 5: return launch_fused_rg<R, 5>(m, g, s);
-        case 6: return launch_fused_rg<R, 6>(m, g, s);
-        case 7: return launch_fused_rg<R, 7>(m, g, s);
-        case 8: return launch_fused_rg<R, 8>(m, g, s);
+        case 1: return launch_fused_rg<R, 1>(m, t, g, n_cus, s);
+        case 2: return launch_fused_rg<R, 2>(m, t, g, n_cus, s);
+        case 3: return launch_fused_rg<R, 3>(m, t, g, n_cus, s);
+        case 4: return launch_fused_rg<R, 4>(m, t, g, n_cus, s);
+        case 5: return launch_fused_rg<R, 5>(m, t, g, n_cus, s);
+        case 6: return launch_fused_rg<R, 6>(m, t, g, n_cus, s);
+        case 7: return launch_fused_rg<R, 7>(m, t, g, n_cus, s);
+        case 8: return launch_fused_rg<R, 8>(m, t, g, n_cus, s);
         default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const GruArgs& g, hipStream_t s) { return launch_fused<double>(m, g, s); }
-hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const GruArgs& g, hipStream_t s) { return launch_fused<float>(m, g, s); }
+hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const WaveTables<double>& t, const GruArgs& g, int n_cus, hipStream_t s) { return launch_fused<double>(m, t, g, n_cus, s); }
+hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const WaveTables<float>& t, const GruArgs& g, int n_cus, hipStream_t s) { return launch_fused<float>(m, t, g, n_cus, s); }
 
 // ---- small utility kernels ---------------------------------------------------------------------
 __global__ void gather_kernel(const GatherArgs a) {

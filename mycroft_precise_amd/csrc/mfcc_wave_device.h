@@ -1,0 +1,330 @@
+// MFCC front end for gfx950 (MI355X), one FRAME per WAVE: int16 PCM -> 13 coefficients.
+//
+// What it computes is the reference's Vectorizer.mfccs entry (/root/reference/precise/vectorization.py:36-39 ->
+// third-party sonopy.mfcc_spec) -- or, with log_mode 1 and that library's filterbank, the legacy speechpy entry
+// (:40-42) -- as driven by Listener.update_vectors (/root/reference/precise/network_runner.py:125-146):
+//   frame = first n_fft(512) samples of each 1600-sample window (numpy's rfft(n=512) crop),
+//   512-point real FFT -> power/512 -> triangular mel filters -> log -> DCT-II ortho -> coefficient 0 := log power.
+//
+// Mapping to the machine (the arithmetic per lane and the tables: mfcc_wave_core.h / mfcc_wave_tables.h, shared
+// with the CPU replay in tools/emulate_mfcc_wave.cpp):
+//   * a frame is a TASK of one wave: 4 complex points per lane (16 data VGPRs in float64), four radix-4 passes,
+//     the (register x lane digit) transposes between them by v_permlane32/16_swap (digit b) and through 5 KB of
+//     wave-private LDS (digits c, d), real-FFT split against the mirror lane, power spectrum to LDS, the sparse
+//     mel filterbank as <= mel_len products per lane with the partial sums added in lane order, log on the lanes
+//     that own a filter, DCT as dct_len products per lane + a quad reduction;
+//   * one wave-instruction loads 256 contiguous bytes of a stream's PCM (4 per frame);
+//   * nothing in a frame waits for another wave: LDS hand-offs are inside the wave (DS instructions of a wave
+//     execute in order; only the compiler has to be kept from moving them), so a SIMD hides one frame's LDS
+//     latency behind the other frames it holds (<= 128 VGPRs: four waves per SIMD);
+//   * no MFMA here: byte shuffling and a small FFT, not a GEMM.
+#pragma once
+#include "pe_common.h"
+#include "mfcc_wave_core.h"
+#include "mfcc_device.h"        // RealK, real_log, group_sync, PcmView helpers shared with the bookkeeping kernel
+
+namespace pe {
+
+#ifndef PE_XCHG_B_LDS
+#define PE_XCHG_B_LDS 0         // 1: digit b also goes through LDS (debug / cross-check of the permlane path)
+#endif
+
+constexpr int kWaveScratchReals = pe_wave::kScratchReals;
+
+__host__ __device__ inline size_t wave_lds_bytes(int real_size, int blob_bytes, int waves) {
+    return (size_t)blob_bytes + (size_t)waves * kWaveScratchReals * real_size;
+}
+
+// workgroup-wide copy of the table image into LDS (16-byte loads); caller synchronises
+template <class R>
+__device__ __forceinline__ pe_wave::Tab<R> wave_tables_to_lds(unsigned char* smem, const WaveTables<R>& g) {
+    const int n16 = g.L.total >> 4;
+    const uint4* src = reinterpret_cast<const uint4*>(g.blob);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    return pe_wave::bind<R>(smem, g.L);
+}
+
+__device__ __forceinline__ void pl32_swap(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);      // a[32..63] <-> b[0..31]
+    a = r[0]; b = r[1];
+}
+__device__ __forceinline__ void pl16_swap(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);      // a[16..31] <-> b[0..15], a[48..63] <-> b[32..47]
+    a = r[0]; b = r[1];
+}
+__device__ __forceinline__ void swap32(double& a, double& b) {
+    unsigned al = (unsigned)__double2loint(a), ah = (unsigned)__double2hiint(a), bl = (unsigned)__double2loint(b), bh = (unsigned)__double2hiint(b);
+    pl32_swap(al, bl); pl32_swap(ah, bh);
+    a = __hiloint2double((int)ah, (int)al); b = __hiloint2double((int)bh, (int)bl);
+}
+__device__ __forceinline__ void swap16(double& a, double& b) {
+    unsigned al = (unsigned)__double2loint(a), ah = (unsigned)__double2hiint(a), bl = (unsigned)__double2loint(b), bh = (unsigned)__double2hiint(b);
+    pl16_swap(al, bl); pl16_swap(ah, bh);
+    a = __hiloint2double((int)ah, (int)al); b = __hiloint2double((int)bh, (int)bl);
+}
+__device__ __forceinline__ void swap32(float& a, float& b) {
+    unsigned x = __float_as_uint(a), y = __float_as_uint(b);
+    pl32_swap(x, y);
+    a = __uint_as_float(x); b = __uint_as_float(y);
+}
+__device__ __forceinline__ void swap16(float& a, float& b) {
+    unsigned x = __float_as_uint(a), y = __float_as_uint(b);
+    pl16_swap(x, y);
+    a = __uint_as_float(x); b = __uint_as_float(y);
+}
+
+// 4x4 transpose of (register index) x (lane digit b = lane bits 5:4) without LDS:
+// bit 1 of the register index <-> lane bit 5, then bit 0 <-> lane bit 4
+template <class R>
+__device__ __forceinline__ void exchange_b(pe_wave::Regs<R>& v) {
+    swap32(v.re[0], v.re[2]); swap32(v.im[0], v.im[2]);
+    swap32(v.re[1], v.re[3]); swap32(v.im[1], v.im[3]);
+    swap16(v.re[0], v.re[1]); swap16(v.im[0], v.im[1]);
+    swap16(v.re[2], v.re[3]); swap16(v.im[2], v.im[3]);
+}
+
+// the same transpose for any lane digit through the wave's scratch (X: [64][5] complex)
+template <class R>
+__device__ __forceinline__ void exchange_lds(pe_wave::Regs<R>& v, pe_wave::cx<R>* X, int lane, int shift) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[pe_wave::xchg_index(lane, r)] = pe_wave::cx<R>{v.re[r], v.im[r]};
+    group_sync();
+    const int sr = pe_wave::xchg_src_reg(lane, shift);
+#pragma unroll
+    for (int rp = 0; rp < 4; ++rp) {
+        const pe_wave::cx<R> z = X[pe_wave::xchg_index(pe_wave::xchg_src_lane(lane, shift, rp), sr)];
+        v.re[rp] = z.x; v.im[rp] = z.y;
+    }
+    group_sync();
+}
+
+template <class R> __device__ __forceinline__ R wave_sum(R x) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+// One frame on one wave.  pcm[a] = the int16 pair (samples 2n, 2n+1 in the low / high half) of point n = lane + 64 a,
+// already zero beyond the frame length -- or, FROM_REAL, re[]/im[] hold the samples as reals (offline form).
+// Returns coefficient c in the four lanes 4c..4c+3 (c < n_mfcc).  S: this wave's scratch; after the call
+// S[kLogMelOff + f] holds the log-mel energy of filter f.
+template <class R>
+__device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, R* S, const int lane, const int n_filt, const int n_mfcc,
+                                             pe_wave::Regs<R>& v, const R pscale, const int log_mode) {
+    using K = RealK<R>;
+    using namespace pe_wave;
+    cx<R>* X = reinterpret_cast<cx<R>*>(S);
+    pass_a(v, lane, t);
+#if PE_XCHG_B_LDS
+    exchange_lds(v, X, lane, 4);
+#else
+    exchange_b(v);
+#endif
+    pass_b(v, lane, t);
+    exchange_lds(v, X, lane, 2);
+    pass_c(v, lane, t);
+    exchange_lds(v, X, lane, 0);
+    pass_d(v);
+    // mirror exchange: bins 256 - p of this lane's registers 0 / 1 are registers 3 / 2 of the partner lane
+    X[xchg_index(lane, 0)] = cx<R>{v.re[2], v.im[2]};
+    X[xchg_index(lane, 1)] = cx<R>{v.re[3], v.im[3]};
+    group_sync();
+    const int pl = t.partner[lane];
+    cx<R> zq0 = X[xchg_index(pl, 1)], zq1 = X[xchg_index(pl, 0)];
+    const cx<R> w0 = t.w512[lane], w1 = t.w512[64 + lane];
+    group_sync();
+    const bool lane0 = kbase_of(lane) == 0;
+    if (lane0) { zq0 = cx<R>{v.re[0], v.im[0]}; zq1 = cx<R>{v.re[3], v.im[3]}; }
+    R pw[4];
+    split_power(v, zq0, zq1, w0, w1, pscale * R(0.25), pw);
+    R* P = S + kPowerOff;
+    R* PART = S + kPartOff;
+    R* LM = S + kLogMelOff;
+    int bins[4];
+    power_bins(lane, bins);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) P[bins[j]] = pw[j];
+    R psum = (pw[0] + pw[1]) + (pw[2] + pw[3]);
+    if (lane0) {
+        const R p128 = (v.re[2] * v.re[2] + v.im[2] * v.im[2]) * pscale;
+        P[128] = p128;
+        psum += p128;
+    }
+    group_sync();
+    // mel filterbank: this lane's run of one filter (all table reads first, then the FMA chain)
+    {
+        const int s = t.mel_start[lane];
+        R acc = R(0);
+        constexpr int CH = 6;
+        for (int i0 = 0; i0 < t.mel_len; i0 += CH) {
+            R pv[CH], wv[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int i = i0 + u < t.mel_len ? i0 + u : t.mel_len - 1;
+                pv[u] = P[s + i];
+                wv[u] = i0 + u < t.mel_len ? t.mel_w[i * 64 + lane] : R(0);
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) acc = real_fma(wv[u], pv[u], acc);
+        }
+        psum = wave_sum(psum);              // (rides in the shadow of the LDS reads above)
+        group_sync();
+        PART[lane] = acc;
+    }
+    group_sync();
+    // filter energies (partial sums of a filter sit in consecutive lanes: added in lane order), total power on
+    // the last lane, one log pass for both
+    {
+        const bool has_filter = lane < n_filt;
+        const bool takes_total = lane == 63 && n_filt < 64;
+        R x = R(1);
+        if (has_filter) x = filter_sum(t, PART, lane);
+        if (takes_total) x = psum;
+        if (has_filter || takes_total) {
+            // sonopy clips at eps (safe_log); speechpy replaces exact zeros only (zero_handling): 0 < x < eps stays x
+            const R y = real_log(log_mode == 0 ? (x > K::EPS ? x : K::EPS) : (x == R(0) ? K::EPS : x));
+            LM[takes_total ? n_filt : lane] = y;
+        }
+        if (n_filt == 64 && lane == 0) {    // no spare lane: a second log for the total
+            LM[64] = real_log(log_mode == 0 ? (psum > K::EPS ? psum : K::EPS) : (psum == R(0) ? K::EPS : psum));
+        }
+    }
+    group_sync();
+    // DCT-II (ortho): lane 4c + q adds its dct_len terms of coefficient c; quad reduction; c0 := log total power
+    R part = R(0);
+    {
+        const int q = lane & 3;
+        constexpr int CH = 5;
+        for (int i0 = 0; i0 < t.dct_len; i0 += CH) {
+            R lv[CH], dv[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int i = i0 + u < t.dct_len ? i0 + u : t.dct_len - 1;
+                const int n = t.dct_len * q + i;
+                lv[u] = LM[n < n_filt ? n : n_filt - 1];
+                dv[u] = i0 + u < t.dct_len ? t.dct_w[i * 64 + lane] : R(0);
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) part = real_fma(dv[u], lv[u], part);
+        }
+    }
+    const R c0 = LM[n_filt];
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    group_sync();                           // the scratch may be rewritten by the next frame
+    return lane < 4 ? c0 : part;
+}
+
+// ---- frame tasks of the streaming engine -------------------------------------------------------------------
+// Which samples form which frame is closed-form integer arithmetic over the virtual stream
+//     [carry (q samples)] ++ chunk 0 ++ chunk 1 ++ ... ++ chunk n_updates-1,
+// so the frames a call completes are independent tasks (tile, row kb, stream): frame kb of that stream, if the call
+// completes that many.  Waves take tasks round-robin; the bookkeeping (leftover samples, counters, per-update
+// emitted-frame history) is a separate small role (mfcc_many_tile<R, true>), which writes the OTHER carry buffer.
+template <class R>
+__device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, const WaveTables<R>& wt, unsigned char* smem,
+                                                 const long long first_task, const long long task_stride) {
+    using K = RealK<R>;
+    const StreamGeom& geo = a.geo;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const pe_wave::Tab<R> tab = wave_tables_to_lds<R>(smem, wt);
+    __syncthreads();
+    R* S = reinterpret_cast<R*>(smem + wt.L.total) + (size_t)wave * kWaveScratchReals;
+    const int n_kb = a.n_frame_rows;
+    const long long row_tasks = (long long)((geo.n_streams + kTileStreams - 1) / kTileStreams) * kTileStreams;
+    const long long n_tasks = row_tasks * n_kb;
+    const int C = a.chunk, hop = geo.hop, flen = geo.frame_len, slots = geo.ring_slots, U = a.n_updates;
+    const size_t update_stride = (size_t)geo.n_streams * C;
+    for (long long task = first_task + wave; task < n_tasks; task += task_stride) {
+        // frame-row major: the rows few streams reach (second frame of an update) end up in the last tasks
+        const int kb = (int)(task / row_tasks);
+        const long long s = task - (long long)kb * row_tasks;
+        const int tile = (int)(s >> 4), j = (int)(s & 15);
+        if (s >= geo.n_streams) continue;
+        const int q = a.st_q[s];
+        const uint32_t kc = a.st_kc[s];
+        const int avail = q + U * C;
+        const int nnew = avail >= flen ? 1 + (avail - flen) / hop : 0;
+        const int f_first = nnew > slots ? nnew - slots : 0;   // older frames would be overwritten anyway
+        if (kb < f_first || kb >= nnew) continue;              // (wave-uniform: one task per wave)
+        const int16_t* car = a.carry + (size_t)s * kCarryCap;
+        const int16_t* base = a.pcm + (size_t)s * C;
+        const int vb = kb * hop;
+        pe_wave::Regs<R> v;
+        // dword loads of (even, odd) pairs: every quantity that shifts a pair boundary must be even, and a
+        // frame may cross at most one chunk boundary
+        const bool fast = a.pcm_pairs_ok && ((q | hop | C | flen) & 1) == 0 && (C >= flen || U == 1);
+        if (fast) {
+            const int w0 = vb - q;                              // < 0: the frame starts inside the carry
+            int u0 = 0, off0 = w0;
+            if (w0 >= 0) { u0 = w0 / C; off0 = w0 - u0 * C; }
+            const int16_t* rowu = base + (size_t)u0 * update_stride;
+            const ptrdiff_t wrap = (ptrdiff_t)update_stride - C;
+            int raw[4];
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                const int n = 2 * (lane + 64 * a4);
+                const int nn = n < flen ? n : 0;
+                const int vv = vb + nn, off = off0 + nn;
+                const int16_t* p = (vv < q) ? (car + vv) : (rowu + off + (off >= C ? wrap : 0));
+                raw[a4] = *reinterpret_cast<const int*>(p);
+                if (n >= flen) raw[a4] = 0;
+            }
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                v.re[a4] = (R)(int)(short)(raw[a4] & 0xffff);
+                v.im[a4] = (R)(raw[a4] >> 16);
+            }
+        } else {
+            auto vsample = [&](int vv) -> int {
+                if (vv < q) return (int)car[vv];
+                const int w = vv - q, u = w / C;
+                return (int)base[(size_t)u * update_stride + (w - u * C)];
+            };
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                const int n = 2 * (lane + 64 * a4);
+                v.re[a4] = n < flen ? (R)vsample(vb + n) : R(0);
+                v.im[a4] = n + 1 < flen ? (R)vsample(vb + n + 1) : R(0);
+            }
+        }
+        const R coeff = mfcc_wave_frame<R>(tab, S, lane, geo.n_filt, geo.n_mfcc, v, K::PSCALE_I16, geo.log_mode);
+        const int slot = (int)((kc + (uint32_t)kb) & (uint32_t)(slots - 1));
+        float* row = a.ring + (((size_t)tile * slots + slot) * kTileStreams + j) * kRowFloats;
+        const int c = lane >> 2;
+        if ((lane & 3) == 0) row[c] = c < geo.n_mfcc ? (float)coeff : 0.0f;
+    }
+}
+
+// ---- stateless whole-buffer form (vectorize_raw): one frame per wave, float64 samples in -------------------------
+template <class R>
+__device__ __forceinline__ void mfcc_offline_frames(const MfccOfflineArgs<R>& a, const WaveTables<R>& wt, unsigned char* smem) {
+    const StreamGeom& geo = a.geo;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const pe_wave::Tab<R> tab = wave_tables_to_lds<R>(smem, wt);
+    __syncthreads();
+    R* S = reinterpret_cast<R*>(smem + wt.L.total) + (size_t)wave * kWaveScratchReals;
+    const int flen = geo.frame_len;
+    for (long long fr = (long long)blockIdx.x * waves + wave; fr < a.n_frames; fr += (long long)gridDim.x * waves) {
+        const double* x = a.audio + fr * geo.hop;
+        pe_wave::Regs<R> v;
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4) {
+            const int n = 2 * (lane + 64 * a4);
+            v.re[a4] = n < flen ? (R)x[n] : R(0);
+            v.im[a4] = n + 1 < flen ? (R)x[n + 1] : R(0);
+        }
+        const R coeff = mfcc_wave_frame<R>(tab, S, lane, geo.n_filt, geo.n_mfcc, v, RealK<R>::INV_FFT, geo.log_mode);
+        const int c = lane >> 2;
+        if ((lane & 3) == 0) {
+            if (a.out && c < geo.n_mfcc) a.out[fr * geo.n_mfcc + c] = (double)coeff;
+            if (a.out_rows) a.out_rows[fr * kRowFloats + c] = c < geo.n_mfcc ? (float)coeff : 0.0f;
+        }
+        if (a.out_mels)             // the log-mel energies are still in this wave's scratch
+            for (int f = lane; f < geo.n_filt; f += 64) a.out_mels[fr * geo.n_filt + f] = (double)S[pe_wave::kLogMelOff + f];
+        group_sync();
+    }
+}
+
+}  // namespace pe

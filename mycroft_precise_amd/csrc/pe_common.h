@@ -1,9 +1,10 @@
 // Shared declarations between the C-ABI host code (engine.hip) and the gfx950 kernels.
-// Everything here is MI355X-only: 64-lane wavefronts, 16x16x4 f32 MFMA tiles, LDS-staged
-// 256-point FFTs.  No portability layer on purpose.
+// Everything here is MI355X-only: 64-lane wavefronts, 16x16x4 f32 MFMA tiles, one 512-point FFT per
+// wave.  No portability layer on purpose.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "mfcc_wave_tables.h"
 
 namespace pe {
 
@@ -16,59 +17,14 @@ constexpr int kMaxFilt = 64;
 
 template <class R> struct cplx { R x, y; };
 
-constexpr int kTrStride = 17;                       // padded row of the 16x16 LDS transpose
-constexpr int kPowerPad = 16 * kTrStride + 2;       // power spectrum, bin b at b + (b >> 4)
-constexpr int kMelSteps = 17;                       // bins per lane in the mel pass: 16 r .. 16 r + 16
-constexpr int kMaxMelParts = 128;                   // partial filter sums per frame
-constexpr int kMaxFrameRows = 4096;                 // pe_update_many: frames one stream may complete per call (= workgroup rows per tile)
-#ifndef PE_TG
-#define PE_TG 16
-#endif
-// 16-lane groups per workgroup of the batch MFCC kernels.  Measured on MI355X (pe_update_many, 4096 streams x 8
-// updates, f64): 16 groups (256 threads, 2 workgroups per CU) 16.2 us per update; 24 groups (384 threads, 3 waves
-// per SIMD) 19.2; 48 groups (768 threads) 16.7 -- the stage is issue-bound, not occupancy-bound.
-constexpr int kThroughputGroups = PE_TG;
-// reals of LDS per 16-lane group: the padded power spectrum (whose head is reused for the n_filt log-mel
-// energies once the mel pass has consumed it) + the partial filter sums + 1 spare slot, padded to
-// 18 mod 64 so that the four groups of a wave start 36 (f64) / 18 (f32) banks apart: a stride of 32 banks
-// (what the unpadded 336 reals give in f64) costs 1.4 us per update in bank conflicts.
-__host__ __device__ inline int group_scratch_reals(int mel_parts) {
-    const int need = kPowerPad + mel_parts + 1;
-    return need + ((18 - need % 64) + 64) % 64;
-}
+constexpr int kMaxFrameRows = 4096;                 // pe_update_many: frames one stream may complete per call (= task rows per tile)
+constexpr int kFrameWaves = 4;                      // waves per workgroup of the MFCC frame role (one frame task per wave at a time)
 
-// The constant tables live in ONE device blob laid out exactly as they sit in LDS:
-//   [tw256: 256 cplx][w512: 130 cplx][dct: n_mfcc*n_filt R][mel_w: 2*17*16 R][pad16]
-//   [mel_flush: 17*16 int][mel_pstart: n_filt+1 int][pad16]          (engine.hip: build_tables)
-__host__ __device__ inline size_t table_blob_bytes(int real_size, int n_filt, int n_mfcc) {
-    size_t b = 0;
-    b += 256 * 2 * (size_t)real_size;
-    b += 130 * 2 * (size_t)real_size;
-    b += (size_t)n_mfcc * n_filt * real_size;
-    b += (size_t)2 * kMelSteps * 16 * real_size;
-    b = (b + 15) & ~(size_t)15;
-    b += ((size_t)(kMelSteps * 16 + n_filt + 1) * sizeof(int) + 15) & ~(size_t)15;
-    return b;
-}
-
-__host__ __device__ inline size_t lds_layout_bytes(int real_size, int n_filt, int n_mfcc, int mel_parts, int groups) {
-    return table_blob_bytes(real_size, n_filt, n_mfcc) + (size_t)groups * group_scratch_reals(mel_parts) * real_size;
-}
-
-// ---------------------------------------------------------------------------------------
-// MFCC front end (vectorization.py:36-39 -> sonopy.mfcc_spec), streaming form
-// ---------------------------------------------------------------------------------------
+// Constant tables of the one-frame-per-wave MFCC (mfcc_wave_tables.h builds the blob on the host)
 template <class R>
-struct MfccTables {
-    // one device blob laid out exactly as the tables sit in LDS (table_blob_bytes above):
-    //   tw256 [16 k1][16 r] exp(-2 pi i r k1 / 256) | w512 [130] exp(-2 pi i p / 512) |
-    //   dct [n_mfcc][n_filt] (DCT-II ortho) |
-    //   mel_w [2 streams][17 steps][16 lanes]: weight of bin 16 r + i in its 1st / 2nd filter |
-    //   mel_flush [17][16]: lo/hi 16 bits = partial-sum slot to write after that step (0xffff: none) |
-    //   mel_pstart [n_filt+1]: partial-sum slots of filter f are [pstart[f], pstart[f+1])
-    const void* blob;
-    int blob_bytes;
-    int mel_parts;          // partial-sum slots in use; slot mel_parts is the spare one
+struct WaveTables {
+    const void* blob;           // device image, laid out as it sits in LDS (pe_wave::Layout)
+    pe_wave::Layout L;
 };
 
 struct StreamGeom {
@@ -86,7 +42,6 @@ struct StreamGeom {
 template <class R>
 struct MfccStreamArgs {
     StreamGeom geo;
-    MfccTables<R> tab;
     const int16_t* pcm;     // [n_streams][chunk]
     int chunk;
     int pcm_pairs_ok;       // chunk even and pcm 4-byte aligned: int16 pairs may be loaded as one dword
@@ -103,7 +58,7 @@ struct MfccStreamArgs {
     float* ring;            // [n_tiles][ring_slots][16 streams][16 floats]
     // several updates per launch (mfcc_many_tile): chunk u of stream s at pcm + (u*n_streams + s)*chunk
     int n_updates;
-    int n_frame_rows;       // workgroup rows per tile that share the frames of a call (+ 1 bookkeeping row)
+    int n_frame_rows;       // frame tasks per stream: the most frames one stream can complete in this call
     int16_t* carry_next;    // leftover after the call; must not alias carry
     uint32_t* ke_hist;      // [n_updates][n_padded] emitted-frame counter after every update
     int n_padded;
@@ -112,7 +67,6 @@ struct MfccStreamArgs {
 template <class R>
 struct MfccOfflineArgs {
     StreamGeom geo;
-    MfccTables<R> tab;
     const double* audio;    // [n_samples] float64 samples
     long long n_samples;
     long long n_frames;
@@ -213,19 +167,19 @@ struct DecodeArgs {
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t s);
 
 // launchers implemented in kernels.hip
-hipError_t launch_mfcc_stream_f64(const MfccStreamArgs<double>& a, hipStream_t s);
-hipError_t launch_mfcc_stream_f32(const MfccStreamArgs<float>& a, hipStream_t s);
-// one launch, two roles: GRU waves read the feature windows as they will be after this update
-// while MFCC workgroups compute this update's frames (legal when chunk <= window - frame_len:
-// no frame computed now becomes visible now)
-hipError_t launch_mfcc_many_f64(const MfccStreamArgs<double>& a, hipStream_t s);
-hipError_t launch_mfcc_many_f32(const MfccStreamArgs<float>& a, hipStream_t s);
+// MFCC of one call (n_updates chunks per stream): every frame the call completes as a task of one wave, then the
+// per-stream bookkeeping (leftover samples to carry_next, counters to st_*_next, ke_hist)
+hipError_t launch_mfcc_f64(const MfccStreamArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s);
+hipError_t launch_mfcc_f32(const MfccStreamArgs<float>& a, const WaveTables<float>& t, int n_cus, hipStream_t s);
 // network for n_updates x n_streams windows, emitted counters from ke_hist, out[u][stream]
 hipError_t launch_gru_many(const GruArgs& a, int n_updates, int n_padded, hipStream_t s);
-hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const GruArgs& g, hipStream_t s);
-hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const GruArgs& g, hipStream_t s);
-hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, hipStream_t s);
-hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, hipStream_t s);
+// one launch, three roles: GRU waves read the feature windows as they will be after this update while MFCC waves
+// compute this update's frames and the bookkeeping groups move the leftover (legal when chunk <= window -
+// frame_len: no frame computed now becomes visible now)
+hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const WaveTables<double>& t, const GruArgs& g, int n_cus, hipStream_t s);
+hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const WaveTables<float>& t, const GruArgs& g, int n_cus, hipStream_t s);
+hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s);
+hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, const WaveTables<float>& t, int n_cus, hipStream_t s);
 hipError_t launch_gru_small(const GruArgs& a, int input_mode, hipStream_t s);   // units <= 32; 0 feats, 1 ring, 2 rows
 int gru_small_regs(int units);                  // R = ceil(units/4)
 int gru_wide_waves(int units);                  // waves per workgroup of the wide kernel (the weight packing follows it)
