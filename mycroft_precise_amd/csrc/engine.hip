@@ -351,6 +351,8 @@ MfccStreamArgs<R> mfcc_args(const pe_engine* e, const int16_t* pcm_dev, int chun
     a.ring = e->ring;
     a.n_updates = 1; a.ke_hist = nullptr; a.n_padded = e->n_padded;
     a.n_frame_rows = max_frames_per_call(e, chunk); a.carry_next = e->carry_alt;
+    a.div_hop = FastDiv::make((uint32_t)e->prm.hop_samples);
+    a.div_chunk = FastDiv::make((uint32_t)chunk);
     return a;
 }
 

@@ -16,7 +16,7 @@ namespace pe {
 template <class R>
 __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void mfcc_frames_kernel(const MfccStreamArgs<R> a, const WaveTables<R> t) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    mfcc_frame_tasks<R>(a, t, smem, (long long)blockIdx.x * kFrameWaves, (long long)gridDim.x * kFrameWaves);
+    mfcc_frame_tasks<R>(a, t, smem, (int)blockIdx.x * kFrameWaves, (int)gridDim.x * kFrameWaves);
 }
 
 template <class R>
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
         const int tile = b * 4 + (threadIdx.x >> 6);
         if (tile < n_tiles) gru_tile_bf16<kRing>(g, tile, threadIdx.x & 63);
     } else if (b < n_gru_blocks + n_frame_blocks) {
-        mfcc_frame_tasks<R>(m, t, smem, (long long)(b - n_gru_blocks) * kFrameWaves, (long long)n_frame_blocks * kFrameWaves);
+        mfcc_frame_tasks<R>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
     } else {
         mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
     }
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
             if (tile < n_tiles) gru_tile<RG, kRing>(g, tile, threadIdx.x & 63);
         }
     } else if (b < n_gru_blocks + n_frame_blocks) {
-        mfcc_frame_tasks<R>(m, t, smem, (long long)(b - n_gru_blocks) * kFrameWaves, (long long)n_frame_blocks * kFrameWaves);
+        mfcc_frame_tasks<R>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
     } else {
         mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
     }

@@ -14,7 +14,7 @@
 
 namespace pe_wave {
 
-template <class R> struct cx { R x, y; };
+template <class R> struct alignas(2 * sizeof(R)) cx { R x, y; };      // one 16 / 8-byte LDS access
 
 template <class R> struct Regs { R re[4], im[4]; };
 
@@ -24,6 +24,7 @@ struct Tab {            // pointers into one image of the blob (LDS on the GPU)
     const cx<R>* tw2;   // [3][16]
     const cx<R>* tw3;   // [3][4]
     const cx<R>* w512;  // [2][64]
+    const cx<R>* logtab;    // [128] {1 / c_i, log c_i} (float64 only)
     const R* mel_w;     // [mel_len][64]
     const R* dct_w;     // [dct_len][64]
     const int* mel_start;   // [64]
@@ -39,6 +40,7 @@ PE_HD Tab<R> bind(const unsigned char* image, const Layout& L) {
     t.tw2 = reinterpret_cast<const cx<R>*>(image + L.tw2);
     t.tw3 = reinterpret_cast<const cx<R>*>(image + L.tw3);
     t.w512 = reinterpret_cast<const cx<R>*>(image + L.w512);
+    t.logtab = reinterpret_cast<const cx<R>*>(image + L.logtab);
     t.mel_w = reinterpret_cast<const R*>(image + L.mel_w);
     t.dct_w = reinterpret_cast<const R*>(image + L.dct_w);
     t.mel_start = reinterpret_cast<const int*>(image + L.mel_start);
@@ -72,10 +74,25 @@ PE_HD void twiddle3(Regs<R>& v, const cx<R>& w1, const cx<R>& w2, const cx<R>& w
     }
 }
 
+// The twiddles a lane needs are the same for every frame: loaded once per wave and kept in registers.
+template <class R>
+struct LaneConsts {
+    cx<R> tw1[3], tw2[3], tw3[3];   // W256^(l k), W64^((l & 15) k), W16^((l & 3) k), k = 1..3
+    cx<R> w512[2];                  // W512^(kbase(l) + 64 j)
+};
+
+template <class R>
+PE_HD LaneConsts<R> lane_consts(const Tab<R>& t, int l) {
+    LaneConsts<R> c;
+    for (int k = 0; k < 3; ++k) { c.tw1[k] = t.tw1[k * 64 + l]; c.tw2[k] = t.tw2[k * 16 + (l & 15)]; c.tw3[k] = t.tw3[k * 4 + (l & 3)]; }
+    c.w512[0] = t.w512[l]; c.w512[1] = t.w512[64 + l];
+    return c;
+}
+
 // the four radix-4 passes; between them the caller transposes (register index) x (lane digit)
-template <class R> PE_HD void pass_a(Regs<R>& v, int l, const Tab<R>& t) { radix4(v); twiddle3(v, t.tw1[l], t.tw1[64 + l], t.tw1[128 + l]); }
-template <class R> PE_HD void pass_b(Regs<R>& v, int l, const Tab<R>& t) { radix4(v); const int m = l & 15; twiddle3(v, t.tw2[m], t.tw2[16 + m], t.tw2[32 + m]); }
-template <class R> PE_HD void pass_c(Regs<R>& v, int l, const Tab<R>& t) { radix4(v); const int d = l & 3; twiddle3(v, t.tw3[d], t.tw3[4 + d], t.tw3[8 + d]); }
+template <class R> PE_HD void pass_a(Regs<R>& v, const LaneConsts<R>& c) { radix4(v); twiddle3(v, c.tw1[0], c.tw1[1], c.tw1[2]); }
+template <class R> PE_HD void pass_b(Regs<R>& v, const LaneConsts<R>& c) { radix4(v); twiddle3(v, c.tw2[0], c.tw2[1], c.tw2[2]); }
+template <class R> PE_HD void pass_c(Regs<R>& v, const LaneConsts<R>& c) { radix4(v); twiddle3(v, c.tw3[0], c.tw3[1], c.tw3[2]); }
 template <class R> PE_HD void pass_d(Regs<R>& v) { radix4(v); }
 
 // source of register r' of lane l in the exchange of lane digit `shift` (4, 2 or 0): (lane, register) it comes from
@@ -109,6 +126,37 @@ PE_HD void split_power(const Regs<R>& v, const cx<R>& zq0, const cx<R>& zq1, con
 PE_HD void power_bins(int l, int (&bins)[4]) {
     const int kb = kbase_of(l);
     bins[0] = kb; bins[1] = kb + 64; bins[2] = 256 - kb; bins[3] = 192 - kb;
+}
+
+// log(x), x > 0.  float64: table-driven -- x = m 2^e, m in [0.5, 1) falls in one of 128 intervals with centre c;
+// log x = e ln 2 + log c + log1p(m / c - 1), |m / c - 1| <= 2^-8, seven terms of the series (truncation < 2^-66);
+// absolute error a few 1e-16 plus |e| ulp(ln 2) -- about 20 float64 operations instead of libm's ~80.
+PE_HD int mant_index7(double m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (__double2hiint(m) >> 13) & 127;
+#else
+    unsigned long long u; std::memcpy(&u, &m, 8); return (int)((u >> 45) & 127);
+#endif
+}
+PE_HD double wave_log(double x, const cx<double>* logtab) {
+    int e;
+    const double m = frexp(x, &e);
+    const cx<double> t = logtab[mant_index7(m)];
+    const double r = fma(m, t.x, -1.0);
+    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+    p = fma(p, r, 1.0 / 5.0);
+    p = fma(p, r, -1.0 / 4.0);
+    p = fma(p, r, 1.0 / 3.0);
+    p = fma(p, r, -1.0 / 2.0);
+    p = fma(p, r, 1.0);
+    return fma((double)e, 0.6931471805599453094, fma(p, r, t.y));
+}
+PE_HD float wave_log(float x, const cx<float>*) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return logf(x);
+#else
+    return std::log(x);
+#endif
 }
 
 template <class R>

@@ -110,20 +110,20 @@ template <class R> __device__ __forceinline__ R wave_sum(R x) {
 // Returns coefficient c in the four lanes 4c..4c+3 (c < n_mfcc).  S: this wave's scratch; after the call
 // S[kLogMelOff + f] holds the log-mel energy of filter f.
 template <class R>
-__device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, R* S, const int lane, const int n_filt, const int n_mfcc,
-                                             pe_wave::Regs<R>& v, const R pscale, const int log_mode) {
+__device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, const pe_wave::LaneConsts<R>& lc, R* S, const int lane,
+                                             const int n_filt, const int n_mfcc, pe_wave::Regs<R>& v, const R pscale, const int log_mode) {
     using K = RealK<R>;
     using namespace pe_wave;
     cx<R>* X = reinterpret_cast<cx<R>*>(S);
-    pass_a(v, lane, t);
+    pass_a(v, lc);
 #if PE_XCHG_B_LDS
     exchange_lds(v, X, lane, 4);
 #else
     exchange_b(v);
 #endif
-    pass_b(v, lane, t);
+    pass_b(v, lc);
     exchange_lds(v, X, lane, 2);
-    pass_c(v, lane, t);
+    pass_c(v, lc);
     exchange_lds(v, X, lane, 0);
     pass_d(v);
     // mirror exchange: bins 256 - p of this lane's registers 0 / 1 are registers 3 / 2 of the partner lane
@@ -132,7 +132,7 @@ __device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, R* S, con
     group_sync();
     const int pl = t.partner[lane];
     cx<R> zq0 = X[xchg_index(pl, 1)], zq1 = X[xchg_index(pl, 0)];
-    const cx<R> w0 = t.w512[lane], w1 = t.w512[64 + lane];
+    const cx<R> w0 = lc.w512[0], w1 = lc.w512[1];
     group_sync();
     const bool lane0 = kbase_of(lane) == 0;
     if (lane0) { zq0 = cx<R>{v.re[0], v.im[0]}; zq1 = cx<R>{v.re[3], v.im[3]}; }
@@ -183,11 +183,11 @@ __device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, R* S, con
         if (takes_total) x = psum;
         if (has_filter || takes_total) {
             // sonopy clips at eps (safe_log); speechpy replaces exact zeros only (zero_handling): 0 < x < eps stays x
-            const R y = real_log(log_mode == 0 ? (x > K::EPS ? x : K::EPS) : (x == R(0) ? K::EPS : x));
+            const R y = wave_log(log_mode == 0 ? (x > K::EPS ? x : K::EPS) : (x == R(0) ? K::EPS : x), t.logtab);
             LM[takes_total ? n_filt : lane] = y;
         }
         if (n_filt == 64 && lane == 0) {    // no spare lane: a second log for the total
-            LM[64] = real_log(log_mode == 0 ? (psum > K::EPS ? psum : K::EPS) : (psum == R(0) ? K::EPS : psum));
+            LM[64] = wave_log(log_mode == 0 ? (psum > K::EPS ? psum : K::EPS) : (psum == R(0) ? K::EPS : psum), t.logtab);
         }
     }
     group_sync();
@@ -219,81 +219,138 @@ __device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, R* S, con
 // ---- frame tasks of the streaming engine -------------------------------------------------------------------
 // Which samples form which frame is closed-form integer arithmetic over the virtual stream
 //     [carry (q samples)] ++ chunk 0 ++ chunk 1 ++ ... ++ chunk n_updates-1,
-// so the frames a call completes are independent tasks (tile, row kb, stream): frame kb of that stream, if the call
+// so the frames a call completes are independent tasks (row kb, stream): frame kb of that stream, if the call
 // completes that many.  Waves take tasks round-robin; the bookkeeping (leftover samples, counters, per-update
-// emitted-frame history) is a separate small role (mfcc_many_tile<R, true>), which writes the OTHER carry buffer.
+// emitted-frame history) is a separate small role (mfcc_book_tile), which writes the OTHER carry buffer.
+//
+// Latency plan: a wave keeps the NEXT due frame's PCM (4 dwords per lane) and the counters of the task after that
+// in flight while it transforms the current frame, so that only the first frame of a wave waits for HBM.
+template <class R>
+struct FrameTask {          // wave-uniform description of one due frame
+    const int16_t* car;     // this stream's carry
+    const int16_t* row;     // chunk that holds the frame's first new sample (u0)
+    float* ring_row;        // where the coefficients go
+    int vb, q, off0;        // first virtual sample; carry length; offset of vb in chunk u0 (negative: inside the carry)
+};
+
+// the rare PCM path (odd chunk lengths, unaligned buffers, chunks shorter than a frame): one sample at a time
+template <class R>
+__device__ __attribute__((noinline)) void fetch_frame_slow(const FrameTask<R>& f, int lane, int flen, int C, size_t update_stride, int (&raw)[4]) {
+    auto vsample = [&](int vv) -> int {
+        if (vv < f.q) return (int)f.car[vv];
+        int w = f.off0 + (vv - f.vb);
+        const int16_t* r = f.row;
+        while (w >= C) { w -= C; r += update_stride; }
+        return (int)r[w];
+    };
+    for (int a4 = 0; a4 < 4; ++a4) {
+        const int n = 2 * (lane + 64 * a4);
+        const int lo = n < flen ? (vsample(f.vb + n) & 0xffff) : 0;
+        const int hi = n + 1 < flen ? vsample(f.vb + n + 1) : 0;
+        raw[a4] = lo | (hi << 16);
+    }
+}
+
 template <class R>
 __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, const WaveTables<R>& wt, unsigned char* smem,
-                                                 const long long first_task, const long long task_stride) {
+                                                 const int first_task, const int task_stride) {
     using K = RealK<R>;
     const StreamGeom& geo = a.geo;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const pe_wave::Tab<R> tab = wave_tables_to_lds<R>(smem, wt);
-    __syncthreads();
-    R* S = reinterpret_cast<R*>(smem + wt.L.total) + (size_t)wave * kWaveScratchReals;
     const int n_kb = a.n_frame_rows;
-    const long long row_tasks = (long long)((geo.n_streams + kTileStreams - 1) / kTileStreams) * kTileStreams;
-    const long long n_tasks = row_tasks * n_kb;
+    const int row_tasks = ((geo.n_streams + kTileStreams - 1) / kTileStreams) * kTileStreams;
     const int C = a.chunk, hop = geo.hop, flen = geo.frame_len, slots = geo.ring_slots, U = a.n_updates;
     const size_t update_stride = (size_t)geo.n_streams * C;
-    for (long long task = first_task + wave; task < n_tasks; task += task_stride) {
-        // frame-row major: the rows few streams reach (second frame of an update) end up in the last tasks
-        const int kb = (int)(task / row_tasks);
-        const long long s = task - (long long)kb * row_tasks;
-        const int tile = (int)(s >> 4), j = (int)(s & 15);
-        if (s >= geo.n_streams) continue;
-        const int q = a.st_q[s];
-        const uint32_t kc = a.st_kc[s];
-        const int avail = q + U * C;
-        const int nnew = avail >= flen ? 1 + (avail - flen) / hop : 0;
-        const int f_first = nnew > slots ? nnew - slots : 0;   // older frames would be overwritten anyway
-        if (kb < f_first || kb >= nnew) continue;              // (wave-uniform: one task per wave)
-        const int16_t* car = a.carry + (size_t)s * kCarryCap;
-        const int16_t* base = a.pcm + (size_t)s * C;
-        const int vb = kb * hop;
-        pe_wave::Regs<R> v;
-        // dword loads of (even, odd) pairs: every quantity that shifts a pair boundary must be even, and a
-        // frame may cross at most one chunk boundary
-        const bool fast = a.pcm_pairs_ok && ((q | hop | C | flen) & 1) == 0 && (C >= flen || U == 1);
-        if (fast) {
-            const int w0 = vb - q;                              // < 0: the frame starts inside the carry
-            int u0 = 0, off0 = w0;
-            if (w0 >= 0) { u0 = w0 / C; off0 = w0 - u0 * C; }
-            const int16_t* rowu = base + (size_t)u0 * update_stride;
-            const ptrdiff_t wrap = (ptrdiff_t)update_stride - C;
-            int raw[4];
+    const ptrdiff_t wrap = (ptrdiff_t)update_stride - C;
+    // dword loads of (even, odd) sample pairs need every quantity that shifts a pair boundary to be even; a frame
+    // may cross at most one chunk boundary (always true for a single update: its samples are carry ++ one chunk)
+    const bool pairs = a.pcm_pairs_ok && ((hop | C | flen) & 1) == 0 && (C >= flen || U == 1);
+
+    // ---- task stream of this wave: (row kb, stream s), frame-row major (rows few streams reach come last);
+    //      the counters of the next task are requested one step ahead ---------------------------------------
+    int s_next = first_task + wave, kb_next = 0;
+    while (s_next >= row_tasks && kb_next < n_kb) { s_next -= row_tasks; ++kb_next; }
+    int pq = 0, pkc = 0;                                   // prefetched counters of the next task
+    auto request_counters = [&]() {
+        if (kb_next < n_kb && s_next < geo.n_streams) { pq = a.st_q[s_next]; pkc = (int)a.st_kc[s_next]; }
+    };
+    // advance to the next DUE frame of this wave's task sequence; false when the sequence is exhausted
+    auto next_frame = [&](FrameTask<R>& f) -> bool {
+        while (kb_next < n_kb) {
+            const int kb = kb_next, s = s_next;
+            const int q = __builtin_amdgcn_readfirstlane(pq);
+            const uint32_t kc = (uint32_t)__builtin_amdgcn_readfirstlane(pkc);
+            s_next += task_stride;
+            while (s_next >= row_tasks && kb_next < n_kb) { s_next -= row_tasks; ++kb_next; }
+            request_counters();
+            if (s >= geo.n_streams) continue;
+            const int avail = q + U * C;
+            const int nnew = avail >= flen ? 1 + (int)a.div_hop.div((uint32_t)(avail - flen)) : 0;
+            const int f_first = nnew > slots ? nnew - slots : 0;       // older frames would be overwritten anyway
+            if (kb < f_first || kb >= nnew) continue;
+            const int tile = s >> 4, j = s & 15;
+            f.car = a.carry + (size_t)s * kCarryCap;
+            f.vb = kb * hop; f.q = q;
+            const int w0 = f.vb - q;
+            int u0 = 0;
+            f.off0 = w0;
+            if (w0 >= 0 && U > 1) { u0 = (int)a.div_chunk.div((uint32_t)w0); f.off0 = w0 - u0 * C; }
+            f.row = a.pcm + (size_t)s * C + (size_t)u0 * update_stride;
+            const int slot = (int)((kc + (uint32_t)kb) & (uint32_t)(slots - 1));
+            f.ring_row = a.ring + (((size_t)tile * slots + slot) * kTileStreams + j) * kRowFloats;
+            return true;
+        }
+        return false;
+    };
+    // the frame's samples as int16 pairs: point n = lane + 64 a4 <-> samples 2n, 2n+1 (zero beyond the frame length)
+    auto request_pcm = [&](const FrameTask<R>& f, int (&raw)[4]) {
+        if (pairs && (f.q & 1) == 0) {
 #pragma unroll
             for (int a4 = 0; a4 < 4; ++a4) {
                 const int n = 2 * (lane + 64 * a4);
-                const int nn = n < flen ? n : 0;
-                const int vv = vb + nn, off = off0 + nn;
-                const int16_t* p = (vv < q) ? (car + vv) : (rowu + off + (off >= C ? wrap : 0));
-                raw[a4] = *reinterpret_cast<const int*>(p);
-                if (n >= flen) raw[a4] = 0;
-            }
-#pragma unroll
-            for (int a4 = 0; a4 < 4; ++a4) {
-                v.re[a4] = (R)(int)(short)(raw[a4] & 0xffff);
-                v.im[a4] = (R)(raw[a4] >> 16);
+                const int nn = n < flen ? n : 0;                       // clamped address, masked result: no branch
+                const int vv = f.vb + nn, off = f.off0 + nn;
+                const uintptr_t pc = reinterpret_cast<uintptr_t>(f.car + vv);
+                const uintptr_t pr = reinterpret_cast<uintptr_t>(f.row + off + (off >= C ? wrap : 0));
+                const int val = *reinterpret_cast<const int*>(vv < f.q ? pc : pr);
+                raw[a4] = n < flen ? val : 0;
             }
         } else {
-            auto vsample = [&](int vv) -> int {
-                if (vv < q) return (int)car[vv];
-                const int w = vv - q, u = w / C;
-                return (int)base[(size_t)u * update_stride + (w - u * C)];
-            };
-#pragma unroll
-            for (int a4 = 0; a4 < 4; ++a4) {
-                const int n = 2 * (lane + 64 * a4);
-                v.re[a4] = n < flen ? (R)vsample(vb + n) : R(0);
-                v.im[a4] = n + 1 < flen ? (R)vsample(vb + n + 1) : R(0);
-            }
+            fetch_frame_slow<R>(f, lane, flen, C, update_stride, raw);
         }
-        const R coeff = mfcc_wave_frame<R>(tab, S, lane, geo.n_filt, geo.n_mfcc, v, K::PSCALE_I16, geo.log_mode);
-        const int slot = (int)((kc + (uint32_t)kb) & (uint32_t)(slots - 1));
-        float* row = a.ring + (((size_t)tile * slots + slot) * kTileStreams + j) * kRowFloats;
-        const int c = lane >> 2;
-        if ((lane & 3) == 0) row[c] = c < geo.n_mfcc ? (float)coeff : 0.0f;
+    };
+
+    request_counters();
+    pe_wave::Tab<R> tab;
+    pe_wave::LaneConsts<R> lc;
+    R* const S = reinterpret_cast<R*>(smem + wt.L.total) + (size_t)wave * kWaveScratchReals;
+    const int c = lane >> 2;
+    pe_wave::Regs<R> v;
+    float* row_cur = nullptr;
+    int raw[4] = {0, 0, 0, 0};
+    bool have_cur = false, first = true;
+    for (;;) {
+        FrameTask<R> nxt;
+        const bool have_next = next_frame(nxt);
+        if (have_next) request_pcm(nxt, raw);              // lands while the current frame is transformed
+        if (first) {                                       // (the first request flies while the tables are copied to LDS)
+            tab = wave_tables_to_lds<R>(smem, wt);
+            __syncthreads();
+            lc = pe_wave::lane_consts(tab, lane);
+            first = false;
+        }
+        if (have_cur) {
+            const R coeff = mfcc_wave_frame<R>(tab, lc, S, lane, geo.n_filt, geo.n_mfcc, v, K::PSCALE_I16, geo.log_mode);
+            if ((lane & 3) == 0) row_cur[c] = c < geo.n_mfcc ? (float)coeff : 0.0f;
+        }
+        if (!have_next) break;
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4) {
+            v.re[a4] = (R)(int)(short)(raw[a4] & 0xffff);
+            v.im[a4] = (R)(raw[a4] >> 16);
+        }
+        row_cur = nxt.ring_row;
+        have_cur = true;
     }
 }
 
@@ -305,6 +362,7 @@ __device__ __forceinline__ void mfcc_offline_frames(const MfccOfflineArgs<R>& a,
     const pe_wave::Tab<R> tab = wave_tables_to_lds<R>(smem, wt);
     __syncthreads();
     R* S = reinterpret_cast<R*>(smem + wt.L.total) + (size_t)wave * kWaveScratchReals;
+    const pe_wave::LaneConsts<R> lc = pe_wave::lane_consts(tab, lane);
     const int flen = geo.frame_len;
     for (long long fr = (long long)blockIdx.x * waves + wave; fr < a.n_frames; fr += (long long)gridDim.x * waves) {
         const double* x = a.audio + fr * geo.hop;
@@ -315,7 +373,7 @@ __device__ __forceinline__ void mfcc_offline_frames(const MfccOfflineArgs<R>& a,
             v.re[a4] = n < flen ? (R)x[n] : R(0);
             v.im[a4] = n + 1 < flen ? (R)x[n + 1] : R(0);
         }
-        const R coeff = mfcc_wave_frame<R>(tab, S, lane, geo.n_filt, geo.n_mfcc, v, RealK<R>::INV_FFT, geo.log_mode);
+        const R coeff = mfcc_wave_frame<R>(tab, lc, S, lane, geo.n_filt, geo.n_mfcc, v, RealK<R>::INV_FFT, geo.log_mode);
         const int c = lane >> 2;
         if ((lane & 3) == 0) {
             if (a.out && c < geo.n_mfcc) a.out[fr * geo.n_mfcc + c] = (double)coeff;

@@ -30,6 +30,7 @@ constexpr int kBins = 257;
 constexpr int kMaxMelLen = 16;      // bins per lane in the mel pass
 constexpr int kMaxDctLen = 16;      // terms per lane in the DCT (n_filt <= 64)
 constexpr int kMaxFilt = 64;
+constexpr int kLogTab = 128;        // intervals of the mantissa in the table-driven float64 logarithm
 
 // per-wave LDS scratch, in reals: the exchange area [64 lanes][5] complex (stride 5: 80 / 40 bytes per lane, no
 // bank conflicts for 16 / 8-byte accesses), reused after the FFT for the power spectrum, the per-lane partial filter
@@ -49,7 +50,7 @@ static_assert(kLogMelOff + kMaxFilt + 1 <= kScratchReals, "scratch layout");
 PE_WAVE_HD inline int kbase_of(int l) { return (l >> 4) + 4 * ((l >> 2) & 3) + 16 * (l & 3); }
 
 struct Layout {          // byte offsets into the blob (16-byte aligned sections)
-    int tw1, tw2, tw3, w512, mel_w, dct_w, mel_start, pstart, partner, total;
+    int tw1, tw2, tw3, w512, logtab, mel_w, dct_w, mel_start, pstart, partner, total;
     int mel_len, dct_len, np_max;
 };
 
@@ -62,6 +63,7 @@ inline Layout layout(int real_size, int mel_len, int dct_len, int np_max) {
     L.tw2 = off; off += 3 * 16 * 2 * real_size;
     L.tw3 = off; off += 3 * 4 * 2 * real_size;
     L.w512 = off; off += 2 * 64 * 2 * real_size;
+    L.logtab = off; off += (real_size == 8 ? kLogTab : 0) * 2 * real_size;       // float64 only (float uses logf)
     L.mel_w = off; off += mel_len * 64 * real_size;
     L.dct_w = off; off += dct_len * 64 * real_size;
     off = align16(off);
@@ -129,6 +131,15 @@ std::string build(const double* mel_filters, int n_filt, int n_mfcc, std::vector
         for (int j = 0; j < 2; ++j) put_c(L.w512, j * 64 + l, -2.0 * PI * (double)(kb + 64 * j) / 512.0);
         put_i(L.partner, l, kb == 0 ? 0 : lane_of_kbase[64 - kb]);
     }
+    // table-driven logarithm (float64): interval i of the mantissa m in [0.5, 1) has centre c_i = (128.5 + i) / 256;
+    // the table holds 1 / c_i (rounded) and -log of THAT rounded value, so log m = logc_i + log1p(m / c_i - 1) exactly
+    if (sizeof(R) == 8)
+        for (int i = 0; i < kLogTab; ++i) {
+            const double inv_c = 256.0 / (128.5 + (double)i);
+            const long double logc = -std::log((long double)inv_c);
+            R v[2] = {(R)inv_c, (R)logc};
+            std::memcpy(blob.data() + L.logtab + (size_t)i * 2 * sizeof(R), v, sizeof v);
+        }
     // mel runs: lane reads P[start .. start + mel_len), fully inside [0, 257)
     for (int l = 0; l < 64; ++l) {
         int start = seg_lo[l];

@@ -27,6 +27,28 @@ struct WaveTables {
     pe_wave::Layout L;
 };
 
+// x / d for 0 <= x < 2^31 and a divisor known on the host: one multiply-high and a shift
+struct FastDiv {
+    uint32_t mul; int shift;
+    __host__ static FastDiv make(uint32_t d) {
+        FastDiv f{0u, 0};
+        if (d <= 1) { f.mul = 0u; f.shift = -1; return f; }            // x / 1 = x
+        int l = 0;
+        while ((1u << l) < d) ++l;                                       // l = ceil(log2 d) >= 1
+        f.mul = (uint32_t)((((uint64_t)1 << (31 + l)) + d - 1) / d);     // ceil(2^(31+l) / d) < 2^32 since d > 2^(l-1)
+        f.shift = l - 1;
+        return f;
+    }
+    __host__ __device__ uint32_t div(uint32_t x) const {
+        if (shift < 0) return x;
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __umulhi(x, mul) >> shift;
+#else
+        return (uint32_t)(((uint64_t)x * mul) >> 32) >> shift;
+#endif
+    }
+};
+
 struct StreamGeom {
     int n_streams;
     int window;       // samples past a frame's start that make it visible: window_samples (+ hop for speechpy)
@@ -59,6 +81,7 @@ struct MfccStreamArgs {
     // several updates per launch (mfcc_many_tile): chunk u of stream s at pcm + (u*n_streams + s)*chunk
     int n_updates;
     int n_frame_rows;       // frame tasks per stream: the most frames one stream can complete in this call
+    FastDiv div_hop, div_chunk;   // division by hop_samples / by the chunk length
     int16_t* carry_next;    // leftover after the call; must not alias carry
     uint32_t* ke_hist;      // [n_updates][n_padded] emitted-frame counter after every update
     int n_padded;

@@ -57,11 +57,13 @@ static int run(int n_filt, int n_mfcc, int log_mode, const char* ffilt, const ch
                 }
             for (int l = 0; l < 64; ++l) v[l] = o[l];
         };
-        for (int l = 0; l < 64; ++l) pass_a(v[l], l, t);
+        LaneConsts<R> lc[64];
+        for (int l = 0; l < 64; ++l) lc[l] = lane_consts(t, l);
+        for (int l = 0; l < 64; ++l) pass_a(v[l], lc[l]);
         exchange(4);
-        for (int l = 0; l < 64; ++l) pass_b(v[l], l, t);
+        for (int l = 0; l < 64; ++l) pass_b(v[l], lc[l]);
         exchange(2);
-        for (int l = 0; l < 64; ++l) pass_c(v[l], l, t);
+        for (int l = 0; l < 64; ++l) pass_c(v[l], lc[l]);
         exchange(0);
         for (int l = 0; l < 64; ++l) pass_d(v[l]);
         // mirror exchange through the scratch, as the kernel does it
@@ -76,7 +78,7 @@ static int run(int n_filt, int n_mfcc, int log_mode, const char* ffilt, const ch
         R lane_sum[64];
         for (int l = 0; l < 64; ++l) {
             R pw[4]; int bins[4];
-            split_power(v[l], zq0[l], zq1[l], t.w512[l], t.w512[64 + l], pscale * (R)0.25, pw);
+            split_power(v[l], zq0[l], zq1[l], lc[l].w512[0], lc[l].w512[1], pscale * (R)0.25, pw);
             power_bins(l, bins);
             for (int j = 0; j < 4; ++j) P[bins[j]] = pw[j];
             lane_sum[l] = (pw[0] + pw[1]) + (pw[2] + pw[3]);
@@ -87,8 +89,8 @@ static int run(int n_filt, int n_mfcc, int log_mode, const char* ffilt, const ch
         for (int l = 0; l < 64; ++l) PART[l] = mel_run(t, P, l);
         R lm[65];
         auto safe = [&](R x) { return log_mode == 0 ? (x > EPS ? x : EPS) : (x == (R)0 ? EPS : x); };
-        for (int f = 0; f < n_filt; ++f) lm[f] = (R)std::log((double)safe(filter_sum(t, PART, f)));
-        lm[n_filt] = (R)std::log((double)safe(lane_sum[0]));
+        for (int f = 0; f < n_filt; ++f) lm[f] = wave_log(safe(filter_sum(t, PART, f)), t.logtab);
+        lm[n_filt] = wave_log(safe(lane_sum[0]), t.logtab);
         for (int f = 0; f <= n_filt; ++f) LM[f] = lm[f];
         R part[64];
         for (int l = 0; l < 64; ++l) part[l] = dct_run(t, LM, l, n_filt);
