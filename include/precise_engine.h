@@ -204,6 +204,14 @@ int pe_get_stream_state(pe_engine* e, int32_t* q_out, uint32_t* computed_out, ui
  * and network roles run concurrently inside ONE launch; 0 = always two dependent launches. */
 int pe_set_fused(pe_engine* e, int32_t enabled);
 
+/* Input projections: 1 = the MFCC stage stores x.W + b of every frame beside its feature row (256 bytes per frame and
+ * stream) and the network starts each timestep from that row instead of recomputing the projection in each of the
+ * n_features windows a frame appears in (16 of its 41 MFMAs per timestep); 0 = recompute.  Default: on for the
+ * float32 network of 17..20 units without delta features while the engine has <= 16384 streams (the rows stay
+ * cache-resident).  Both settings agree to float32 rounding (different summation order), each is deterministic;
+ * changing the setting restarts all streams. */
+int pe_set_input_projection(pe_engine* e, int32_t enabled);
+
 /* Network kernel shape: 0 (default) = automatic (four waves share each 16-stream tile while the
  * engine has no more tiles than the device has compute units -- 256 on MI355X, i.e. 4096 streams -- one wave
  * per tile beyond; use_delta networks always take the one-wave kernel), 1 / 4 = forced.  Results are identical. */

@@ -75,6 +75,7 @@ EXPORTS = {
     'pe_get_stream_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pe_set_fused': (C.c_int, [C.c_void_p, C.c_int32]),
     'pe_set_gru_waves': (C.c_int, [C.c_void_p, C.c_int32]),
+    'pe_set_input_projection': (C.c_int, [C.c_void_p, C.c_int32]),
     'pe_set_timing': (C.c_int, [C.c_void_p, C.c_int32]),
     'pe_get_last_timing': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
@@ -360,6 +361,10 @@ class HipEngine:
 
     def set_fused(self, enabled: bool):
         self._check(self._lib.pe_set_fused(self._h, int(bool(enabled))))
+
+    def set_input_projection(self, enabled: bool):
+        """Store x.W + b per frame beside the feature ring (True) or recompute it in the network (False); restarts the streams."""
+        self._check(self._lib.pe_set_input_projection(self._h, int(bool(enabled))))
 
     def set_gru_waves(self, waves: int):
         self._check(self._lib.pe_set_gru_waves(self._h, int(waves)))

@@ -51,6 +51,11 @@ struct pe_engine {
     int gru_waves = 0;      // 0 = auto (4 waves per tile while tiles <= CUs, else 1), or forced 1 / 4
     int n_cus = 256;        // compute units of the device (MI355X: 256)
     float* ring = nullptr;
+    // input projections x.W + b of every frame beside its feature row (stock-width float32 network, <= kProjMaxTiles
+    // tiles): written once by the MFCC stage, read by the network instead of 16 of its 41 MFMAs per timestep
+    float* proj_ring = nullptr;
+    bool proj_ok = false, proj_on = false;
+    std::vector<float> proj_w_host, proj_b_host;
     // several updates per call (pe_reserve_updates / pe_update_many*)
     int max_updates = 1;
     uint32_t* ke_hist = nullptr;
@@ -139,10 +144,13 @@ int ensure(pe_engine* e, DeviceBuf& b, size_t bytes) {
 
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+constexpr int kProjMaxTiles = 1024;      // input-projection rows are kept up to 16384 streams per engine (134 MB at 32 slots)
+
 template <class R>
 int build_tables(pe_engine* e, const double* mel_filters) {
     std::vector<unsigned char> blob;
-    const std::string err = pe_wave::build<R>(mel_filters, e->prm.n_filt, e->prm.n_mfcc, blob, e->table_layout);
+    const std::string err = pe_wave::build<R>(mel_filters, e->prm.n_filt, e->prm.n_mfcc, blob, e->table_layout,
+                                              e->proj_ok ? e->proj_w_host.data() : nullptr, e->proj_ok ? e->proj_b_host.data() : nullptr);
     if (!err.empty()) return fail(e, PE_ERR_UNSUPPORTED, "%s", err.c_str());
     return dev_upload(e, &e->table_blob, blob);
 }
@@ -187,6 +195,21 @@ int pack_gru_weights(pe_engine* e, const pe_gru_layer& L, const float* dense_ker
             const int u = 4 * rho + (lane >> 4);
             if (u < H) wd[(size_t)rho * 64 + lane] = dense_kernel[u];
         }
+    // input-projection rows (mfcc_wave_device.h epilogue): element o = 16 g + 4 tile + q of a row is accumulator q of
+    // output tile `tile` in lane group g, i.e. slot 4 tile + q, unit 4 rho + g
+    if (NT <= 4 && !delta) {
+        e->proj_w_host.assign((size_t)F * kProjRow, 0.f);
+        e->proj_b_host.assign(kProjRow, 0.f);
+        for (int o = 0; o < kProjRow; ++o) {
+            const int g = o >> 4, tile = (o >> 2) & 3, q = o & 3;
+            const int slot = 4 * tile + q;
+            const int gate = slot / R, rho = slot % R, u = 4 * rho + g;
+            if (tile >= NT || slot >= 3 * R || u >= H) continue;
+            const int col = gate * H + u;
+            e->proj_b_host[o] = L.bias[col];
+            for (int c = 0; c < F; ++c) e->proj_w_host[(size_t)c * kProjRow + o] = L.kernel[(size_t)c * 3 * H + col];
+        }
+    }
     int rc;
     if ((rc = dev_upload(e, &e->wx, wx))) return rc;
     if ((rc = dev_upload(e, &e->wxd, wxd))) return rc;
@@ -349,6 +372,7 @@ MfccStreamArgs<R> mfcc_args(const pe_engine* e, const int16_t* pcm_dev, int chun
     a.st_q = e->st_q[c]; a.st_kc = e->st_kc[c]; a.st_ke = e->st_ke[c];
     a.st_q_next = e->st_q[n]; a.st_kc_next = e->st_kc[n]; a.st_ke_next = e->st_ke[n];
     a.ring = e->ring;
+    a.proj_ring = e->proj_on ? e->proj_ring : nullptr;
     a.n_updates = 1; a.ke_hist = nullptr; a.n_padded = e->n_padded;
     a.n_frame_rows = max_frames_per_call(e, chunk); a.carry_next = e->carry_alt;
     a.div_hop = FastDiv::make((uint32_t)e->prm.hop_samples);
@@ -382,6 +406,7 @@ GruArgs gru_args(const pe_engine* e) {
     a.wx = e->wx; a.wr1 = e->wr1; a.wr2 = e->wr2; a.bias = e->bias; a.wd = e->wd;
     a.dense_bias = e->dense_bias;
     a.ring = e->ring; a.st_ke = e->st_ke[e->cur]; a.ring_slots = e->ring_slots;
+    a.proj_ring = e->proj_on ? e->proj_ring : nullptr;
     a.predict_ke = 0;
     a.st_q = e->st_q[e->cur]; a.st_kc = e->st_kc[e->cur];
     a.chunk = 0;
@@ -546,11 +571,16 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         }
         if (rc) break;
         if ((rc = dev_alloc(e, &e->ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kRowFloats))) break;
-        rc = (p->mfcc_precision == 0) ? build_tables<double>(e, mel_filters) : build_tables<float>(e, mel_filters);
-        if (rc) break;
         if (wide) { if ((rc = pack_gru_weights_wide(e, w))) break; }
         else if ((rc = pack_gru_weights(e, L, w->dense_kernel))) break;
         if (p->gru_precision == 1 && (rc = pack_gru_weights_bf16(e, L, w->dense_kernel))) break;
+        // the projection rows exist for the stock-width float32 network (3 R <= 16 slots: 4 output tiles, R = 5) fed
+        // from the ring; they pay while the ring stays cache-resident (256 B per frame and stream)
+        e->proj_ok = !wide && p->gru_precision == 0 && !p->use_delta && gru_small_regs(L.units) == 5 && !e->proj_w_host.empty();
+        e->proj_on = e->proj_ok && e->n_tiles <= kProjMaxTiles;
+        rc = (p->mfcc_precision == 0) ? build_tables<double>(e, mel_filters) : build_tables<float>(e, mel_filters);
+        if (rc) break;
+        if (e->proj_on && (rc = dev_alloc(e, &e->proj_ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kProjRow))) break;
         for (auto& ev : e->ev)
             if (hipEventCreate(&ev) != hipSuccess) { rc = fail(e, PE_ERR_HIP, "hipEventCreate failed"); break; }
         if (rc) break;
@@ -590,7 +620,9 @@ int pe_clear(pe_engine* e, const uint8_t* mask_host) {
         PE_HIP(e, hipMemcpy(e->st_mask.p, mask_host, (size_t)e->n_streams, hipMemcpyHostToDevice));
         mask_dev = static_cast<const uint8_t*>(e->st_mask.p);
     }
-    ClearArgs a{e->n_padded, e->ring_slots, mask_dev, e->st_q[e->cur], e->st_kc[e->cur], e->st_ke[e->cur], e->ring, e->activation};
+    ClearArgs a{e->n_padded, e->ring_slots, mask_dev, e->st_q[e->cur], e->st_kc[e->cur], e->st_ke[e->cur], e->ring, e->activation,
+                e->proj_on ? e->proj_ring : nullptr,
+                e->proj_on ? reinterpret_cast<const float*>(e->table_blob + e->table_layout.proj_b) : nullptr};
     if (mask_dev) a.n_streams = e->n_streams;
     PE_HIP(e, launch_clear(a, nullptr));
     PE_HIP(e, hipStreamSynchronize(nullptr));
@@ -670,6 +702,10 @@ int pe_set_vectors(pe_engine* e, const float* feats_host) {
     PE_HIP(e, hipMemcpy(e->st_feats.p, feats_host, feat_bytes, hipMemcpyHostToDevice));
     GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->ring, e->st_ke[e->cur], static_cast<float*>(e->st_feats.p)};
     PE_HIP(e, launch_scatter(g, e->st_q[e->cur], e->st_kc[e->cur], nullptr));
+    if (e->proj_on)
+        PE_HIP(e, launch_project_rows(e->ring, e->proj_ring, reinterpret_cast<const float*>(e->table_blob + e->table_layout.proj_w),
+                                      reinterpret_cast<const float*>(e->table_blob + e->table_layout.proj_b), e->prm.n_mfcc,
+                                      (long long)e->n_tiles * e->ring_slots * kTileStreams, nullptr));
     PE_HIP(e, hipStreamSynchronize(nullptr));
     return PE_OK;
 }
@@ -857,9 +893,12 @@ int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samp
     if (slots != e->ring_slots) {
         dev_free(e, e->ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kRowFloats * sizeof(float));
         e->ring = nullptr;
+        dev_free(e, e->proj_ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kProjRow * sizeof(float));
+        e->proj_ring = nullptr;
         e->ring_slots = slots;
         int rc = dev_alloc(e, &e->ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kRowFloats);
         if (rc) return rc;
+        if (e->proj_on && (rc = dev_alloc(e, &e->proj_ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kProjRow))) return rc;
     }
     if (!e->ke_hist || max_updates > e->max_updates) {
         if (e->ke_hist) {
@@ -952,6 +991,21 @@ int pe_set_fused(pe_engine* e, int32_t enabled) {
     if (!e) return PE_ERR_INVALID;
     e->fused = enabled != 0;
     return PE_OK;
+}
+
+int pe_set_input_projection(pe_engine* e, int32_t enabled) {
+    if (!e) return PE_ERR_INVALID;
+    if (enabled != 0 && enabled != 1) return fail(e, PE_ERR_INVALID, "input projection must be 0 or 1");
+    if (enabled && !e->proj_ok) return fail(e, PE_ERR_UNSUPPORTED, "input-projection rows exist for the float32 network of 17..20 units without delta features only");
+    if ((enabled != 0) == e->proj_on) return PE_OK;
+    PE_HIP(e, hipSetDevice(e->device));
+    PE_HIP(e, hipDeviceSynchronize());
+    e->proj_on = enabled != 0;
+    if (e->proj_on && !e->proj_ring) {
+        int rc = dev_alloc(e, &e->proj_ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kProjRow);
+        if (rc) { e->proj_on = false; return rc; }
+    }
+    return pe_clear(e, nullptr);          // rows written so far lack (or no longer need) their projections: streams restart
 }
 
 int pe_set_gru_waves(pe_engine* e, int32_t waves) {

@@ -57,10 +57,20 @@ enum GruInput {
                     // [w*stride, w*stride + T)                               (simulate.py:92-104)
 };
 
+// Address of the input-projection row of (tile, stream j) for lane group g; slot `s` of the ring is
+// s * kTileStreams * kProjRow floats further.  Row layout [g][output tile][q]: a lane's 4 accumulators of tile tl are
+// one float4 at +4 tl.
+__device__ __forceinline__ const float* proj_base(const GruArgs& a, int tile, int j, int g) {
+    return a.proj_ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kProjRow + 16 * g;
+}
+
 // One wave = one tile of 16 streams, whole window, weights resident in registers.
-template <int R, int MODE>
+// PROJ: every timestep starts from the input projection x.W + b that the MFCC stage stored beside the feature row
+// (a.proj_ring), instead of recomputing it with 4 MFMAs per output tile.
+template <int R, int MODE, bool PROJ = false>
 __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const int lane) {
     constexpr bool FROM_RING = MODE == kRing;
+    static_assert(!PROJ || (MODE == kRing && GruShape<R>::NT <= 4), "projection rows hold 4 output tiles");
     using G = GruShape<R>;
     const int g = lane >> 4, j = lane & 15;
     const long long stream = (long long)tile * kTileStreams + j;
@@ -151,19 +161,36 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
 #pragma unroll
     for (int rho = 0; rho < R; ++rho) h[rho] = 0.f;
 
-    f32x4 x = load_x(0);
+    const float* pbase = PROJ ? proj_base(a, tile, j, g) : nullptr;
+    auto load_p = [&](int t, f32x4 (&p)[G::NT]) {
+        const int tc = t < T ? t : T - 1;
+        const uint32_t slot = (first + (uint32_t)tc) & mask;
+        const f32x4* q = reinterpret_cast<const f32x4*>(pbase + (size_t)slot * kTileStreams * kProjRow);
+#pragma unroll
+        for (int tl = 0; tl < G::NT; ++tl) p[tl] = q[tl];
+    };
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pn[G::NT];
+    if (PROJ) load_p(0, pn); else x = load_x(0);
     f32x4 xprev = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < T; ++t) {
-        const f32x4 xn = load_x(t + 1);      // prefetch next timestep's features
+        f32x4 xn = {0.f, 0.f, 0.f, 0.f};
         f32x4 acc[G::NT];
-        // input projection, bias as the initial accumulator
+        if (PROJ) {
 #pragma unroll
-        for (int tl = 0; tl < G::NT; ++tl) {
-            acc[tl] = mfma(wx[tl][0], x[0], bias[tl]);
+            for (int tl = 0; tl < G::NT; ++tl) acc[tl] = pn[tl];
+            load_p(t + 1, pn);                   // prefetch next timestep's projections
+        } else {
+            xn = load_x(t + 1);                  // prefetch next timestep's features
+            // input projection, bias as the initial accumulator
 #pragma unroll
-            for (int kk = 1; kk < 4; ++kk) acc[tl] = mfma(wx[tl][kk], x[kk], acc[tl]);
+            for (int tl = 0; tl < G::NT; ++tl) {
+                acc[tl] = mfma(wx[tl][0], x[0], bias[tl]);
+#pragma unroll
+                for (int kk = 1; kk < 4; ++kk) acc[tl] = mfma(wx[tl][kk], x[kk], acc[tl]);
+            }
         }
-        if (delta) {
+        if (delta && !PROJ) {
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
             if (MODE == kFeats) d = load_d(t);
             else if (t > 0) d = x - xprev;
@@ -226,11 +253,12 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
 // the candidates travel from LDS.
 // (A five-wave variant with one wave per (tile, phase) role measured the same 21 us stand-alone
 // but needs 320-thread workgroups, which halves the residency of the fused launch: rejected.)
-template <int R>
+template <int R, bool PROJ = false>
 __device__ __forceinline__ void gru_tile_mw(const GruArgs& a, const int tile, const int wave, const int lane,
                                             float* S /* [3R][64] floats of LDS */) {
     using G = GruShape<R>;
     constexpr int MAXT = (G::NT + 3) / 4;
+    static_assert(!PROJ || MAXT == 1, "projection rows hold 4 output tiles");
     const int g = lane >> 4, j = lane & 15;
     const long long stream = (long long)tile * kTileStreams + j;
     const bool valid = stream < a.n_streams;
@@ -272,15 +300,19 @@ __device__ __forceinline__ void gru_tile_mw(const GruArgs& a, const int tile, co
     const uint32_t first = ke - (uint32_t)T;
     const uint32_t mask = (uint32_t)(a.ring_slots - 1);
     const float* xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats + 4 * g;
+    const float* pbase = PROJ ? proj_base(a, tile, j, g) + 4 * (wave < G::NT ? wave : 0) : nullptr;
     auto load_x = [&](int t) -> f32x4 {
         const int tc = t < T ? t : T - 1;
         const uint32_t slot = (first + (uint32_t)tc) & mask;
+        if (PROJ) return *reinterpret_cast<const f32x4*>(pbase + (size_t)slot * kTileStreams * kProjRow);
         return *reinterpret_cast<const f32x4*>(xbase + (size_t)slot * kTileStreams * kRowFloats);
     };
+    // the accumulators a timestep starts from: x.W + b, computed here or (PROJ) fetched as stored by the MFCC stage
     auto xproj = [&](const f32x4& x, f32x4 (&acc)[MAXT]) {
 #pragma unroll
         for (int i = 0; i < MAXT; ++i) {
             if (!own[i]) continue;
+            if (PROJ) { acc[i] = x; continue; }
             acc[i] = mfma(wx[i][0], x[0], bias[i]);
 #pragma unroll
             for (int kk = 1; kk < 4; ++kk) acc[i] = mfma(wx[i][kk], x[kk], acc[i]);
@@ -354,6 +386,7 @@ __device__ __forceinline__ void gru_tile_mw(const GruArgs& a, const int tile, co
 // theirs while waves 2/3 run phase 2; wave 3, idle during phase 1, computes its own AND tile 2's and
 // hands the latter to wave 2 through LDS.  What stays serial per timestep is two 5-MFMA chains and
 // two LDS hand-offs.
+template <bool PROJ>
 __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, const int wave, const int lane,
                                              float* S /* [15][64] gate slots + [64][4] tile-2 projection */) {
     constexpr int R = 5;
@@ -394,13 +427,18 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
     }
     const uint32_t first = ke - (uint32_t)T;
     const uint32_t mask = (uint32_t)(a.ring_slots - 1);
-    const float* xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats + 4 * g;
+    // what a wave fetches per timestep: the feature row (4 features per lane) -- or, PROJ, the input projection of
+    // ITS OWN output tile as the MFCC stage stored it (then no wave computes projections and nothing is handed over)
+    const float* xbase = PROJ ? proj_base(a, tile, j, g) + 4 * wave
+                              : a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats + 4 * g;
+    const size_t xstride = (size_t)kTileStreams * (PROJ ? kProjRow : kRowFloats);
     auto load_x = [&](int t) -> f32x4 {
         const int tc = t < T ? t : T - 1;
         const uint32_t slot = (first + (uint32_t)tc) & mask;
-        return *reinterpret_cast<const f32x4*>(xbase + (size_t)slot * kTileStreams * kRowFloats);
+        return *reinterpret_cast<const f32x4*>(xbase + (size_t)slot * xstride);
     };
     auto xproj = [&](const float (&w)[4], const f32x4& b, const f32x4& x) -> f32x4 {
+        if (PROJ) return x;
         f32x4 acc = mfma(w[0], x[0], b);
 #pragma unroll
         for (int kk = 1; kk < 4; ++kk) acc = mfma(w[kk], x[kk], acc);
@@ -422,8 +460,10 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
         if (wave == 3) {
             // phase 1 of the others: projections of timestep t+1 for tile 3 (own) and tile 2 (wave 2's)
             const f32x4 an = xproj(wx, bias, x1);
-            const f32x4 a2 = xproj(wx2, bias2, x1);
-            *reinterpret_cast<f32x4*>(X2 + lane * 4) = a2;
+            if (!PROJ) {
+                const f32x4 a2 = xproj(wx2, bias2, x1);
+                *reinterpret_cast<f32x4*>(X2 + lane * 4) = a2;
+            }
             x1 = load_x(t + 2);
             lds_barrier();                                           // A
             float rr[R];
@@ -444,7 +484,9 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
             float rr[R];
 #pragma unroll
             for (int rho = 0; rho < R; ++rho) { z[rho] = Sl[rho * 64]; rr[rho] = Sl[(R + rho) * 64]; }
-            const f32x4 an = *reinterpret_cast<const f32x4*>(X2 + lane * 4);
+            f32x4 an;
+            if (PROJ) { an = x1; x1 = load_x(t + 2); }
+            else an = *reinterpret_cast<const f32x4*>(X2 + lane * 4);
 #pragma unroll
             for (int rho = 0; rho < R; ++rho) acc = mfma(wrB[rho], rr[rho] * h[rho], acc);
             Sl[10 * 64] = acc[2]; Sl[11 * 64] = acc[3];
@@ -480,10 +522,10 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
     }
 }
 
-template <int R>
+template <int R, bool PROJ = false>
 __device__ __forceinline__ void gru_tile_mw_any(const GruArgs& a, const int tile, const int wave, const int lane, float* S) {
-    if constexpr (R == 5) gru_tile_mw5(a, tile, wave, lane, S);
-    else gru_tile_mw<R>(a, tile, wave, lane, S);
+    if constexpr (R == 5) gru_tile_mw5<PROJ>(a, tile, wave, lane, S);
+    else gru_tile_mw<R, PROJ>(a, tile, wave, lane, S);
 }
 
 }  // namespace pe

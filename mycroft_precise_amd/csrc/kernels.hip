@@ -13,30 +13,28 @@ namespace pe {
 #ifndef PE_FRAME_WPE
 #define PE_FRAME_WPE 4          // waves per SIMD the frame role is compiled for (<= 128 VGPRs)
 #endif
+// workgroups [0, n_frame_blocks): frame tasks; the rest: one bookkeeping workgroup per tile (they read what the
+// frame tasks read and write elsewhere, so the two roles share a launch)
 template <class R>
-__global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void mfcc_frames_kernel(const MfccStreamArgs<R> a, const WaveTables<R> t) {
+__global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void mfcc_kernel(const MfccStreamArgs<R> a, const WaveTables<R> t, const int n_frame_blocks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    mfcc_frame_tasks<R>(a, t, smem, (int)blockIdx.x * kFrameWaves, (int)gridDim.x * kFrameWaves);
-}
-
-template <class R>
-__global__ __launch_bounds__(256) void mfcc_book_kernel(const MfccStreamArgs<R> a) {
-    mfcc_book_tile<R>(a, blockIdx.x);
+    if ((int)blockIdx.x < n_frame_blocks) mfcc_frame_tasks<R>(a, t, smem, (int)blockIdx.x * kFrameWaves, n_frame_blocks * kFrameWaves);
+    else mfcc_book_tile<R>(a, (int)blockIdx.x - n_frame_blocks);
 }
 
 // network for a whole batch of updates: workgroup (one wave) b serves update b / n_tiles, tile b % n_tiles
-template <int R>
+template <int R, bool PROJ>
 __global__ __launch_bounds__(64) void gru_many_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
     const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
     GruArgs b = a;
     b.st_ke = a.st_ke + (size_t)u * n_padded;
     b.out = a.out + (size_t)u * a.n_streams;
     b.predict_ke = 0;
-    gru_tile<R, kRing>(b, tile, threadIdx.x);
+    gru_tile<R, kRing, PROJ>(b, tile, threadIdx.x);
 }
 
 // same, four waves sharing each (update, tile) -- few tiles per SIMD: latency matters more than issue slots
-template <int R>
+template <int R, bool PROJ>
 __global__ __launch_bounds__(256) void gru_many_mw_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
     __shared__ __attribute__((aligned(16))) float S[3 * R * 64 + 256];
     const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
@@ -45,7 +43,7 @@ __global__ __launch_bounds__(256) void gru_many_mw_kernel(const GruArgs a, const
     b.out = a.out + (size_t)u * a.n_streams;
     b.predict_ke = 0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    gru_tile_mw_any<R>(b, tile, wave, threadIdx.x & 63, S);
+    gru_tile_mw_any<R, PROJ>(b, tile, wave, threadIdx.x & 63, S);
 }
 
 __global__ __launch_bounds__(64) void gru_many_bf16_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
@@ -64,9 +62,9 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
 }
 
 // ---- GRU: one wave per 16-stream tile ----------------------------------------------------------
-template <int R, int MODE>
+template <int R, int MODE, bool PROJ = false>
 __global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
-    gru_tile<R, MODE>(a, blockIdx.x, threadIdx.x);
+    gru_tile<R, MODE, PROJ>(a, blockIdx.x, threadIdx.x);
 }
 
 // ---- wide / stacked GRU: one workgroup per 16-stream tile, weights streamed from L2 -------------------
@@ -131,11 +129,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
 }
 
 // ---- GRU: four waves per 16-stream tile (few tiles: fills all four SIMDs of a CU) -----------------
-template <int R>
+template <int R, bool PROJ = false>
 __global__ __launch_bounds__(256) void gru_mw_kernel(const GruArgs a) {
     __shared__ __attribute__((aligned(16))) float S[3 * R * 64 + 256];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    gru_tile_mw_any<R>(a, blockIdx.x, wave, threadIdx.x & 63, S);
+    gru_tile_mw_any<R, PROJ>(a, blockIdx.x, wave, threadIdx.x & 63, S);
 }
 
 // ---- fused update: GRU role || MFCC frame role || bookkeeping role in ONE launch -------------------------------
@@ -143,7 +141,7 @@ __global__ __launch_bounds__(256) void gru_mw_kernel(const GruArgs a) {
 // are dispatched first: the long pole); the next n_frame_blocks compute this update's MFCC frames, one frame task
 // per wave; the last n_tiles move the leftover samples and the counters.  MW = true: one GRU workgroup per tile,
 // its four waves share the tile (gru_tile_mw); MW = false: four tiles per GRU workgroup, one wave each.
-template <class R, int RG, bool MW>
+template <class R, int RG, bool MW, bool PROJ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
                                                            const int n_gru_blocks, const int n_frame_blocks, const int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -151,10 +149,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
     if (b < n_gru_blocks) {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         if (MW) {
-            gru_tile_mw_any<RG>(g, b, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
+            gru_tile_mw_any<RG, PROJ>(g, b, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
         } else {
             const int tile = b * 4 + wave;
-            if (tile < n_tiles) gru_tile<RG, kRing>(g, tile, threadIdx.x & 63);
+            if (tile < n_tiles) gru_tile<RG, kRing, PROJ>(g, tile, threadIdx.x & 63);
         }
     } else if (b < n_gru_blocks + n_frame_blocks) {
         mfcc_frame_tasks<R>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
@@ -178,8 +176,8 @@ template <class R>
 static hipError_t launch_mfcc(const MfccStreamArgs<R>& a, const WaveTables<R>& t, int n_cus, hipStream_t s) {
     const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
     const long long n_tasks = (long long)tiles * kTileStreams * a.n_frame_rows;
-    hipLaunchKernelGGL(mfcc_frames_kernel<R>, dim3(frame_blocks(n_tasks, n_cus)), dim3(64 * kFrameWaves), frame_lds(t), s, a, t);
-    hipLaunchKernelGGL(mfcc_book_kernel<R>, dim3(tiles), dim3(256), 0, s, a);      // reads what the frames read, writes elsewhere
+    const int fb = frame_blocks(n_tasks, n_cus);
+    hipLaunchKernelGGL(mfcc_kernel<R>, dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
     return hipGetLastError();
 }
 hipError_t launch_mfcc_f64(const MfccStreamArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s) { return launch_mfcc<double>(a, t, n_cus, s); }
@@ -201,6 +199,13 @@ template <int R>
 static hipError_t launch_r(const GruArgs& a, int mode, hipStream_t s) {
     const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
     if (tiles == 0) return hipSuccess;
+    if constexpr (R == 5) {
+        if (mode == kRing && a.proj_ring) {
+            if (a.waves_per_tile == 4) hipLaunchKernelGGL((gru_mw_kernel<R, true>), dim3(tiles), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((gru_small_kernel<R, kRing, true>), dim3(tiles), dim3(64), 0, s, a);
+            return hipGetLastError();
+        }
+    }
     if (mode == kRing && a.waves_per_tile == 4) hipLaunchKernelGGL((gru_mw_kernel<R>), dim3(tiles), dim3(256), 0, s, a);
     else if (mode == kRing) hipLaunchKernelGGL((gru_small_kernel<R, kRing>), dim3(tiles), dim3(64), 0, s, a);
     else if (mode == kRows) hipLaunchKernelGGL((gru_small_kernel<R, kRows>), dim3(tiles), dim3(64), 0, s, a);
@@ -235,10 +240,16 @@ static hipError_t launch_many_r(const GruArgs& a, int n_updates, int n_padded, h
     const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
     // up to ~1.5 windows per SIMD the four-wave kernel wins (4096 streams x 4 updates: 18.1 vs 20.1 us per
     // update), from 2 per SIMD on the one-wave kernel does (x 16: 12.5 vs 14.0)
-    if ((long long)tiles * n_updates <= 1536 && !a.use_delta)      // (the delta inputs: one-wave kernel only)
-        hipLaunchKernelGGL((gru_many_mw_kernel<R>), dim3(tiles * n_updates), dim3(256), 0, s, a, tiles, n_padded);
-    else
-        hipLaunchKernelGGL((gru_many_kernel<R>), dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
+    const bool mw = (long long)tiles * n_updates <= 1536 && !a.use_delta;      // (the delta inputs: one-wave kernel only)
+    if constexpr (R == 5) {
+        if (a.proj_ring) {
+            if (mw) hipLaunchKernelGGL((gru_many_mw_kernel<R, true>), dim3(tiles * n_updates), dim3(256), 0, s, a, tiles, n_padded);
+            else hipLaunchKernelGGL((gru_many_kernel<R, true>), dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
+            return hipGetLastError();
+        }
+    }
+    if (mw) hipLaunchKernelGGL((gru_many_mw_kernel<R, false>), dim3(tiles * n_updates), dim3(256), 0, s, a, tiles, n_padded);
+    else hipLaunchKernelGGL((gru_many_kernel<R, false>), dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
     return hipGetLastError();
 }
 
@@ -267,12 +278,17 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
     const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
     const size_t lds = frame_lds(t);
     const int fb = frame_blocks((long long)tiles * kTileStreams * m.n_frame_rows, n_cus);
-    if (g.waves_per_tile == 4) {
-        hipLaunchKernelGGL((fused_update_kernel<R, RG, true>), dim3(tiles + fb + tiles), dim3(256), lds, s, m, t, g, tiles, fb, tiles);
-    } else {
-        const int gru_blocks = (tiles + 3) / 4;
-        hipLaunchKernelGGL((fused_update_kernel<R, RG, false>), dim3(gru_blocks + fb + tiles), dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
+    const int gru_blocks = g.waves_per_tile == 4 ? tiles : (tiles + 3) / 4;
+    const dim3 grid(gru_blocks + fb + tiles);
+    if constexpr (RG == 5) {                 // (projection rows exist for the stock width only)
+        if (g.proj_ring) {
+            if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, RG, true, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
+            else hipLaunchKernelGGL((fused_update_kernel<R, RG, false, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
+            return hipGetLastError();
+        }
     }
+    if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, RG, true, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
+    else hipLaunchKernelGGL((fused_update_kernel<R, RG, false, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
     return hipGetLastError();
 }
 
@@ -355,6 +371,26 @@ __global__ void clear_kernel(const ClearArgs a) {
         const int slot = i / kRowFloats, f = i % kRowFloats;
         a.ring[(((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kRowFloats + f] = 0.0f;
     }
+    if (a.proj_ring)            // the projection of an all-zero frame is the bias row
+        for (int i = threadIdx.x; i < a.ring_slots * kProjRow; i += blockDim.x) {
+            const int slot = i / kProjRow, o = i % kProjRow;
+            a.proj_ring[(((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kProjRow + o] = a.proj_b[o];
+        }
+}
+
+__global__ void project_rows_kernel(const float* ring, float* proj, const float* w, const float* b, const int n_mfcc, const long long n_rows) {
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int o = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    float acc = b[o];
+    for (int c = 0; c < n_mfcc; ++c) acc = fmaf(ring[row * kRowFloats + c], w[c * kProjRow + o], acc);
+    proj[row * kProjRow + o] = acc;
+}
+
+hipError_t launch_project_rows(const float* ring, float* proj, const float* w, const float* b, int n_mfcc, long long n_rows, hipStream_t s) {
+    if (n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(project_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, ring, proj, w, b, n_mfcc, n_rows);
+    return hipGetLastError();
 }
 
 __global__ void decode_kernel(const DecodeArgs a) {

@@ -30,7 +30,9 @@ struct Tab {            // pointers into one image of the blob (LDS on the GPU)
     const int* mel_start;   // [64]
     const int* pstart;      // [65]
     const int* partner;     // [64]
-    int mel_len, dct_len, np_max;
+    const float* proj_w;    // [proj_rows][64] float32, may be absent (proj_rows == 0)
+    const float* proj_b;    // [64]
+    int mel_len, dct_len, np_max, proj_rows;
 };
 
 template <class R>
@@ -46,7 +48,9 @@ PE_HD Tab<R> bind(const unsigned char* image, const Layout& L) {
     t.mel_start = reinterpret_cast<const int*>(image + L.mel_start);
     t.pstart = reinterpret_cast<const int*>(image + L.pstart);
     t.partner = reinterpret_cast<const int*>(image + L.partner);
-    t.mel_len = L.mel_len; t.dct_len = L.dct_len; t.np_max = L.np_max;
+    t.proj_w = reinterpret_cast<const float*>(image + L.proj_w);
+    t.proj_b = reinterpret_cast<const float*>(image + L.proj_b);
+    t.mel_len = L.mel_len; t.dct_len = L.dct_len; t.np_max = L.np_max; t.proj_rows = L.proj_rows;
     return t;
 }
 

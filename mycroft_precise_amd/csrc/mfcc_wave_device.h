@@ -230,6 +230,7 @@ struct FrameTask {          // wave-uniform description of one due frame
     const int16_t* car;     // this stream's carry
     const int16_t* row;     // chunk that holds the frame's first new sample (u0)
     float* ring_row;        // where the coefficients go
+    float* proj_row;        // where the input projection of the frame goes (may be null)
     int vb, q, off0;        // first virtual sample; carry length; offset of vb in chunk u0 (negative: inside the carry)
 };
 
@@ -297,7 +298,9 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
             if (w0 >= 0 && U > 1) { u0 = (int)a.div_chunk.div((uint32_t)w0); f.off0 = w0 - u0 * C; }
             f.row = a.pcm + (size_t)s * C + (size_t)u0 * update_stride;
             const int slot = (int)((kc + (uint32_t)kb) & (uint32_t)(slots - 1));
-            f.ring_row = a.ring + (((size_t)tile * slots + slot) * kTileStreams + j) * kRowFloats;
+            const size_t cell = ((size_t)tile * slots + slot) * kTileStreams + j;
+            f.ring_row = a.ring + cell * kRowFloats;
+            f.proj_row = a.proj_ring ? a.proj_ring + cell * kProjRow : nullptr;
             return true;
         }
         return false;
@@ -327,6 +330,7 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
     const int c = lane >> 2;
     pe_wave::Regs<R> v;
     float* row_cur = nullptr;
+    float* prow_cur = nullptr;
     int raw[4] = {0, 0, 0, 0};
     bool have_cur = false, first = true;
     for (;;) {
@@ -341,7 +345,19 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
         }
         if (have_cur) {
             const R coeff = mfcc_wave_frame<R>(tab, lc, S, lane, geo.n_filt, geo.n_mfcc, v, K::PSCALE_I16, geo.log_mode);
-            if ((lane & 3) == 0) row_cur[c] = c < geo.n_mfcc ? (float)coeff : 0.0f;
+            const float xf = c < geo.n_mfcc ? (float)coeff : 0.0f;
+            if ((lane & 3) == 0) row_cur[c] = xf;
+            if (prow_cur) {
+                // input projection of this frame, once, for every window it will appear in: row[o] = b[o] + sum_c x[c] W[c][o]
+                // (o in MFMA slot order); the rounded float32 features are what the network would have read
+                float* XF = reinterpret_cast<float*>(S);
+                if ((lane & 3) == 0) XF[c] = xf;
+                group_sync();
+                float acc = tab.proj_b[lane];
+                for (int cc = 0; cc < tab.proj_rows; ++cc) acc = fmaf(XF[cc], tab.proj_w[cc * kProjRow + lane], acc);
+                prow_cur[lane] = acc;
+                group_sync();
+            }
         }
         if (!have_next) break;
 #pragma unroll
@@ -350,6 +366,7 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
             v.im[a4] = (R)(raw[a4] >> 16);
         }
         row_cur = nxt.ring_row;
+        prow_cur = nxt.proj_row;
         have_cur = true;
     }
 }

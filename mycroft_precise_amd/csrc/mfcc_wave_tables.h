@@ -50,13 +50,16 @@ static_assert(kLogMelOff + kMaxFilt + 1 <= kScratchReals, "scratch layout");
 PE_WAVE_HD inline int kbase_of(int l) { return (l >> 4) + 4 * ((l >> 2) & 3) + 16 * (l & 3); }
 
 struct Layout {          // byte offsets into the blob (16-byte aligned sections)
-    int tw1, tw2, tw3, w512, logtab, mel_w, dct_w, mel_start, pstart, partner, total;
+    int tw1, tw2, tw3, w512, logtab, mel_w, dct_w, mel_start, pstart, partner, proj_w, proj_b, total;
+    int proj_rows;       // 0: no input-projection epilogue; else n_mfcc (rows of proj_w)
     int mel_len, dct_len, np_max;
 };
 
 inline int align16(int v) { return (v + 15) & ~15; }
 
-inline Layout layout(int real_size, int mel_len, int dct_len, int np_max) {
+constexpr int kProjRow = 64;        // floats per input-projection row (4 MFMA output tiles x 16 rows)
+
+inline Layout layout(int real_size, int mel_len, int dct_len, int np_max, int proj_rows = 0) {
     Layout L{};
     int off = 0;
     L.tw1 = off; off += 3 * 64 * 2 * real_size;
@@ -70,14 +73,19 @@ inline Layout layout(int real_size, int mel_len, int dct_len, int np_max) {
     L.mel_start = off; off += 64 * 4;
     L.pstart = off; off += (kMaxFilt + 1) * 4; off = align16(off);
     L.partner = off; off += 64 * 4;
+    L.proj_w = off; off += proj_rows * kProjRow * 4;      // float32 [n_mfcc][64]: the network's input kernel in MFMA slot order
+    L.proj_b = off; off += (proj_rows ? kProjRow * 4 : 0);
+    L.proj_rows = proj_rows;
     L.total = align16(off);
     L.mel_len = mel_len; L.dct_len = dct_len; L.np_max = np_max;
     return L;
 }
 
 // mel_filters: [n_filt][257] row-major; dct-II ortho rows built here.  Returns "" or an error message.
+// proj_w / proj_b (optional): [n_mfcc][64] / [64] float32, appended to the image for the input-projection epilogue
 template <class R>
-std::string build(const double* mel_filters, int n_filt, int n_mfcc, std::vector<unsigned char>& blob, Layout& L) {
+std::string build(const double* mel_filters, int n_filt, int n_mfcc, std::vector<unsigned char>& blob, Layout& L,
+                  const float* proj_w = nullptr, const float* proj_b = nullptr) {
     const double PI = 3.14159265358979323846;
     if (n_filt < 1 || n_filt > kMaxFilt || n_mfcc < 1 || n_mfcc > 16 || n_mfcc > n_filt) return "need 1 <= n_mfcc <= 16, n_mfcc <= n_filt <= 64";
     // support of every filter: one contiguous run of non-zero weights
@@ -111,8 +119,12 @@ std::string build(const double* mel_filters, int n_filt, int n_mfcc, std::vector
         }
     }
     for (int f = n_filt; f <= kMaxFilt; ++f) pstart[f] = lane;
-    L = layout((int)sizeof(R), mel_len, dct_len, np_max);
+    L = layout((int)sizeof(R), mel_len, dct_len, np_max, proj_w ? n_mfcc : 0);
     blob.assign((size_t)L.total, 0);
+    if (proj_w) {
+        std::memcpy(blob.data() + L.proj_w, proj_w, (size_t)n_mfcc * kProjRow * 4);
+        std::memcpy(blob.data() + L.proj_b, proj_b, (size_t)kProjRow * 4);
+    }
     auto put_c = [&](int off, int idx, double ang) {
         R v[2] = {(R)std::cos(ang), (R)std::sin(ang)};
         std::memcpy(blob.data() + off + (size_t)idx * 2 * sizeof(R), v, sizeof v);

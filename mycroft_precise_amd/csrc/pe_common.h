@@ -78,6 +78,7 @@ struct MfccStreamArgs {
     uint32_t* st_kc_next;
     uint32_t* st_ke_next;
     float* ring;            // [n_tiles][ring_slots][16 streams][16 floats]
+    float* proj_ring;       // [n_tiles][ring_slots][16 streams][64 floats] x.W + b of every frame, or null
     // several updates per launch (mfcc_many_tile): chunk u of stream s at pcm + (u*n_streams + s)*chunk
     int n_updates;
     int n_frame_rows;       // frame tasks per stream: the most frames one stream can complete in this call
@@ -123,6 +124,10 @@ struct GruArgs {
     const float* wd_bf16;   // [8][64]
     // input: either the feature ring (+ per-stream emitted-frame counters) ...
     const float* ring;
+    // ... with, when the MFCC stage wrote it, the input projection x.W + b of every frame beside it, in MFMA slot
+    // order [tile][slot][stream][g][output tile][q]: the network then starts every timestep from that accumulator
+    // instead of recomputing the projection in each of the n_features windows the frame appears in
+    const float* proj_ring;
     const uint32_t* st_ke;
     int ring_slots;
     // predict_ke != 0: st_q/st_kc/st_ke hold the state BEFORE the update whose chunk is `chunk`
@@ -170,6 +175,8 @@ struct ClearArgs {
     int32_t* st_q; uint32_t* st_kc; uint32_t* st_ke;
     float* ring;
     int32_t* activation;    // per-stream trigger state, may be null
+    float* proj_ring;       // input-projection rows, may be null: a cleared row is the projection of a zero frame = bias
+    const float* proj_b;    // [kProjRow]
 };
 
 // ThresholdDecoder.decode + TriggerDetector.update for every stream (threshold_decoder.py:45-57,
@@ -192,6 +199,7 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t s);
 // launchers implemented in kernels.hip
 // MFCC of one call (n_updates chunks per stream): every frame the call completes as a task of one wave, then the
 // per-stream bookkeeping (leftover samples to carry_next, counters to st_*_next, ke_hist)
+constexpr int kProjRow = pe_wave::kProjRow;
 hipError_t launch_mfcc_f64(const MfccStreamArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s);
 hipError_t launch_mfcc_f32(const MfccStreamArgs<float>& a, const WaveTables<float>& t, int n_cus, hipStream_t s);
 // network for n_updates x n_streams windows, emitted counters from ke_hist, out[u][stream]
@@ -211,5 +219,7 @@ hipError_t launch_gru_wide(const WideArgs& a, int input_mode, hipStream_t s);   
 hipError_t launch_gather(const GatherArgs& a, hipStream_t s);
 hipError_t launch_scatter(const GatherArgs& a, int32_t* st_q, uint32_t* st_kc, hipStream_t s);   // a.out is read
 hipError_t launch_clear(const ClearArgs& a, hipStream_t s);
+// proj[row][o] = b[o] + sum_c ring[row][c] w[c][o] for n_rows feature rows (after the ring was written from outside)
+hipError_t launch_project_rows(const float* ring, float* proj, const float* w, const float* b, int n_mfcc, long long n_rows, hipStream_t s);
 
 }  // namespace pe

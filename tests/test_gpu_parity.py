@@ -270,6 +270,67 @@ def test_gru_kernel_shapes_agree_bitwise(stock_weights):
         engines[0].engine.set_gru_waves(3)
 
 
+def test_input_projection_rows_agree_with_recomputed_projection(stock_weights):
+    """pe_set_input_projection: x.W + b stored once per frame by the MFCC stage (default up to 16384 streams) vs
+    recomputed by the network in every window.  Same numbers to float32 summation order, both inside the oracle
+    bar; every kernel shape (fused / two launches, one / four waves per tile, pe_update_many) agrees BIT FOR BIT
+    with the others under the same setting; masked clears and pe_set_vectors keep the rows consistent."""
+    from mycroft_precise_amd._lib import HipEngine
+    n, n_up = 53, 44
+    pcm = _stream_batch(['tone_noise'] * (n - 3) + ['zeros', 'square', 'quiet'], n_up)
+    ref = ol.BatchedOracle(stock_weights, n)
+    outs = {}
+    for proj in (True, False):
+        variants = []
+        for fused, waves in ((True, 4), (True, 1), (False, 4), (False, 1)):
+            e = HipEngine(P.pr, stock_weights, n_streams=n)
+            e.set_input_projection(proj)
+            e.set_fused(fused); e.set_gru_waves(waves)
+            variants.append(e)
+        res = []
+        for u in range(n_up):
+            if u == 20:
+                mask = np.zeros(n, np.uint8); mask[::5] = 1
+                for e in variants:
+                    e.clear(mask)
+            got = [e.update(pcm[u]) for e in variants]
+            for g in got[1:]:
+                assert np.array_equal(g, got[0]), (proj, u)
+            res.append(got[0])
+        outs[proj] = np.stack(res)
+        for e in variants:
+            e.close()
+        # the batched path under the same setting: equal to single updates
+        single, many = HipEngine(P.pr, stock_weights, n_streams=n), HipEngine(P.pr, stock_weights, n_streams=n)
+        many.reserve_updates(4, 1024)
+        single.set_input_projection(proj); many.set_input_projection(proj)
+        for u in range(0, 40, 4):
+            want = np.stack([single.update(pcm[u + i]) for i in range(4)])
+            assert np.array_equal(many.update_many(pcm[u:u + 4]), want), (proj, u)
+        single.close(); many.close()
+    ref_out = []
+    refs = [ol.OracleListener(stock_weights) for _ in range(n)]
+    for u in range(n_up):
+        if u == 20:
+            for j in range(0, n, 5):
+                refs[j].clear()
+        ref_out.append([r.update_raw(pcm[u, j].tobytes()) for j, r in enumerate(refs)])
+    ref_out = np.array(ref_out)
+    assert np.abs(outs[True] - ref_out).max() <= GUARD_RAW and np.abs(outs[False] - ref_out).max() <= GUARD_RAW
+    assert np.abs(outs[True] - outs[False]).max() <= 5e-6
+    # pe_set_vectors rebuilds the projection rows of the window it installs
+    e = HipEngine(P.pr, stock_weights, n_streams=n)
+    feats = np.random.default_rng(4).normal(0, 3, (n, 29, 13)).astype(np.float32)
+    e.set_vectors(feats)
+    buf = e.update_vectors(np.zeros((n, 2), np.int16))            # 2 samples: no new frame, window unchanged
+    assert np.array_equal(buf, feats)
+    got = e.update(np.zeros((n, 2), np.int16))
+    assert np.abs(got - keras_gru.predict(feats, stock_weights)[:, 0]).max() <= GUARD_RAW
+    with pytest.raises(NotImplementedError):
+        HipEngine(P.pr, synth.make_weights(units=(8,)), n_streams=4).set_input_projection(True)
+    e.close()
+
+
 def test_update_vectors_and_masked_clear_desynchronise_streams(stock_weights):
     """pe_clear(mask) restarts some streams mid-way: afterwards streams of one tile sit at
     different positions of their feature rings; each must still match its own oracle."""

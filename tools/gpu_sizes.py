@@ -14,6 +14,8 @@ ap.add_argument('--mfcc', default='f64')
 ap.add_argument('--gru', default='f32')
 ap.add_argument('--ring', default='f32')
 ap.add_argument('--desync', action='store_true')
+ap.add_argument('--proj', type=int, default=-1)
+ap.add_argument('--waves', type=int, default=0)
 ap.add_argument('sizes', nargs='*', type=int, default=[4096, 8192, 16384, 65536])
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
@@ -21,6 +23,10 @@ w = synth.make_weights()
 rng = np.random.default_rng(3)
 for B in args.sizes:
     eng = _lib.HipEngine(pr, w, n_streams=B, mfcc_precision=args.mfcc, gru_precision=args.gru, ring_precision=args.ring)
+    if args.proj >= 0:
+        eng.set_input_projection(bool(args.proj))
+    if args.waves:
+        eng.set_gru_waves(args.waves)
     n_res = 32
     pcm = (torch.randn((n_res, B, 1024), device=dev) * 3000).to(torch.int16)
     out = torch.zeros(B, device=dev)
@@ -45,7 +51,7 @@ for B in args.sizes:
     fused = timeit(lambda i: eng.update_device(pcm[i % n_res].data_ptr(), 1024, out.data_ptr(), st))
     mfcc = timeit(lambda i: eng.update_vectors_device(pcm[i % n_res].data_ptr(), 1024, 0, st))
     gru = timeit(lambda i: eng.run_device(out.data_ptr(), st))
-    print('streams %6d  mfcc=%s gru=%s ring=%s%s: fused %7.2f us (%6.1f M windows/s)  mfcc alone %7.2f us (%6.1f M/s, %5.1f %% of 8 TB/s)  '
-          'network alone %7.2f us (%6.1f M/s)' % (B, args.mfcc, args.gru, args.ring, ' desync' if args.desync else '', fused, B / fused, mfcc, B / mfcc,
+    print('streams %6d  mfcc=%s gru=%s ring=%s%s proj=%d waves=%d: fused %7.2f us (%6.1f M windows/s)  mfcc alone %7.2f us (%6.1f M/s, %5.1f %% of 8 TB/s)  '
+          'network alone %7.2f us (%6.1f M/s)' % (B, args.mfcc, args.gru, args.ring, ' desync' if args.desync else '', args.proj, args.waves, fused, B / fused, mfcc, B / mfcc,
                                                   100 * 2114.6 * B / (mfcc * 1e-6) / 8e12, gru, B / gru), flush=True)
     eng.close()
