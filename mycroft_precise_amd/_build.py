@@ -17,12 +17,8 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ_DIR = os.path.join(CSRC, 'build')
 LIB_PATH = os.path.join(HERE, 'libprecise_engine.so')
 SOURCES = ['engine.hip', 'kernels.hip']
-HEADERS = [os.path.join(CSRC, 'pe_common.h'), os.path.join(CSRC, 'mfcc_device.h'),
-           os.path.join(CSRC, 'mfcc_wave_device.h'), os.path.join(CSRC, 'mfcc_wave_core.h'),
-           os.path.join(CSRC, 'mfcc_wave_tables.h'),
-           os.path.join(CSRC, 'gru_device.h'), os.path.join(CSRC, 'gru_bf16_device.h'),
-           os.path.join(CSRC, 'gru_wide_device.h'),
-           os.path.join(os.path.dirname(HERE), 'include', 'precise_engine.h')]
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + \
+    [os.path.join(os.path.dirname(HERE), 'include', 'precise_engine.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 

@@ -65,6 +65,7 @@ struct pe_engine {
     // packed network
     float* wxd = nullptr;
     float* wx = nullptr; float* wr1 = nullptr; float* wr2 = nullptr; float* bias = nullptr; float* wd = nullptr;
+    float* rk_plain = nullptr; float* wd_plain = nullptr;     // Keras layout, for the DPP kernel
     // wide / stacked network (units 64..256, 1-2 layers): weight streams in MFMA A-operand order
     bool wide = false;
     float* wide_buf[2][6] = {{nullptr}};     // per layer: wx1, wr1, wx2, wr2, b1, b2
@@ -211,6 +212,11 @@ int pack_gru_weights(pe_engine* e, const pe_gru_layer& L, const float* dense_ker
         }
     }
     int rc;
+    {
+        std::vector<float> rk(L.recurrent_kernel, L.recurrent_kernel + (size_t)H * 3 * H), wdp(dense_kernel, dense_kernel + H);
+        if ((rc = dev_upload(e, &e->rk_plain, rk))) return rc;
+        if ((rc = dev_upload(e, &e->wd_plain, wdp))) return rc;
+    }
     if ((rc = dev_upload(e, &e->wx, wx))) return rc;
     if ((rc = dev_upload(e, &e->wxd, wxd))) return rc;
     if ((rc = dev_upload(e, &e->wr1, wr1))) return rc;
@@ -405,6 +411,7 @@ GruArgs gru_args(const pe_engine* e) {
     a.wxd = e->wxd; a.use_delta = e->prm.use_delta;
     a.wx = e->wx; a.wr1 = e->wr1; a.wr2 = e->wr2; a.bias = e->bias; a.wd = e->wd;
     a.dense_bias = e->dense_bias;
+    a.rk = e->rk_plain; a.wd_plain = e->wd_plain;
     a.ring = e->ring; a.st_ke = e->st_ke[e->cur]; a.ring_slots = e->ring_slots;
     a.proj_ring = e->proj_on ? e->proj_ring : nullptr;
     a.predict_ke = 0;
@@ -418,7 +425,10 @@ GruArgs gru_args(const pe_engine* e) {
     // Four waves per tile cut the latency of a tile's chain; that only pays while every tile gets a CU of its
     // own next to one MFCC workgroup.  Measured (fused, f64 front end; tools/gpu_policy.py): 4096 streams
     // 21.9 us (4 waves) vs 32.0 (1); 8192: 41.5 vs 33.5; 16384: 76.0 vs 55.3; 65536: 284 vs 199.
-    a.waves_per_tile = e->gru_waves ? e->gru_waves : (e->n_tiles <= e->n_cus ? 4 : 1);
+    // The DPP kernel (sixteen lanes per stream, no hand-offs) has the shortest chain of all, and needs the projection rows.
+    const bool dpp_ok = e->proj_on && e->units >= 17 && e->units <= 20;
+    a.waves_per_tile = e->gru_waves ? e->gru_waves : (e->n_tiles <= e->n_cus ? (dpp_ok ? 16 : 4) : 1);
+    if (a.waves_per_tile == 16 && !dpp_ok) a.waves_per_tile = 4;
     if (e->prm.use_delta) a.waves_per_tile = 1;          // only the one-wave kernel carries the delta inputs
     return a;
 }
@@ -941,7 +951,8 @@ int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, i
     GruArgs g = gru_args(e);
     g.st_ke = e->ke_hist;
     g.out = raw_out_dev;
-    g.waves_per_tile = 1;
+    if (g.waves_per_tile != 16) g.waves_per_tile = 1;     // (16: the engine's updates run the DPP kernel, and so does the batch;
+                                                          //  otherwise the launcher picks one or four waves per window itself)
     PE_HIP(e, launch_gru_many(g, n_updates, e->n_padded, s));
     return PE_OK;
 }
@@ -1010,7 +1021,7 @@ int pe_set_input_projection(pe_engine* e, int32_t enabled) {
 
 int pe_set_gru_waves(pe_engine* e, int32_t waves) {
     if (!e) return PE_ERR_INVALID;
-    if (waves != 0 && waves != 1 && waves != 4) return fail(e, PE_ERR_INVALID, "gru waves per tile must be 0 (auto), 1 or 4");
+    if (waves != 0 && waves != 1 && waves != 4 && waves != 16) return fail(e, PE_ERR_INVALID, "gru kernel shape must be 0 (auto), 1, 4 (waves per tile) or 16 (lanes per stream)");
     e->gru_waves = waves;
     return PE_OK;
 }

@@ -1,9 +1,11 @@
 // Every __global__ entry point of libprecise_engine.so and its launcher.  The device code lives
 // in mfcc_wave_device.h / mfcc_device.h (MFCC front end: frames / bookkeeping) and gru_*_device.h (GRU + Dense
 // on the matrix cores).
+#include <cstdlib>
 #include "mfcc_device.h"
 #include "mfcc_wave_device.h"
 #include "gru_device.h"
+#include "gru_dpp_device.h"
 #include "gru_bf16_device.h"
 #include "gru_wide_device.h"
 
@@ -136,6 +138,39 @@ __global__ __launch_bounds__(256) void gru_mw_kernel(const GruArgs a) {
     gru_tile_mw_any<R, PROJ>(a, blockIdx.x, wave, threadIdx.x & 63, S);
 }
 
+// ---- GRU: sixteen lanes per stream, no hand-offs (few tiles: the window's dependent chain is what counts) ----------
+__global__ __launch_bounds__(256) void gru_dpp_kernel(const GruArgs a) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    gru_tile_dpp(a, blockIdx.x, wave, threadIdx.x & 63);
+}
+
+// the same for a whole batch of updates: workgroup b serves update b / n_tiles, tile b % n_tiles
+__global__ __launch_bounds__(256) void gru_many_dpp_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
+    const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
+    GruArgs b = a;
+    b.st_ke = a.st_ke + (size_t)u * n_padded;
+    b.out = a.out + (size_t)u * a.n_streams;
+    b.predict_ke = 0;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    gru_tile_dpp(b, tile, wave, threadIdx.x & 63);
+}
+
+// the fused update with that network role (its ~150 registers per lane leave three waves per SIMD)
+template <class R>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void fused_update_dpp_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
+                                                               const int n_gru_blocks, const int n_frame_blocks, const int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    if (b < n_gru_blocks) {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        gru_tile_dpp(g, b, wave, threadIdx.x & 63);
+    } else if (b < n_gru_blocks + n_frame_blocks) {
+        mfcc_frame_tasks<R>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
+    } else {
+        mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
+    }
+}
+
 // ---- fused update: GRU role || MFCC frame role || bookkeeping role in ONE launch -------------------------------
 // Workgroups [0, n_gru_blocks) run the network on the feature windows as they will stand after this update (they
 // are dispatched first: the long pole); the next n_frame_blocks compute this update's MFCC frames, one frame task
@@ -147,6 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
     if (b < n_gru_blocks) {
+        __builtin_amdgcn_s_setprio(3);          // the network role is the long pole: it wins every issue arbitration
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         if (MW) {
             gru_tile_mw_any<RG, PROJ>(g, b, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
@@ -163,9 +199,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
 
 // Workgroups of the frame role: one wave per task while that fits the machine (4 workgroups of 4 waves per compute
 // unit are resident: LDS and a 128-register budget), more tasks per wave beyond.
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
 static int frame_blocks(long long n_tasks, int n_cus) {
+    static const int per_cu = env_int("PE_FRAME_WG_PER_CU", 4);      // tuning knob (tools/): resident frame workgroups per CU
     const long long need = (n_tasks + kFrameWaves - 1) / kFrameWaves;
-    const long long cap = (long long)n_cus * 4;
+    const long long cap = (long long)n_cus * per_cu;
     return (int)(need < cap ? (need < 1 ? 1 : need) : cap);
 }
 
@@ -200,6 +241,10 @@ static hipError_t launch_r(const GruArgs& a, int mode, hipStream_t s) {
     const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
     if (tiles == 0) return hipSuccess;
     if constexpr (R == 5) {
+        if (mode == kRing && a.proj_ring && a.waves_per_tile == 16) {
+            hipLaunchKernelGGL(gru_dpp_kernel, dim3(tiles), dim3(256), 0, s, a);
+            return hipGetLastError();
+        }
         if (mode == kRing && a.proj_ring) {
             if (a.waves_per_tile == 4) hipLaunchKernelGGL((gru_mw_kernel<R, true>), dim3(tiles), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((gru_small_kernel<R, kRing, true>), dim3(tiles), dim3(64), 0, s, a);
@@ -242,6 +287,10 @@ static hipError_t launch_many_r(const GruArgs& a, int n_updates, int n_padded, h
     // update), from 2 per SIMD on the one-wave kernel does (x 16: 12.5 vs 14.0)
     const bool mw = (long long)tiles * n_updates <= 1536 && !a.use_delta;      // (the delta inputs: one-wave kernel only)
     if constexpr (R == 5) {
+        if (a.proj_ring && a.waves_per_tile == 16) {       // the engine's single updates use the DPP kernel: so does the batch
+            hipLaunchKernelGGL(gru_many_dpp_kernel, dim3(tiles * n_updates), dim3(256), 0, s, a, tiles, n_padded);
+            return hipGetLastError();
+        }
         if (a.proj_ring) {
             if (mw) hipLaunchKernelGGL((gru_many_mw_kernel<R, true>), dim3(tiles * n_updates), dim3(256), 0, s, a, tiles, n_padded);
             else hipLaunchKernelGGL((gru_many_kernel<R, true>), dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
@@ -281,6 +330,10 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
     const int gru_blocks = g.waves_per_tile == 4 ? tiles : (tiles + 3) / 4;
     const dim3 grid(gru_blocks + fb + tiles);
     if constexpr (RG == 5) {                 // (projection rows exist for the stock width only)
+        if (g.proj_ring && g.waves_per_tile == 16) {
+            hipLaunchKernelGGL((fused_update_dpp_kernel<R>), dim3(tiles + fb + tiles), dim3(256), lds, s, m, t, g, tiles, fb, tiles);
+            return hipGetLastError();
+        }
         if (g.proj_ring) {
             if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, RG, true, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
             else hipLaunchKernelGGL((fused_update_kernel<R, RG, false, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);

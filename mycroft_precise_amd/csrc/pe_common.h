@@ -116,6 +116,9 @@ struct GruArgs {
     const float* bias;      // [NT][4][64]      accumulator init per output register
     const float* wd;        // [R][64]          dense kernel for unit 4*rho+g
     float dense_bias;
+    // the same matrices as Keras stores them, for the DPP kernel (gru_dpp_device.h), which picks its own order
+    const float* rk;        // [H][3H] recurrent kernel, gate order z | r | h
+    const float* wd_plain;  // [H]     dense kernel
     // bf16-operand variant (gru_bf16_device.h): unit 8 g + i, tiles z0 z1 r0 r1 c0 c1
     int bf16;               // != 0: run the bf16 kernel
     const void* wx_bf16;    // [6][64] x 8 bf16    input kernel, k = 8 g + e <-> feature
@@ -141,7 +144,8 @@ struct GruArgs {
     const float* feats;
     int row_stride;
     float* out;             // [n_streams]
-    int waves_per_tile;     // 1: one wave per tile (gru_tile);  4: four waves share a tile (gru_tile_mw)
+    int waves_per_tile;     // 1: one wave per tile (gru_tile);  4: four waves share a tile (gru_tile_mw);
+                            // 16: four waves per tile, sixteen LANES per stream (gru_tile_dpp)
 };
 
 struct WideLayerArgs {

@@ -268,6 +268,14 @@ def test_gru_kernel_shapes_agree_bitwise(stock_weights):
             assert np.array_equal(o, outs[0]), u
     with pytest.raises(ValueError):
         engines[0].engine.set_gru_waves(3)
+    # 16 = sixteen LANES per stream (gru_dpp_device.h, the default up to 4096 streams): float32 multiply-adds in
+    # another order than the matrix cores' -- agrees to rounding, not bit for bit
+    d = BatchedListener(stock_weights, n)
+    d.engine.set_gru_waves(16)
+    ref = BatchedListener(stock_weights, n)
+    ref.engine.set_gru_waves(4)
+    for u in range(n_up):
+        assert np.abs(d.update_raw(pcm[u]) - ref.update_raw(pcm[u])).max() <= 5e-6, u
 
 
 def test_input_projection_rows_agree_with_recomputed_projection(stock_weights):
@@ -287,18 +295,27 @@ def test_input_projection_rows_agree_with_recomputed_projection(stock_weights):
             e.set_input_projection(proj)
             e.set_fused(fused); e.set_gru_waves(waves)
             variants.append(e)
+        dpp = []
+        for fused in ((True, False) if proj else ()):
+            e = HipEngine(P.pr, stock_weights, n_streams=n)
+            e.set_fused(fused); e.set_gru_waves(16)
+            dpp.append(e)
         res = []
         for u in range(n_up):
             if u == 20:
                 mask = np.zeros(n, np.uint8); mask[::5] = 1
-                for e in variants:
+                for e in variants + dpp:
                     e.clear(mask)
             got = [e.update(pcm[u]) for e in variants]
             for g in got[1:]:
                 assert np.array_equal(g, got[0]), (proj, u)
             res.append(got[0])
+            if proj:        # the sixteen-lanes-per-stream kernel: its own summation order, fused == two launches
+                gd = [e.update(pcm[u]) for e in dpp]
+                assert np.array_equal(gd[0], gd[1]), u
+                assert np.abs(gd[0] - got[0]).max() <= 5e-6, u
         outs[proj] = np.stack(res)
-        for e in variants:
+        for e in variants + dpp:
             e.close()
         # the batched path under the same setting: equal to single updates
         single, many = HipEngine(P.pr, stock_weights, n_streams=n), HipEngine(P.pr, stock_weights, n_streams=n)
