@@ -145,7 +145,6 @@ int ensure(pe_engine* e, DeviceBuf& b, size_t bytes) {
 
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-constexpr int kProjMaxTiles = 1024;      // input-projection rows are kept up to 16384 streams per engine (134 MB at 32 slots)
 
 template <class R>
 int build_tables(pe_engine* e, const double* mel_filters) {
@@ -427,7 +426,7 @@ GruArgs gru_args(const pe_engine* e) {
     // 21.9 us (4 waves) vs 32.0 (1); 8192: 41.5 vs 33.5; 16384: 76.0 vs 55.3; 65536: 284 vs 199.
     // The DPP kernel (sixteen lanes per stream, no hand-offs) has the shortest chain of all, and needs the projection rows.
     const bool dpp_ok = e->proj_on && e->units >= 17 && e->units <= 20;
-    a.waves_per_tile = e->gru_waves ? e->gru_waves : (e->n_tiles <= e->n_cus ? (dpp_ok ? 16 : 4) : 1);
+    a.waves_per_tile = e->gru_waves ? e->gru_waves : (e->n_tiles <= e->n_cus ? 4 : 1);      // (16 = DPP kernel: opt-in)
     if (a.waves_per_tile == 16 && !dpp_ok) a.waves_per_tile = 4;
     if (e->prm.use_delta) a.waves_per_tile = 1;          // only the one-wave kernel carries the delta inputs
     return a;
@@ -474,7 +473,8 @@ int check_chunk(pe_engine* e, const void* pcm, int chunk) {
 // True when no frame computed by an update of `chunk` samples can become visible in that same
 // update (it needs window - frame_len more samples), so the network does not depend on it.
 bool can_fuse(const pe_engine* e, int chunk) {
-    return e->fused && !e->wide && chunk <= emit_window(e->prm) - frame_len_of(e->prm);
+    // (the fused kernels exist for the stock table shape: filterbanks whose runs need the wide loop bounds take two launches)
+    return e->fused && !e->wide && e->table_layout.mel_pad == 10 && chunk <= emit_window(e->prm) - frame_len_of(e->prm);
 }
 
 int do_update(pe_engine* e, const int16_t* pcm_dev, int chunk, float* raw_out_dev, float* feats_out_dev,
@@ -587,7 +587,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         // the projection rows exist for the stock-width float32 network (3 R <= 16 slots: 4 output tiles, R = 5) fed
         // from the ring; they pay while the ring stays cache-resident (256 B per frame and stream)
         e->proj_ok = !wide && p->gru_precision == 0 && !p->use_delta && gru_small_regs(L.units) == 5 && !e->proj_w_host.empty();
-        e->proj_on = e->proj_ok && e->n_tiles <= kProjMaxTiles;
+        e->proj_on = false;          // opt-in (pe_set_input_projection): measured no gain for the MFMA kernels at <= 4096 streams
         rc = (p->mfcc_precision == 0) ? build_tables<double>(e, mel_filters) : build_tables<float>(e, mel_filters);
         if (rc) break;
         if (e->proj_on && (rc = dev_alloc(e, &e->proj_ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kProjRow))) break;

@@ -17,10 +17,10 @@ namespace pe {
 #endif
 // workgroups [0, n_frame_blocks): frame tasks; the rest: one bookkeeping workgroup per tile (they read what the
 // frame tasks read and write elsewhere, so the two roles share a launch)
-template <class R>
+template <class R, class SH>
 __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void mfcc_kernel(const MfccStreamArgs<R> a, const WaveTables<R> t, const int n_frame_blocks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if ((int)blockIdx.x < n_frame_blocks) mfcc_frame_tasks<R>(a, t, smem, (int)blockIdx.x * kFrameWaves, n_frame_blocks * kFrameWaves);
+    if ((int)blockIdx.x < n_frame_blocks) mfcc_frame_tasks<R, SH>(a, t, smem, (int)blockIdx.x * kFrameWaves, n_frame_blocks * kFrameWaves);
     else mfcc_book_tile<R>(a, (int)blockIdx.x - n_frame_blocks);
 }
 
@@ -57,10 +57,10 @@ __global__ __launch_bounds__(64) void gru_many_bf16_kernel(const GruArgs a, cons
     gru_tile_bf16<kRing>(b, tile, threadIdx.x);
 }
 
-template <class R>
+template <class R, class SH>
 __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void mfcc_offline_kernel(const MfccOfflineArgs<R> a, const WaveTables<R> t) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    mfcc_offline_frames<R>(a, t, smem);
+    mfcc_offline_frames<R, SH>(a, t, smem);
 }
 
 // ---- GRU: one wave per 16-stream tile ----------------------------------------------------------
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void gru_bf16_kernel(const GruArgs a) {
 }
 
 // fused update with the bf16 network role (four tiles per GRU workgroup, one wave each)
-template <class R>
+template <class R, class SH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_bf16_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
                                                                 const int n_gru_blocks, const int n_frame_blocks, const int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
         const int tile = b * 4 + (threadIdx.x >> 6);
         if (tile < n_tiles) gru_tile_bf16<kRing>(g, tile, threadIdx.x & 63);
     } else if (b < n_gru_blocks + n_frame_blocks) {
-        mfcc_frame_tasks<R>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
+        mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
     } else {
         mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
     }
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void gru_many_dpp_kernel(const GruArgs a, cons
 }
 
 // the fused update with that network role (its ~150 registers per lane leave three waves per SIMD)
-template <class R>
+template <class R, class SH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void fused_update_dpp_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
                                                                const int n_gru_blocks, const int n_frame_blocks, const int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         gru_tile_dpp(g, b, wave, threadIdx.x & 63);
     } else if (b < n_gru_blocks + n_frame_blocks) {
-        mfcc_frame_tasks<R>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
+        mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
     } else {
         mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
     }
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 // are dispatched first: the long pole); the next n_frame_blocks compute this update's MFCC frames, one frame task
 // per wave; the last n_tiles move the leftover samples and the counters.  MW = true: one GRU workgroup per tile,
 // its four waves share the tile (gru_tile_mw); MW = false: four tiles per GRU workgroup, one wave each.
-template <class R, int RG, bool MW, bool PROJ>
+template <class R, class SH, int RG, bool MW, bool PROJ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
                                                            const int n_gru_blocks, const int n_frame_blocks, const int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
             if (tile < n_tiles) gru_tile<RG, kRing, PROJ>(g, tile, threadIdx.x & 63);
         }
     } else if (b < n_gru_blocks + n_frame_blocks) {
-        mfcc_frame_tasks<R>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
+        mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
     } else {
         mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
     }
@@ -211,14 +211,15 @@ static int frame_blocks(long long n_tasks, int n_cus) {
 }
 
 template <class R>
-static size_t frame_lds(const WaveTables<R>& t) { return wave_lds_bytes(sizeof(R), t.L.total, kFrameWaves); }
+static size_t frame_lds(const WaveTables<R>& t) { return wave_lds_bytes(sizeof(R), t.L, kFrameWaves); }
 
 template <class R>
 static hipError_t launch_mfcc(const MfccStreamArgs<R>& a, const WaveTables<R>& t, int n_cus, hipStream_t s) {
     const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
     const long long n_tasks = (long long)tiles * kTileStreams * a.n_frame_rows;
     const int fb = frame_blocks(n_tasks, n_cus);
-    hipLaunchKernelGGL(mfcc_kernel<R>, dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
+    if (t.L.mel_pad == ShapeStock::MEL) hipLaunchKernelGGL((mfcc_kernel<R, ShapeStock>), dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
+    else hipLaunchKernelGGL((mfcc_kernel<R, ShapeAny>), dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
     return hipGetLastError();
 }
 hipError_t launch_mfcc_f64(const MfccStreamArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s) { return launch_mfcc<double>(a, t, n_cus, s); }
@@ -227,7 +228,8 @@ hipError_t launch_mfcc_f32(const MfccStreamArgs<float>& a, const WaveTables<floa
 template <class R>
 static hipError_t launch_offline(const MfccOfflineArgs<R>& a, const WaveTables<R>& t, int n_cus, hipStream_t s) {
     if (a.n_frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(mfcc_offline_kernel<R>, dim3(frame_blocks(a.n_frames, n_cus)), dim3(64 * kFrameWaves), frame_lds(t), s, a, t);
+    if (t.L.mel_pad == ShapeStock::MEL) hipLaunchKernelGGL((mfcc_offline_kernel<R, ShapeStock>), dim3(frame_blocks(a.n_frames, n_cus)), dim3(64 * kFrameWaves), frame_lds(t), s, a, t);
+    else hipLaunchKernelGGL((mfcc_offline_kernel<R, ShapeAny>), dim3(frame_blocks(a.n_frames, n_cus)), dim3(64 * kFrameWaves), frame_lds(t), s, a, t);
     return hipGetLastError();
 }
 hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s) { return launch_offline<double>(a, t, n_cus, s); }
@@ -331,27 +333,29 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
     const dim3 grid(gru_blocks + fb + tiles);
     if constexpr (RG == 5) {                 // (projection rows exist for the stock width only)
         if (g.proj_ring && g.waves_per_tile == 16) {
-            hipLaunchKernelGGL((fused_update_dpp_kernel<R>), dim3(tiles + fb + tiles), dim3(256), lds, s, m, t, g, tiles, fb, tiles);
+            hipLaunchKernelGGL((fused_update_dpp_kernel<R, ShapeStock>), dim3(tiles + fb + tiles), dim3(256), lds, s, m, t, g, tiles, fb, tiles);
             return hipGetLastError();
         }
         if (g.proj_ring) {
-            if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, RG, true, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
-            else hipLaunchKernelGGL((fused_update_kernel<R, RG, false, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
+            if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
+            else hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
             return hipGetLastError();
         }
     }
-    if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, RG, true, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
-    else hipLaunchKernelGGL((fused_update_kernel<R, RG, false, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
+    if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
+    else hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
     return hipGetLastError();
 }
 
+// (the fused kernels are built for the stock table shape only: engine.hip falls back to two launches otherwise)
 template <class R>
 static hipError_t launch_fused(const MfccStreamArgs<R>& m, const WaveTables<R>& t, const GruArgs& g, int n_cus, hipStream_t s) {
+    if (t.L.mel_pad != ShapeStock::MEL) return hipErrorInvalidValue;
     if (g.bf16) {
         const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
         const int gru_blocks = (tiles + 3) / 4;
         const int fb = frame_blocks((long long)tiles * kTileStreams * m.n_frame_rows, n_cus);
-        hipLaunchKernelGGL((fused_update_bf16_kernel<R>), dim3(gru_blocks + fb + tiles), dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles);
+        hipLaunchKernelGGL((fused_update_bf16_kernel<R, ShapeStock>), dim3(gru_blocks + fb + tiles), dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles);
         return hipGetLastError();
     }
     switch (gru_small_regs(g.units)) {

@@ -33,10 +33,14 @@ struct Tab {            // pointers into one image of the blob (LDS on the GPU)
     const float* proj_w;    // [proj_rows][64] float32, may be absent (proj_rows == 0)
     const float* proj_b;    // [64]
     int mel_len, dct_len, np_max, proj_rows;
+    int mel_pad;        // rows of mel_w (>= mel_len, zero beyond)
 };
 
+// image: where byte `skip` of the blob sits (the GPU's LDS image leaves out the leading twiddle sections, which
+// every wave reads once, straight from global memory)
 template <class R>
-PE_HD Tab<R> bind(const unsigned char* image, const Layout& L) {
+PE_HD Tab<R> bind(const unsigned char* image0, const Layout& L, int skip = 0) {
+    const unsigned char* image = image0 - skip;
     Tab<R> t;
     t.tw1 = reinterpret_cast<const cx<R>*>(image + L.tw1);
     t.tw2 = reinterpret_cast<const cx<R>*>(image + L.tw2);
@@ -51,6 +55,7 @@ PE_HD Tab<R> bind(const unsigned char* image, const Layout& L) {
     t.proj_w = reinterpret_cast<const float*>(image + L.proj_w);
     t.proj_b = reinterpret_cast<const float*>(image + L.proj_b);
     t.mel_len = L.mel_len; t.dct_len = L.dct_len; t.np_max = L.np_max; t.proj_rows = L.proj_rows;
+    t.mel_pad = L.mel_pad;
     return t;
 }
 
@@ -83,6 +88,7 @@ template <class R>
 struct LaneConsts {
     cx<R> tw1[3], tw2[3], tw3[3];   // W256^(l k), W64^((l & 15) k), W16^((l & 3) k), k = 1..3
     cx<R> w512[2];                  // W512^(kbase(l) + 64 j)
+    int partner;                    // lane holding the mirror bins
 };
 
 template <class R>
@@ -90,6 +96,7 @@ PE_HD LaneConsts<R> lane_consts(const Tab<R>& t, int l) {
     LaneConsts<R> c;
     for (int k = 0; k < 3; ++k) { c.tw1[k] = t.tw1[k * 64 + l]; c.tw2[k] = t.tw2[k * 16 + (l & 15)]; c.tw3[k] = t.tw3[k * 4 + (l & 3)]; }
     c.w512[0] = t.w512[l]; c.w512[1] = t.w512[64 + l];
+    c.partner = t.partner[l];
     return c;
 }
 
@@ -167,7 +174,7 @@ template <class R>
 PE_HD R mel_run(const Tab<R>& t, const R* P, int l) {
     const int s = t.mel_start[l];
     R acc = R(0);
-    for (int i = 0; i < t.mel_len; ++i) acc += t.mel_w[i * 64 + l] * P[s + i];
+    for (int i = 0; i < t.mel_pad; ++i) acc += t.mel_w[i * 64 + l] * P[s + i];
     return acc;
 }
 

@@ -25,24 +25,63 @@
 
 namespace pe {
 
+#ifndef PE_TW_LDS
+#define PE_TW_LDS 1             // 1: the W64 / W16 twiddles (16 / 4 distinct values) are read from LDS per frame instead of
+#endif                          //    living in 24 registers (measured: 109 vs 126 us per update at 65536 streams -- the registers
+                                //    buy a fourth wave per SIMD)
 #ifndef PE_XCHG_B_LDS
 #define PE_XCHG_B_LDS 0         // 1: digit b also goes through LDS (debug / cross-check of the permlane path)
+#endif
+// Section timers for the tuning harness (tools/build_debug.sh builds a -DPE_SECTION_TIMERS copy of the library,
+// tools/gpu_sections.py reads them): shader-clock stamps of ONE wave; compiled out of the product.
+#ifdef PE_SECTION_TIMERS
+__device__ unsigned long long pe_dbg_timers[32];
+#define PE_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) pe_dbg_timers[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PE_T(i) do { } while (0)
 #endif
 
 constexpr int kWaveScratchReals = pe_wave::kScratchReals;
 
-__host__ __device__ inline size_t wave_lds_bytes(int real_size, int blob_bytes, int waves) {
-    return (size_t)blob_bytes + (size_t)waves * kWaveScratchReals * real_size;
+// The LDS image of a workgroup: the blob from the logarithm table on (mel / DCT weights, run starts, ...); the twiddle
+// sections before it are read once per wave straight from global memory into registers (LaneConsts).
+__host__ __device__ inline int wave_lds_skip(const pe_wave::Layout& L) { return PE_TW_LDS ? L.tw2 : L.logtab; }
+__host__ __device__ inline size_t wave_lds_bytes(int real_size, const pe_wave::Layout& L, int waves) {
+    return (size_t)(L.total - wave_lds_skip(L)) + (size_t)waves * kWaveScratchReals * real_size;
 }
 
-// workgroup-wide copy of the table image into LDS (16-byte loads); caller synchronises
+// workgroup-wide copy of the table image into LDS in two steps, so that the global loads can be issued at the very
+// top of a kernel and the LDS stores + barrier placed where the tables are first needed
+constexpr int kTabRegs = 2;                 // 16-byte pieces per thread held in flight (256 threads: 8 KB)
+struct TabRegs { uint4 v[kTabRegs]; };
+
 template <class R>
-__device__ __forceinline__ pe_wave::Tab<R> wave_tables_to_lds(unsigned char* smem, const WaveTables<R>& g) {
-    const int n16 = g.L.total >> 4;
-    const uint4* src = reinterpret_cast<const uint4*>(g.blob);
+__device__ __forceinline__ TabRegs wave_tables_issue(const WaveTables<R>& g) {
+    const int skip = wave_lds_skip(g.L);
+    const int n16 = (g.L.total - skip) >> 4;
+    const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(g.blob) + skip);
+    TabRegs t;
+#pragma unroll
+    for (int k = 0; k < kTabRegs; ++k) {
+        const int i = threadIdx.x + k * blockDim.x;
+        t.v[k] = i < n16 ? src[i] : uint4{0, 0, 0, 0};
+    }
+    return t;
+}
+
+template <class R>
+__device__ __forceinline__ void wave_tables_commit(unsigned char* smem, const WaveTables<R>& g, const TabRegs& t) {
+    const int skip = wave_lds_skip(g.L);
+    const int n16 = (g.L.total - skip) >> 4;
+    const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(g.blob) + skip);
     uint4* dst = reinterpret_cast<uint4*>(smem);
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
-    return pe_wave::bind<R>(smem, g.L);
+#pragma unroll
+    for (int k = 0; k < kTabRegs; ++k) {
+        const int i = threadIdx.x + k * blockDim.x;
+        if (i < n16) dst[i] = t.v[k];
+    }
+    for (int i = threadIdx.x + kTabRegs * blockDim.x; i < n16; i += blockDim.x) dst[i] = src[i];     // (larger filterbanks)
+    __syncthreads();
 }
 
 __device__ __forceinline__ void pl32_swap(unsigned& a, unsigned& b) {
@@ -99,43 +138,74 @@ __device__ __forceinline__ void exchange_lds(pe_wave::Regs<R>& v, pe_wave::cx<R>
     group_sync();
 }
 
+// Sum over the 64 lanes, result in every lane, without LDS: xor-butterfly inside the quads (quad_perm), mirrored halves
+// and rows (row_half_mirror, row_mirror), then the two row-pair steps with v_permlane16/32_swap.  The order of the
+// additions is fixed (deterministic).  A float64 shuffle through ds_bpermute costs an LDS round trip per step.
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 template <class R> __device__ __forceinline__ R wave_sum(R x) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
-    return x;
+    x += dpp_mov<0xB1>(x);          // quad_perm:[1,0,3,2]
+    x += dpp_mov<0x4E>(x);          // quad_perm:[2,3,0,1]
+    x += dpp_mov<0x141>(x);         // row_half_mirror
+    x += dpp_mov<0x140>(x);         // row_mirror: every lane of a row now holds the row's sum
+    R a = x, b = x;
+    swap16(a, b);                   // a: rows (0, 0, 2, 2), b: rows (1, 1, 3, 3)
+    x = a + b;
+    a = x; b = x;
+    swap32(a, b);                   // a: lower half everywhere, b: upper half everywhere
+    return a + b;
 }
 
 // One frame on one wave.  pcm[a] = the int16 pair (samples 2n, 2n+1 in the low / high half) of point n = lane + 64 a,
 // already zero beyond the frame length -- or, FROM_REAL, re[]/im[] hold the samples as reals (offline form).
 // Returns coefficient c in the four lanes 4c..4c+3 (c < n_mfcc).  S: this wave's scratch; after the call
 // S[kLogMelOff + f] holds the log-mel energy of filter f.
-template <class R>
+// SH: compile-time bounds of the three table-driven loops (the tables are zero-padded up to them on the host)
+struct ShapeStock { static constexpr int MEL = 10, DCT = 5, NP = 8; };      // 20 filters (sonopy 9 / 5 / 8, speechpy 4 / 5 / 7)
+struct ShapeAny { static constexpr int MEL = 16, DCT = 16, NP = 16; };
+
+template <class R, class SH>
 __device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, const pe_wave::LaneConsts<R>& lc, R* S, const int lane,
                                              const int n_filt, const int n_mfcc, pe_wave::Regs<R>& v, const R pscale, const int log_mode) {
     using K = RealK<R>;
     using namespace pe_wave;
     cx<R>* X = reinterpret_cast<cx<R>*>(S);
+    PE_T(3);
     pass_a(v, lc);
 #if PE_XCHG_B_LDS
     exchange_lds(v, X, lane, 4);
 #else
     exchange_b(v);
 #endif
+#if PE_TW_LDS
+    { radix4(v); const int m = lane & 15; twiddle3(v, t.tw2[m], t.tw2[16 + m], t.tw2[32 + m]); }
+    exchange_lds(v, X, lane, 2);
+    { radix4(v); const int d = lane & 3; twiddle3(v, t.tw3[d], t.tw3[4 + d], t.tw3[8 + d]); }
+#else
     pass_b(v, lc);
     exchange_lds(v, X, lane, 2);
     pass_c(v, lc);
+#endif
     exchange_lds(v, X, lane, 0);
     pass_d(v);
+    PE_T(4);
     // mirror exchange: bins 256 - p of this lane's registers 0 / 1 are registers 3 / 2 of the partner lane
     X[xchg_index(lane, 0)] = cx<R>{v.re[2], v.im[2]};
     X[xchg_index(lane, 1)] = cx<R>{v.re[3], v.im[3]};
     group_sync();
-    const int pl = t.partner[lane];
+    const int pl = lc.partner;
     cx<R> zq0 = X[xchg_index(pl, 1)], zq1 = X[xchg_index(pl, 0)];
     const cx<R> w0 = lc.w512[0], w1 = lc.w512[1];
     group_sync();
     const bool lane0 = kbase_of(lane) == 0;
     if (lane0) { zq0 = cx<R>{v.re[0], v.im[0]}; zq1 = cx<R>{v.re[3], v.im[3]}; }
+    PE_T(5);
     R pw[4];
     split_power(v, zq0, zq1, w0, w1, pscale * R(0.25), pw);
     R* P = S + kPowerOff;
@@ -152,34 +222,45 @@ __device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, const pe_
         psum += p128;
     }
     group_sync();
+    PE_T(6);
     // mel filterbank: this lane's run of one filter (all table reads first, then the FMA chain)
     {
         const int s = t.mel_start[lane];
+        constexpr int HALF = (SH::MEL + 1) / 2;        // two batches of reads: half the registers in flight
         R acc = R(0);
-        constexpr int CH = 6;
-        for (int i0 = 0; i0 < t.mel_len; i0 += CH) {
-            R pv[CH], wv[CH];
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int i = i0 + u < t.mel_len ? i0 + u : t.mel_len - 1;
+        for (int h = 0; h < 2; ++h) {
+            R pv[HALF], wv[HALF];
+#pragma unroll
+            for (int u = 0; u < HALF; ++u) {
+                const int i = h * HALF + u < SH::MEL ? h * HALF + u : SH::MEL - 1;
                 pv[u] = P[s + i];
-                wv[u] = i0 + u < t.mel_len ? t.mel_w[i * 64 + lane] : R(0);
+                wv[u] = h * HALF + u < SH::MEL ? t.mel_w[i * 64 + lane] : R(0);
             }
+            if (h == 0) psum = wave_sum(psum);          // (rides in the shadow of the LDS reads)
 #pragma unroll
-            for (int u = 0; u < CH; ++u) acc = real_fma(wv[u], pv[u], acc);
+            for (int u = 0; u < HALF; ++u) acc = real_fma(wv[u], pv[u], acc);
         }
-        psum = wave_sum(psum);              // (rides in the shadow of the LDS reads above)
         group_sync();
         PART[lane] = acc;
     }
     group_sync();
+    PE_T(7);
     // filter energies (partial sums of a filter sit in consecutive lanes: added in lane order), total power on
     // the last lane, one log pass for both
     {
         const bool has_filter = lane < n_filt;
         const bool takes_total = lane == 63 && n_filt < 64;
         R x = R(1);
-        if (has_filter) x = filter_sum(t, PART, lane);
+        if (has_filter) {
+            const int p0 = t.pstart[lane], np = t.pstart[lane + 1] - p0;
+            R pv[SH::NP];
+#pragma unroll
+            for (int i = 0; i < SH::NP; ++i) pv[i] = PART[p0 + i < 64 ? p0 + i : 63];
+            x = R(0);
+#pragma unroll
+            for (int i = 0; i < SH::NP; ++i) x += i < np ? pv[i] : R(0);
+        }
         if (takes_total) x = psum;
         if (has_filter || takes_total) {
             // sonopy clips at eps (safe_log); speechpy replaces exact zeros only (zero_handling): 0 < x < eps stays x
@@ -191,28 +272,26 @@ __device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, const pe_
         }
     }
     group_sync();
+    PE_T(8);
     // DCT-II (ortho): lane 4c + q adds its dct_len terms of coefficient c; quad reduction; c0 := log total power
     R part = R(0);
     {
         const int q = lane & 3;
-        constexpr int CH = 5;
-        for (int i0 = 0; i0 < t.dct_len; i0 += CH) {
-            R lv[CH], dv[CH];
+        R lv[SH::DCT], dv[SH::DCT];
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int i = i0 + u < t.dct_len ? i0 + u : t.dct_len - 1;
-                const int n = t.dct_len * q + i;
-                lv[u] = LM[n < n_filt ? n : n_filt - 1];
-                dv[u] = i0 + u < t.dct_len ? t.dct_w[i * 64 + lane] : R(0);
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) part = real_fma(dv[u], lv[u], part);
+        for (int i = 0; i < SH::DCT; ++i) {
+            const int n = t.dct_len * q + i;
+            lv[i] = LM[n < n_filt ? n : n_filt - 1];
+            dv[i] = t.dct_w[i * 64 + lane];
         }
+#pragma unroll
+        for (int i = 0; i < SH::DCT; ++i) part = real_fma(dv[i], lv[i], part);
     }
     const R c0 = LM[n_filt];
     part += __shfl_xor(part, 1, 64);
     part += __shfl_xor(part, 2, 64);
     group_sync();                           // the scratch may be rewritten by the next frame
+    PE_T(9);
     return lane < 4 ? c0 : part;
 }
 
@@ -235,8 +314,11 @@ struct FrameTask {          // wave-uniform description of one due frame
 };
 
 // the rare PCM path (odd chunk lengths, unaligned buffers, chunks shorter than a frame): one sample at a time
+struct RawFrame { int v[4]; };
+
 template <class R>
-__device__ __attribute__((noinline)) void fetch_frame_slow(const FrameTask<R>& f, int lane, int flen, int C, size_t update_stride, int (&raw)[4]) {
+__device__ __attribute__((noinline)) RawFrame fetch_frame_slow(const FrameTask<R> f, int lane, int flen, int C, size_t update_stride) {
+    RawFrame out;
     auto vsample = [&](int vv) -> int {
         if (vv < f.q) return (int)f.car[vv];
         int w = f.off0 + (vv - f.vb);
@@ -248,11 +330,12 @@ __device__ __attribute__((noinline)) void fetch_frame_slow(const FrameTask<R>& f
         const int n = 2 * (lane + 64 * a4);
         const int lo = n < flen ? (vsample(f.vb + n) & 0xffff) : 0;
         const int hi = n + 1 < flen ? vsample(f.vb + n + 1) : 0;
-        raw[a4] = lo | (hi << 16);
+        out.v[a4] = lo | (hi << 16);
     }
+    return out;
 }
 
-template <class R>
+template <class R, class SH>
 __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, const WaveTables<R>& wt, unsigned char* smem,
                                                  const int first_task, const int task_stride) {
     using K = RealK<R>;
@@ -271,19 +354,25 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
     //      the counters of the next task are requested one step ahead ---------------------------------------
     int s_next = first_task + wave, kb_next = 0;
     while (s_next >= row_tasks && kb_next < n_kb) { s_next -= row_tasks; ++kb_next; }
-    int pq = 0, pkc = 0;                                   // prefetched counters of the next task
-    auto request_counters = [&]() {
-        if (kb_next < n_kb && s_next < geo.n_streams) { pq = a.st_q[s_next]; pkc = (int)a.st_kc[s_next]; }
+    // the counters of the next TWO tasks are kept in flight (a wave's second task is often a frame row its stream does
+    // not reach in this call: skipping it must not cost a memory round trip before the first frame starts)
+    int s_req = s_next, kb_req = kb_next;                  // task the next request_counters() call fetches for
+    int pq0 = 0, pkc0 = 0, pq1 = 0, pkc1 = 0;              // [0]: counters of task (s_next, kb_next), [1]: of the one after
+    auto request_counters = [&](int& pq, int& pkc) {
+        if (kb_req < n_kb && s_req < geo.n_streams) { pq = a.st_q[s_req]; pkc = (int)a.st_kc[s_req]; }
+        s_req += task_stride;
+        while (s_req >= row_tasks && kb_req < n_kb) { s_req -= row_tasks; ++kb_req; }
     };
     // advance to the next DUE frame of this wave's task sequence; false when the sequence is exhausted
     auto next_frame = [&](FrameTask<R>& f) -> bool {
         while (kb_next < n_kb) {
             const int kb = kb_next, s = s_next;
-            const int q = __builtin_amdgcn_readfirstlane(pq);
-            const uint32_t kc = (uint32_t)__builtin_amdgcn_readfirstlane(pkc);
+            const int q = __builtin_amdgcn_readfirstlane(pq0);
+            const uint32_t kc = (uint32_t)__builtin_amdgcn_readfirstlane(pkc0);
             s_next += task_stride;
             while (s_next >= row_tasks && kb_next < n_kb) { s_next -= row_tasks; ++kb_next; }
-            request_counters();
+            pq0 = pq1; pkc0 = pkc1;
+            request_counters(pq1, pkc1);
             if (s >= geo.n_streams) continue;
             const int avail = q + U * C;
             const int nnew = avail >= flen ? 1 + (int)a.div_hop.div((uint32_t)(avail - flen)) : 0;
@@ -319,34 +408,38 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
                 raw[a4] = n < flen ? val : 0;
             }
         } else {
-            fetch_frame_slow<R>(f, lane, flen, C, update_stride, raw);
+            const RawFrame r = fetch_frame_slow<R>(f, lane, flen, C, update_stride);
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) raw[a4] = r.v[a4];
         }
     };
 
-    request_counters();
-    pe_wave::Tab<R> tab;
-    pe_wave::LaneConsts<R> lc;
-    R* const S = reinterpret_cast<R*>(smem + wt.L.total) + (size_t)wave * kWaveScratchReals;
+    PE_T(0);
+    // ---- kernel top: everything whose address is known without a dependent load goes out first ------------------
+    request_counters(pq0, pkc0);
+    request_counters(pq1, pkc1);
+    const TabRegs tab_regs = wave_tables_issue<R>(wt);                 // table image for LDS
+    // this lane's twiddles, straight from the global image (once per wave)
+    const pe_wave::LaneConsts<R> lc = pe_wave::lane_consts(pe_wave::bind<R>(static_cast<const unsigned char*>(wt.blob), wt.L), lane);
+    const pe_wave::Tab<R> tab = pe_wave::bind<R>(smem, wt.L, wave_lds_skip(wt.L));
+    R* const S = reinterpret_cast<R*>(smem + (wt.L.total - wave_lds_skip(wt.L))) + (size_t)wave * kWaveScratchReals;
     const int c = lane >> 2;
     pe_wave::Regs<R> v;
     float* row_cur = nullptr;
     float* prow_cur = nullptr;
     int raw[4] = {0, 0, 0, 0};
-    bool have_cur = false, first = true;
+    bool have_cur = false;
+    wave_tables_commit<R>(smem, wt, tab_regs);
+    PE_T(1);
     for (;;) {
         FrameTask<R> nxt;
         const bool have_next = next_frame(nxt);
         if (have_next) request_pcm(nxt, raw);              // lands while the current frame is transformed
-        if (first) {                                       // (the first request flies while the tables are copied to LDS)
-            tab = wave_tables_to_lds<R>(smem, wt);
-            __syncthreads();
-            lc = pe_wave::lane_consts(tab, lane);
-            first = false;
-        }
         if (have_cur) {
-            const R coeff = mfcc_wave_frame<R>(tab, lc, S, lane, geo.n_filt, geo.n_mfcc, v, K::PSCALE_I16, geo.log_mode);
+            const R coeff = mfcc_wave_frame<R, SH>(tab, lc, S, lane, geo.n_filt, geo.n_mfcc, v, K::PSCALE_I16, geo.log_mode);
             const float xf = c < geo.n_mfcc ? (float)coeff : 0.0f;
             if ((lane & 3) == 0) row_cur[c] = xf;
+            PE_T(10);
             if (prow_cur) {
                 // input projection of this frame, once, for every window it will appear in: row[o] = b[o] + sum_c x[c] W[c][o]
                 // (o in MFMA slot order); the rounded float32 features are what the network would have read
@@ -365,21 +458,24 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
             v.re[a4] = (R)(int)(short)(raw[a4] & 0xffff);
             v.im[a4] = (R)(raw[a4] >> 16);
         }
+        PE_T(2);
         row_cur = nxt.ring_row;
         prow_cur = nxt.proj_row;
         have_cur = true;
     }
+    PE_T(15);
 }
 
 // ---- stateless whole-buffer form (vectorize_raw): one frame per wave, float64 samples in -------------------------
-template <class R>
+template <class R, class SH>
 __device__ __forceinline__ void mfcc_offline_frames(const MfccOfflineArgs<R>& a, const WaveTables<R>& wt, unsigned char* smem) {
     const StreamGeom& geo = a.geo;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-    const pe_wave::Tab<R> tab = wave_tables_to_lds<R>(smem, wt);
-    __syncthreads();
-    R* S = reinterpret_cast<R*>(smem + wt.L.total) + (size_t)wave * kWaveScratchReals;
-    const pe_wave::LaneConsts<R> lc = pe_wave::lane_consts(tab, lane);
+    const TabRegs tab_regs = wave_tables_issue<R>(wt);
+    wave_tables_commit<R>(smem, wt, tab_regs);
+    const pe_wave::Tab<R> tab = pe_wave::bind<R>(smem, wt.L, wave_lds_skip(wt.L));
+    R* S = reinterpret_cast<R*>(smem + (wt.L.total - wave_lds_skip(wt.L))) + (size_t)wave * kWaveScratchReals;
+    const pe_wave::LaneConsts<R> lc = pe_wave::lane_consts(pe_wave::bind<R>(static_cast<const unsigned char*>(wt.blob), wt.L), lane);
     const int flen = geo.frame_len;
     for (long long fr = (long long)blockIdx.x * waves + wave; fr < a.n_frames; fr += (long long)gridDim.x * waves) {
         const double* x = a.audio + fr * geo.hop;
@@ -390,7 +486,7 @@ __device__ __forceinline__ void mfcc_offline_frames(const MfccOfflineArgs<R>& a,
             v.re[a4] = n < flen ? (R)x[n] : R(0);
             v.im[a4] = n + 1 < flen ? (R)x[n + 1] : R(0);
         }
-        const R coeff = mfcc_wave_frame<R>(tab, lc, S, lane, geo.n_filt, geo.n_mfcc, v, RealK<R>::INV_FFT, geo.log_mode);
+        const R coeff = mfcc_wave_frame<R, SH>(tab, lc, S, lane, geo.n_filt, geo.n_mfcc, v, RealK<R>::INV_FFT, geo.log_mode);
         const int c = lane >> 2;
         if ((lane & 3) == 0) {
             if (a.out && c < geo.n_mfcc) a.out[fr * geo.n_mfcc + c] = (double)coeff;

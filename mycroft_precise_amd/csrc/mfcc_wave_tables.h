@@ -52,6 +52,7 @@ PE_WAVE_HD inline int kbase_of(int l) { return (l >> 4) + 4 * ((l >> 2) & 3) + 1
 struct Layout {          // byte offsets into the blob (16-byte aligned sections)
     int tw1, tw2, tw3, w512, logtab, mel_w, dct_w, mel_start, pstart, partner, proj_w, proj_b, total;
     int proj_rows;       // 0: no input-projection epilogue; else n_mfcc (rows of proj_w)
+    int mel_pad, dct_pad, np_pad;     // loop bounds the kernel is compiled for (tables zero-padded up to them)
     int mel_len, dct_len, np_max;
 };
 
@@ -105,6 +106,12 @@ std::string build(const double* mel_filters, int n_filt, int n_mfcc, std::vector
     }
     if (!mel_len) return "mel filterbank too wide for one wave: the non-zero runs need more than 64 lanes of 16 bins";
     const int dct_len = (n_filt + 3) / 4;
+    // the kernel's table-driven loops have compile-time bounds: "stock" (10 / 5 / 8) when everything fits, else 16 / 16 / 16
+    int np_needed = 1;
+    for (int f = 0; f < n_filt; ++f) { const int n = hi[f] - lo[f]; np_needed = std::max(np_needed, n > 0 ? (n + mel_len - 1) / mel_len : 1); }
+    const bool stock = mel_len <= 10 && dct_len <= 5 && np_needed <= 8;
+    const int mel_pad = stock ? 10 : 16, dct_pad = stock ? 5 : 16, np_pad = stock ? 8 : 16;
+    if (np_needed > np_pad) return "mel filterbank: a filter is spread over more than 16 lanes";
     std::vector<int> pstart(kMaxFilt + 1, 0), mel_start(64, 0), seg_lo(64, 0), seg_n(64, 0), seg_f(64, -1);
     int lane = 0, np_max = 1;
     for (int f = 0; f < n_filt; ++f) {
@@ -119,7 +126,9 @@ std::string build(const double* mel_filters, int n_filt, int n_mfcc, std::vector
         }
     }
     for (int f = n_filt; f <= kMaxFilt; ++f) pstart[f] = lane;
-    L = layout((int)sizeof(R), mel_len, dct_len, np_max, proj_w ? n_mfcc : 0);
+    L = layout((int)sizeof(R), mel_pad, dct_pad, np_max, proj_w ? n_mfcc : 0);
+    L.mel_len = mel_len; L.dct_len = dct_len;
+    L.mel_pad = mel_pad; L.dct_pad = dct_pad; L.np_pad = np_pad;
     blob.assign((size_t)L.total, 0);
     if (proj_w) {
         std::memcpy(blob.data() + L.proj_w, proj_w, (size_t)n_mfcc * kProjRow * 4);
@@ -152,13 +161,13 @@ std::string build(const double* mel_filters, int n_filt, int n_mfcc, std::vector
             R v[2] = {(R)inv_c, (R)logc};
             std::memcpy(blob.data() + L.logtab + (size_t)i * 2 * sizeof(R), v, sizeof v);
         }
-    // mel runs: lane reads P[start .. start + mel_len), fully inside [0, 257)
+    // mel runs: lane reads P[start .. start + mel_pad), fully inside [0, 257)
     for (int l = 0; l < 64; ++l) {
         int start = seg_lo[l];
-        if (start + mel_len > kBins) start = kBins - mel_len;
+        if (start + mel_pad > kBins) start = kBins - mel_pad;
         if (seg_f[l] < 0) start = 0;
         put_i(L.mel_start, l, start);
-        for (int i = 0; i < mel_len; ++i) {
+        for (int i = 0; i < mel_pad; ++i) {
             const int k = start + i;
             double w = 0.0;
             if (seg_f[l] >= 0 && k >= seg_lo[l] && k < seg_lo[l] + seg_n[l]) w = mel_filters[(size_t)seg_f[l] * kBins + k];

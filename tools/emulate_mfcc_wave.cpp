@@ -70,7 +70,7 @@ static int run(int n_filt, int n_mfcc, int log_mode, const char* ffilt, const ch
         for (int l = 0; l < 64; ++l) { X[xchg_index(l, 0)] = {v[l].re[2], v[l].im[2]}; X[xchg_index(l, 1)] = {v[l].re[3], v[l].im[3]}; }
         cx<R> zq0[64], zq1[64];
         for (int l = 0; l < 64; ++l) {
-            const int pl = t.partner[l];
+            const int pl = lc[l].partner;
             zq0[l] = X[xchg_index(pl, 1)]; zq1[l] = X[xchg_index(pl, 0)];
             if (kbase_of(l) == 0) { zq0[l] = {v[l].re[0], v[l].im[0]}; zq1[l] = {v[l].re[3], v[l].im[3]}; }
         }

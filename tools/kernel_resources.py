@@ -28,4 +28,4 @@ for n, r in rows.items():
     if not re.search(pat, d):
         continue
     print('%-64s %5s %5s %5s %6s %7s %4s' % (d[:64], r.get('VGPRs'), r.get('AGPRs'), r.get('TotalSGPRs'),
-          r.get('VGPR Spill', '0'), r.get('LDS Size [bytes/block]'), r.get('Occupancy [waves/SIMD]')))
+          r.get('ScratchSize [bytes/lane]', r.get('VGPR Spill', '0')), r.get('LDS Size [bytes/block]'), r.get('Occupancy [waves/SIMD]')))
