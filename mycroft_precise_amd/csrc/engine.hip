@@ -145,6 +145,12 @@ int ensure(pe_engine* e, DeviceBuf& b, size_t bytes) {
 
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// floats of HBM behind the feature ring: 16 floats per row, or 16 bf16 (half of it) with ring_precision = 1
+size_t ring_floats(const pe_engine* e) {
+    const size_t rows = (size_t)e->n_tiles * e->ring_slots * kTileStreams;
+    return e->prm.ring_precision == 1 ? rows * kRowFloats / 2 : rows * kRowFloats;
+}
+
 
 template <class R>
 int build_tables(pe_engine* e, const double* mel_filters) {
@@ -376,7 +382,7 @@ MfccStreamArgs<R> mfcc_args(const pe_engine* e, const int16_t* pcm_dev, int chun
     const int c = e->cur, n = e->cur ^ 1;
     a.st_q = e->st_q[c]; a.st_kc = e->st_kc[c]; a.st_ke = e->st_ke[c];
     a.st_q_next = e->st_q[n]; a.st_kc_next = e->st_kc[n]; a.st_ke_next = e->st_ke[n];
-    a.ring = e->ring;
+    a.ring = e->ring; a.ring_bf16 = e->prm.ring_precision;
     a.proj_ring = e->proj_on ? e->proj_ring : nullptr;
     a.n_updates = 1; a.ke_hist = nullptr; a.n_padded = e->n_padded;
     a.n_frame_rows = max_frames_per_call(e, chunk); a.carry_next = e->carry_alt;
@@ -411,7 +417,7 @@ GruArgs gru_args(const pe_engine* e) {
     a.wx = e->wx; a.wr1 = e->wr1; a.wr2 = e->wr2; a.bias = e->bias; a.wd = e->wd;
     a.dense_bias = e->dense_bias;
     a.rk = e->rk_plain; a.wd_plain = e->wd_plain;
-    a.ring = e->ring; a.st_ke = e->st_ke[e->cur]; a.ring_slots = e->ring_slots;
+    a.ring = e->ring; a.st_ke = e->st_ke[e->cur]; a.ring_slots = e->ring_slots; a.ring_bf16 = e->prm.ring_precision;
     a.proj_ring = e->proj_on ? e->proj_ring : nullptr;
     a.predict_ke = 0;
     a.st_q = e->st_q[e->cur]; a.st_kc = e->st_kc[e->cur];
@@ -500,7 +506,7 @@ int do_update(pe_engine* e, const int16_t* pcm_dev, int chunk, float* raw_out_de
         if (t) { PE_HIP(e, hipEventRecord(e->ev[2], s)); e->ev_valid = true; e->ev_has_gru = raw_out_dev != nullptr; }
     }
     if (feats_out_dev) {
-        GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->ring, e->st_ke[e->cur], feats_out_dev};
+        GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, e->st_ke[e->cur], feats_out_dev};
         PE_HIP(e, launch_gather(g, s));
     }
     return PE_OK;
@@ -531,7 +537,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     if (p->vectorizer != 0 && p->vectorizer != 2 && p->vectorizer != 3)
         return fail(nullptr, PE_ERR_UNSUPPORTED, "vectorizer must be 2 (mfccs) or 3 (speechpy_mfccs); Vectorizer.mels (1) exists in the offline form only (pe_vectorize_mels), got %d", p->vectorizer);
     if (p->ring_precision != 0 && p->ring_precision != 1) return fail(nullptr, PE_ERR_INVALID, "ring_precision must be 0 (f32 rows) or 1 (bf16 rows)");
-    if (p->ring_precision == 1) return fail(nullptr, PE_ERR_UNSUPPORTED, "bf16 feature rows are not built yet");
+    if (p->ring_precision == 1 && p->gru_precision != 1) return fail(nullptr, PE_ERR_UNSUPPORTED, "bf16 feature rows (ring_precision = 1) feed the bf16-operand network only (gru_precision = 1)");
     if (w->n_layers < 1 || w->n_layers > 2 || !w->layers) return fail(nullptr, PE_ERR_UNSUPPORTED, "networks of 1 or 2 GRU layers have kernels (got %d layers)", w->n_layers);
     const pe_gru_layer& L = w->layers[0];
     const bool wide = w->n_layers == 2 || L.units > 32;
@@ -580,7 +586,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
             if ((rc = dev_alloc(e, &e->st_ke[b], (size_t)e->n_padded))) break;
         }
         if (rc) break;
-        if ((rc = dev_alloc(e, &e->ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kRowFloats))) break;
+        if ((rc = dev_alloc(e, &e->ring, ring_floats(e)))) break;
         if (wide) { if ((rc = pack_gru_weights_wide(e, w))) break; }
         else if ((rc = pack_gru_weights(e, L, w->dense_kernel))) break;
         if (p->gru_precision == 1 && (rc = pack_gru_weights_bf16(e, L, w->dense_kernel))) break;
@@ -630,7 +636,7 @@ int pe_clear(pe_engine* e, const uint8_t* mask_host) {
         PE_HIP(e, hipMemcpy(e->st_mask.p, mask_host, (size_t)e->n_streams, hipMemcpyHostToDevice));
         mask_dev = static_cast<const uint8_t*>(e->st_mask.p);
     }
-    ClearArgs a{e->n_padded, e->ring_slots, mask_dev, e->st_q[e->cur], e->st_kc[e->cur], e->st_ke[e->cur], e->ring, e->activation,
+    ClearArgs a{e->n_padded, e->ring_slots, mask_dev, e->st_q[e->cur], e->st_kc[e->cur], e->st_ke[e->cur], e->ring, e->prm.ring_precision, e->activation,
                 e->proj_on ? e->proj_ring : nullptr,
                 e->proj_on ? reinterpret_cast<const float*>(e->table_blob + e->table_layout.proj_b) : nullptr};
     if (mask_dev) a.n_streams = e->n_streams;
@@ -696,7 +702,7 @@ int pe_get_vectors(pe_engine* e, float* feats_out_host) {
     int rc;
     const size_t feat_bytes = (size_t)e->n_streams * e->prm.n_features * e->prm.n_mfcc * sizeof(float);
     if ((rc = ensure(e, e->st_feats, feat_bytes))) return rc;
-    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->ring, e->st_ke[e->cur], static_cast<float*>(e->st_feats.p)};
+    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, e->st_ke[e->cur], static_cast<float*>(e->st_feats.p)};
     PE_HIP(e, launch_gather(g, nullptr));
     PE_HIP(e, hipMemcpy(feats_out_host, e->st_feats.p, feat_bytes, hipMemcpyDeviceToHost));
     return PE_OK;
@@ -710,7 +716,7 @@ int pe_set_vectors(pe_engine* e, const float* feats_host) {
     const size_t feat_bytes = (size_t)e->n_streams * e->prm.n_features * e->prm.n_mfcc * sizeof(float);
     if ((rc = ensure(e, e->st_feats, feat_bytes))) return rc;
     PE_HIP(e, hipMemcpy(e->st_feats.p, feats_host, feat_bytes, hipMemcpyHostToDevice));
-    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->ring, e->st_ke[e->cur], static_cast<float*>(e->st_feats.p)};
+    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, e->st_ke[e->cur], static_cast<float*>(e->st_feats.p)};
     PE_HIP(e, launch_scatter(g, e->st_q[e->cur], e->st_kc[e->cur], nullptr));
     if (e->proj_on)
         PE_HIP(e, launch_project_rows(e->ring, e->proj_ring, reinterpret_cast<const float*>(e->table_blob + e->table_layout.proj_w),
@@ -901,12 +907,12 @@ int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samp
     const long long frames = ((long long)max_updates * max_chunk_samples + e->prm.hop_samples - 1) / e->prm.hop_samples + 1;
     const int slots = next_pow2((int)(e->prm.n_features + pending + frames));
     if (slots != e->ring_slots) {
-        dev_free(e, e->ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kRowFloats * sizeof(float));
+        dev_free(e, e->ring, ring_floats(e) * sizeof(float));
         e->ring = nullptr;
         dev_free(e, e->proj_ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kProjRow * sizeof(float));
         e->proj_ring = nullptr;
         e->ring_slots = slots;
-        int rc = dev_alloc(e, &e->ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kRowFloats);
+        int rc = dev_alloc(e, &e->ring, ring_floats(e));
         if (rc) return rc;
         if (e->proj_on && (rc = dev_alloc(e, &e->proj_ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kProjRow))) return rc;
     }

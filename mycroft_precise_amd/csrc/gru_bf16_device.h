@@ -69,7 +69,8 @@ __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, 
             if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
         }
         first = ke - (uint32_t)T;
-        xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats;
+        xbase = a.ring_bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.ring) + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats)
+                            : a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats;
     } else if (MODE == kRows) {
         const long long w = valid ? stream : 0;
         xbase = a.feats + ((size_t)w * a.row_stride) * kRowFloats;
@@ -78,6 +79,13 @@ __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, 
     }
     // lane group g supplies features 8 g .. 8 g + 7 (a ring row has 16 floats: groups 2, 3 supply zeros)
     auto load_x = [&](int t) -> bf16x8 {
+        if (MODE == kRing && a.ring_bf16) {
+            // bf16 rows: the 16 bytes a lane group needs ARE its MFMA operand (groups 2, 3 supply zeros)
+            const int tc = t < T ? t : T - 1;
+            const __bf16* p = reinterpret_cast<const __bf16*>(xbase) + (size_t)((first + (uint32_t)tc) & mask) * kTileStreams * kRowFloats + 8 * (g & 1);
+            const uint4 u = *reinterpret_cast<const uint4*>(p);
+            return g < 2 ? __builtin_bit_cast(bf16x8, u) : __builtin_bit_cast(bf16x8, uint4{0, 0, 0, 0});
+        }
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = 0.f;

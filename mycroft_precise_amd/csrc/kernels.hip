@@ -329,7 +329,10 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
     const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
     const size_t lds = frame_lds(t);
     const int fb = frame_blocks((long long)tiles * kTileStreams * m.n_frame_rows, n_cus);
-    const int gru_blocks = g.waves_per_tile == 4 ? tiles : (tiles + 3) / 4;
+    int gru_blocks = g.waves_per_tile == 4 ? tiles : (tiles + 3) / 4;
+    static const int skip = env_int("PE_FUSED_SKIP", 0);       // tuning aid: 1 = launch without the MFCC roles, 2 = without the network role
+    if (skip == 1) { hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false>), dim3(gru_blocks), dim3(256), lds, s, m, t, g, gru_blocks, 0, 0); return hipGetLastError(); }
+    if (skip == 2) gru_blocks = 0;
     const dim3 grid(gru_blocks + fb + tiles);
     if constexpr (RG == 5) {                 // (projection rows exist for the stock width only)
         if (g.proj_ring && g.waves_per_tile == 16) {
@@ -386,7 +389,8 @@ __global__ void gather_kernel(const GatherArgs a) {
     const uint32_t slot = (a.st_ke[s] - (uint32_t)a.n_features + (uint32_t)t) & (uint32_t)(a.ring_slots - 1);
     const long long tile = s / kTileStreams;
     const int j = (int)(s % kTileStreams);
-    a.out[idx] = a.ring[(((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kRowFloats + f];
+    const size_t at = (((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kRowFloats + f;
+    a.out[idx] = a.ring_bf16 ? (float)reinterpret_cast<const __bf16*>(a.ring)[at] : a.ring[at];
 }
 
 __global__ void scatter_kernel(const GatherArgs a, int32_t* st_q, uint32_t* st_kc) {
@@ -401,7 +405,9 @@ __global__ void scatter_kernel(const GatherArgs a, int32_t* st_q, uint32_t* st_k
     const long long tile = s / kTileStreams;
     const int j = (int)(s % kTileStreams);
     const float v = f < a.n_mfcc ? a.out[(s * a.n_features + t) * a.n_mfcc + f] : 0.0f;
-    const_cast<float*>(a.ring)[(((size_t)tile * a.ring_slots + t) * kTileStreams + j) * kRowFloats + f] = v;
+    const size_t at = (((size_t)tile * a.ring_slots + t) * kTileStreams + j) * kRowFloats + f;
+    if (a.ring_bf16) reinterpret_cast<__bf16*>(const_cast<float*>(a.ring))[at] = (__bf16)v;
+    else const_cast<float*>(a.ring)[at] = v;
     if (f == 0 && t == 0) {
         st_q[s] = 0;
         st_kc[s] = (uint32_t)a.n_features;
@@ -426,7 +432,9 @@ __global__ void clear_kernel(const ClearArgs a) {
     const int j = (int)(s % kTileStreams);
     for (int i = threadIdx.x; i < a.ring_slots * kRowFloats; i += blockDim.x) {
         const int slot = i / kRowFloats, f = i % kRowFloats;
-        a.ring[(((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kRowFloats + f] = 0.0f;
+        const size_t at = (((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kRowFloats + f;
+        if (a.ring_bf16) reinterpret_cast<__bf16*>(a.ring)[at] = (__bf16)0.0f;
+        else a.ring[at] = 0.0f;
     }
     if (a.proj_ring)            // the projection of an all-zero frame is the bias row
         for (int i = threadIdx.x; i < a.ring_slots * kProjRow; i += blockDim.x) {

@@ -388,7 +388,8 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
             f.row = a.pcm + (size_t)s * C + (size_t)u0 * update_stride;
             const int slot = (int)((kc + (uint32_t)kb) & (uint32_t)(slots - 1));
             const size_t cell = ((size_t)tile * slots + slot) * kTileStreams + j;
-            f.ring_row = a.ring + cell * kRowFloats;
+            f.ring_row = a.ring_bf16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(a.ring) + cell * kRowFloats)
+                                     : a.ring + cell * kRowFloats;
             f.proj_row = a.proj_ring ? a.proj_ring + cell * kProjRow : nullptr;
             return true;
         }
@@ -438,7 +439,10 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
         if (have_cur) {
             const R coeff = mfcc_wave_frame<R, SH>(tab, lc, S, lane, geo.n_filt, geo.n_mfcc, v, K::PSCALE_I16, geo.log_mode);
             const float xf = c < geo.n_mfcc ? (float)coeff : 0.0f;
-            if ((lane & 3) == 0) row_cur[c] = xf;
+            if ((lane & 3) == 0) {
+                if (a.ring_bf16) reinterpret_cast<__bf16*>(row_cur)[c] = (__bf16)xf;     // round to nearest even where the row is stored
+                else row_cur[c] = xf;
+            }
             PE_T(10);
             if (prow_cur) {
                 // input projection of this frame, once, for every window it will appear in: row[o] = b[o] + sum_c x[c] W[c][o]

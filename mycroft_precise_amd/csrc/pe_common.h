@@ -77,7 +77,8 @@ struct MfccStreamArgs {
     int32_t* st_q_next;
     uint32_t* st_kc_next;
     uint32_t* st_ke_next;
-    float* ring;            // [n_tiles][ring_slots][16 streams][16 floats]
+    float* ring;            // [n_tiles][ring_slots][16 streams][16 floats] -- or, ring_bf16, 16 bf16 per row (32 bytes)
+    int ring_bf16;
     float* proj_ring;       // [n_tiles][ring_slots][16 streams][64 floats] x.W + b of every frame, or null
     // several updates per launch (mfcc_many_tile): chunk u of stream s at pcm + (u*n_streams + s)*chunk
     int n_updates;
@@ -127,6 +128,7 @@ struct GruArgs {
     const float* wd_bf16;   // [8][64]
     // input: either the feature ring (+ per-stream emitted-frame counters) ...
     const float* ring;
+    int ring_bf16;          // rows hold 16 bf16 (32 bytes) instead of 16 floats: bf16-operand kernel only
     // ... with, when the MFCC stage wrote it, the input projection x.W + b of every frame beside it, in MFMA slot
     // order [tile][slot][stream][g][output tile][q]: the network then starts every timestep from that accumulator
     // instead of recomputing the projection in each of the n_features windows the frame appears in
@@ -167,7 +169,7 @@ struct WideArgs {
 };
 
 struct GatherArgs {         // ring -> [n][T][F] time-ordered features (update_vectors result)
-    int n_streams, n_features, n_mfcc, ring_slots;
+    int n_streams, n_features, n_mfcc, ring_slots, ring_bf16;
     const float* ring;
     const uint32_t* st_ke;
     float* out;
@@ -178,6 +180,7 @@ struct ClearArgs {
     const uint8_t* mask;
     int32_t* st_q; uint32_t* st_kc; uint32_t* st_ke;
     float* ring;
+    int ring_bf16;
     int32_t* activation;    // per-stream trigger state, may be null
     float* proj_ring;       // input-projection rows, may be null: a cleared row is the projection of a zero frame = bias
     const float* proj_b;    // [kProjRow]

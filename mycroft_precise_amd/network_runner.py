@@ -241,7 +241,7 @@ class BatchedListener:
     """
 
     def __init__(self, model, n_streams: int, device: int = 0, mfcc_precision: str = 'f64', params=None,
-                 gru_precision: str = 'f32'):
+                 gru_precision: str = 'f32', ring_precision: str = 'f32'):
         if isinstance(model, str):
             self.pr = inject_params(model).copy()
             weights = load_weights(model)
@@ -252,7 +252,7 @@ class BatchedListener:
         self.weights = weights
         _require_streamable(self.pr)
         self.engine = HipEngine(self.pr, weights, n_streams=self.n_streams, device=device,
-                                mfcc_precision=mfcc_precision, gru_precision=gru_precision)
+                                mfcc_precision=mfcc_precision, gru_precision=gru_precision, ring_precision=ring_precision)
         self.threshold_decoder = ThresholdDecoder(self.pr.threshold_config, self.pr.threshold_center)
         self.engine.set_decoder(self.threshold_decoder)
         self._trigger = False

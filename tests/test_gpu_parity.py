@@ -675,6 +675,46 @@ def test_bf16_network_within_1e2_of_oracle(stock_weights, mfcc):
     eng.close()
 
 
+def test_bf16_feature_rows_equal_float32_rows_rounded_at_the_load(stock_weights):
+    """ring_precision='bf16' (BASELINE configs[4]: "bf16 MFCC+GRU"): the MFCC stage rounds each row to bf16 where it
+    stores it (round to nearest even) -- the same rounding the bf16 network applies to float32 rows when it loads
+    them, so the two layouts must agree BIT FOR BIT on every output; Listener.mfccs reads back the rounded rows."""
+    from mycroft_precise_amd._lib import HipEngine
+    n, n_up = 45, 40
+    pcm = _stream_batch(['tone_noise'] * (n - 3) + ['zeros', 'square', 'quiet'], n_up)
+    for mfcc in ('f32', 'f64'):
+        a = HipEngine(P.pr, stock_weights, n_streams=n, mfcc_precision=mfcc, gru_precision='bf16')
+        b = HipEngine(P.pr, stock_weights, n_streams=n, mfcc_precision=mfcc, gru_precision='bf16', ring_precision='bf16')
+        c = HipEngine(P.pr, stock_weights, n_streams=n, mfcc_precision=mfcc, gru_precision='bf16', ring_precision='bf16')
+        c.set_fused(False)
+        d = HipEngine(P.pr, stock_weights, n_streams=n, mfcc_precision=mfcc, gru_precision='bf16', ring_precision='bf16')
+        d.reserve_updates(4, 1024)
+        outs = []
+        for u in range(n_up):
+            if u == 17:
+                mask = np.zeros(n, np.uint8); mask[::4] = 1
+                for e in (a, b, c):
+                    e.clear(mask)
+            ra, rb, rc = a.update(pcm[u]), b.update(pcm[u]), c.update(pcm[u])
+            assert np.array_equal(ra, rb) and np.array_equal(rb, rc), (mfcc, u)
+            if u < 16:
+                outs.append(rb)
+        for u in range(0, 16, 4):
+            assert np.array_equal(d.update_many(pcm[u:u + 4]), np.stack(outs[u:u + 4])), (mfcc, u)
+        fa, fb = a.get_vectors(), b.get_vectors()
+        import torch
+        want = torch.from_numpy(fa).to(torch.bfloat16).to(torch.float32).numpy()        # round to nearest even
+        assert np.array_equal(fb, want)
+        assert b.info().device_bytes < a.info().device_bytes
+        feats = np.random.default_rng(2).normal(0, 3, (n, 29, 13)).astype(np.float32)
+        b.set_vectors(feats)
+        assert np.array_equal(b.get_vectors(), torch.from_numpy(feats).to(torch.bfloat16).to(torch.float32).numpy())
+        for e in (a, b, c, d):
+            e.close()
+    with pytest.raises(NotImplementedError):
+        HipEngine(P.pr, stock_weights, n_streams=4, ring_precision='bf16')          # bf16 rows feed the bf16 network only
+
+
 @pytest.mark.parametrize('units', [8, 20, 32])
 def test_bf16_network_other_widths(units):
     from mycroft_precise_amd._lib import HipEngine
@@ -884,11 +924,13 @@ def test_full_batch_wide_gru_4096_streams_properties():
     assert np.array_equal(hip.engine.predict(feats)[:, 0], first[-1])
 
 
-@pytest.mark.parametrize('B', [8192, 65536])
-def test_full_batch_bf16_properties(stock_weights, B):
-    """BASELINE configs[4] per-GPU shapes: 8192 and 65536 streams, bf16 network + float32 front end; the
-    launch policy differs between the two (tiles <= / > compute units)."""
-    hip, base, owner, first = _full_size_run(stock_weights, B, 32, 24, TOL_BF16, mfcc_precision='f32', gru_precision='bf16')
+@pytest.mark.parametrize('B,ring', [(8192, 'f32'), (8192, 'bf16'), (65536, 'bf16')])
+def test_full_batch_bf16_properties(stock_weights, B, ring):
+    """BASELINE configs[4] per-GPU shapes: 8192 and 65536 streams, bf16 network + float32 front end, feature rows
+    kept as float32 or as bf16 (32 bytes per frame and stream); the launch policy differs between the two sizes
+    (tiles <= / > compute units)."""
+    hip, base, owner, first = _full_size_run(stock_weights, B, 32, 24, TOL_BF16, mfcc_precision='f32', gru_precision='bf16',
+                                             ring_precision=ring)
     # both launch shapes of the network agree bit for bit at this size too
     hip.engine.set_fused(False)
     hip.clear()
