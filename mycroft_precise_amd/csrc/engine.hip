@@ -242,7 +242,9 @@ uint16_t to_bf16(float f) {
 }
 
 int pack_gru_weights_bf16(pe_engine* e, const pe_gru_layer& L, const float* dense_kernel) {
-    const int H = L.units, F = L.n_in;
+    // with use_delta the layer has 2 F inputs: features in k = 0..15, their first differences in k = 16..31
+    const bool delta = e->prm.use_delta != 0;
+    const int H = L.units, F = delta ? L.n_in / 2 : L.n_in;
     std::vector<uint16_t> wx((size_t)6 * 64 * 8, 0), wr((size_t)6 * 64 * 8, 0);
     std::vector<float> bias((size_t)6 * 4 * 64, 0.f), wd((size_t)8 * 64, 0.f);
     for (int tl = 0; tl < 6; ++tl) {
@@ -256,6 +258,7 @@ int pack_gru_weights_bf16(pe_engine* e, const pe_gru_layer& L, const float* dens
                 for (int ek = 0; ek < 8; ++ek) {
                     const int k = 8 * g + ek;
                     if (k < F) wx[((size_t)tl * 64 + lane) * 8 + ek] = to_bf16(L.kernel[(size_t)k * 3 * H + col]);
+                    if (delta && k >= 16 && k - 16 < F) wx[((size_t)tl * 64 + lane) * 8 + ek] = to_bf16(L.kernel[(size_t)(F + k - 16) * 3 * H + col]);
                     if (k < H) wr[((size_t)tl * 64 + lane) * 8 + ek] = to_bf16(L.recurrent_kernel[(size_t)k * 3 * H + col]);
                 }
             }
@@ -531,7 +534,6 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         return fail(nullptr, PE_ERR_UNSUPPORTED, "need 1 <= n_mfcc <= n_filt <= 64 (got n_filt=%d n_mfcc=%d)", p->n_filt, p->n_mfcc);
     if (p->hop_samples < 1 || p->window_samples < 1 || p->n_features < 1)
         return fail(nullptr, PE_ERR_INVALID, "window/hop/n_features must be positive");
-    if (p->use_delta && p->gru_precision != 0) return fail(nullptr, PE_ERR_UNSUPPORTED, "use_delta has no bf16 kernel");
     if (p->mfcc_precision != 0 && p->mfcc_precision != 1) return fail(nullptr, PE_ERR_INVALID, "mfcc_precision must be 0 (f64) or 1 (f32)");
     if (p->gru_precision != 0 && p->gru_precision != 1) return fail(nullptr, PE_ERR_INVALID, "gru_precision must be 0 (f32) or 1 (bf16 operands)");
     if (p->vectorizer != 0 && p->vectorizer != 2 && p->vectorizer != 3)
@@ -542,15 +544,18 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     const pe_gru_layer& L = w->layers[0];
     const bool wide = w->n_layers == 2 || L.units > 32;
     if (!wide && L.units < 1) return fail(nullptr, PE_ERR_INVALID, "units must be positive");
+    int wide_units = 0;          // width the streamed-weight kernel runs at: the layers' widths padded to a multiple of 64
     if (wide) {
-        if (L.units % 64 != 0 || L.units < 64 || L.units > 256)
-            return fail(nullptr, PE_ERR_UNSUPPORTED, "the streamed-weight GRU kernel needs units in {64, 128, 192, 256} (got %d); the register-resident one units <= 32 and one layer", L.units);
-        if (p->use_delta || p->gru_precision != 0) return fail(nullptr, PE_ERR_UNSUPPORTED, "use_delta / bf16 have no wide-GRU kernel");
+        int hmax = L.units;
         if (w->n_layers == 2) {
             const pe_gru_layer& L2 = w->layers[1];
-            if (L2.units != L.units || L2.n_in != L.units) return fail(nullptr, PE_ERR_UNSUPPORTED, "stacked layers must have equal widths (layer 2: n_in=%d units=%d)", L2.n_in, L2.units);
             if (!L2.kernel || !L2.recurrent_kernel || !L2.bias) return fail(nullptr, PE_ERR_INVALID, "null weight pointer");
+            if (L2.n_in != L.units || L2.units < 1) return fail(nullptr, PE_ERR_INVALID, "layer 2 (n_in=%d, units=%d) does not follow layer 1 (units=%d)", L2.n_in, L2.units, L.units);
+            if (L2.units > hmax) hmax = L2.units;
         }
+        if (hmax > 256) return fail(nullptr, PE_ERR_UNSUPPORTED, "the streamed-weight GRU kernel holds up to 256 units per layer (got %d)", hmax);
+        if (p->use_delta || p->gru_precision != 0) return fail(nullptr, PE_ERR_UNSUPPORTED, "use_delta / bf16 have no wide-GRU kernel");
+        wide_units = (hmax + 63) / 64 * 64;
     }
     const int feature_size = p->use_delta ? 2 * p->n_mfcc : p->n_mfcc;          // params.py:99-109
     if (L.n_in != feature_size) return fail(nullptr, PE_ERR_INVALID, "layer n_in=%d does not match feature_size=%d", L.n_in, feature_size);
@@ -587,7 +592,32 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         }
         if (rc) break;
         if ((rc = dev_alloc(e, &e->ring, ring_floats(e)))) break;
-        if (wide) { if ((rc = pack_gru_weights_wide(e, w))) break; }
+        if (wide) {
+            // Any width 33..256 (and stacked layers of different widths) runs on the streamed-weight kernel at the next
+            // multiple of 64: a padded unit has zero weights and zero bias everywhere, so z = r = 1/2, candidate = 0 and
+            // its state stays exactly 0 -- it neither receives nor contributes anything.
+            const int Hp = wide_units;
+            std::vector<std::vector<float>> kp(w->n_layers), rp(w->n_layers), bp(w->n_layers);
+            std::vector<pe_gru_layer> lp(w->n_layers);
+            for (int l = 0; l < w->n_layers; ++l) {
+                const pe_gru_layer& Ls = w->layers[l];
+                const int Hs = Ls.units, Fin = Ls.n_in, Fp = l == 0 ? Fin : Hp;
+                kp[l].assign((size_t)Fp * 3 * Hp, 0.f); rp[l].assign((size_t)Hp * 3 * Hp, 0.f); bp[l].assign((size_t)3 * Hp, 0.f);
+                for (int gate = 0; gate < 3; ++gate)
+                    for (int u = 0; u < Hs; ++u) {
+                        for (int k = 0; k < Fin; ++k) kp[l][(size_t)k * 3 * Hp + gate * Hp + u] = Ls.kernel[(size_t)k * 3 * Hs + gate * Hs + u];
+                        for (int k = 0; k < Hs; ++k) rp[l][(size_t)k * 3 * Hp + gate * Hp + u] = Ls.recurrent_kernel[(size_t)k * 3 * Hs + gate * Hs + u];
+                        bp[l][(size_t)gate * Hp + u] = Ls.bias[gate * Hs + u];
+                    }
+                lp[l] = pe_gru_layer{Fp, Hp, kp[l].data(), rp[l].data(), bp[l].data()};
+            }
+            std::vector<float> dp(Hp, 0.f);
+            const int Hlast = w->layers[w->n_layers - 1].units;
+            for (int u = 0; u < Hlast; ++u) dp[u] = w->dense_kernel[u];
+            pe_weights wp{w->n_layers, lp.data(), dp.data(), w->dense_bias};
+            e->units = Hp;
+            if ((rc = pack_gru_weights_wide(e, &wp))) break;
+        }
         else if ((rc = pack_gru_weights(e, L, w->dense_kernel))) break;
         if (p->gru_precision == 1 && (rc = pack_gru_weights_bf16(e, L, w->dense_kernel))) break;
         // the projection rows exist for the stock-width float32 network (3 R <= 16 slots: 4 output tiles, R = 5) fed
@@ -900,7 +930,6 @@ int pe_decode(pe_engine* e, const float* raw_host, double* conf_out_host, unsign
 
 int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samples) {
     if (!e || max_updates < 1 || max_chunk_samples < 1) return fail(e, PE_ERR_INVALID, "bad arguments to pe_reserve_updates");
-    if (e->wide) return fail(e, PE_ERR_UNSUPPORTED, "pe_update_many has no wide-GRU path");
     PE_HIP(e, hipSetDevice(e->device));
     PE_HIP(e, hipDeviceSynchronize());
     const int pending = pending_frames(e->prm);
@@ -957,6 +986,18 @@ int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, i
     GruArgs g = gru_args(e);
     g.st_ke = e->ke_hist;
     g.out = raw_out_dev;
+    if (e->wide) {
+        // the streamed-weight network: one launch per update of the call (each fills the machine on its own), the
+        // window of update u found through its row of the emitted-frame history
+        for (int u = 0; u < n_updates; ++u) {
+            GruArgs gu = g;
+            gu.st_ke = e->ke_hist + (size_t)u * e->n_padded;
+            gu.out = raw_out_dev + (size_t)u * e->n_streams;
+            int nrc = launch_network(e, gu, 1, s);
+            if (nrc) return nrc;
+        }
+        return PE_OK;
+    }
     if (g.waves_per_tile != 16) g.waves_per_tile = 1;     // (16: the engine's updates run the DPP kernel, and so does the batch;
                                                           //  otherwise the launcher picks one or four waves per window itself)
     PE_HIP(e, launch_gru_many(g, n_updates, e->n_padded, s));

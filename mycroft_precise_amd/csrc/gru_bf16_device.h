@@ -75,11 +75,19 @@ __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, 
         const long long w = valid ? stream : 0;
         xbase = a.feats + ((size_t)w * a.row_stride) * kRowFloats;
     } else {
-        xbase = a.feats + (size_t)(valid ? stream : 0) * T * a.n_in;
+        xbase = a.feats + (size_t)(valid ? stream : 0) * T * (a.use_delta ? 2 * a.n_in : a.n_in);
     }
-    // lane group g supplies features 8 g .. 8 g + 7 (a ring row has 16 floats: groups 2, 3 supply zeros)
+    // use_delta (vectorization.py:53-59): K = 32 holds the 13 features in k = 0..15 AND their first differences in
+    // k = 16..31, so the same single MFMA per output tile covers the doubled input; lane groups 2, 3 form x_t - x_(t-1)
+    // from the rows they fetch (zero at the first timestep); an explicit batch carries its delta columns
+    const bool delta = a.use_delta != 0;
+    const int frow = delta ? 2 * a.n_in : a.n_in;
+    // lane group g supplies k = 8 g .. 8 g + 7: features 8 (g & 1) .. + 7 (groups 0, 1), zeros or deltas (groups 2, 3)
+    float vprev[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vprev[i] = 0.f;
     auto load_x = [&](int t) -> bf16x8 {
-        if (MODE == kRing && a.ring_bf16) {
+        if (MODE == kRing && a.ring_bf16 && !delta) {
             // bf16 rows: the 16 bytes a lane group needs ARE its MFMA operand (groups 2, 3 supply zeros)
             const int tc = t < T ? t : T - 1;
             const __bf16* p = reinterpret_cast<const __bf16*>(xbase) + (size_t)((first + (uint32_t)tc) & mask) * kTileStreams * kRowFloats + 8 * (g & 1);
@@ -90,17 +98,32 @@ __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = 0.f;
         const int tc = t < T ? t : T - 1;
+        const int fg = 8 * (g & 1);                            // first feature of this lane group's slice
         if (MODE == kFeats) {
-            const float* p = xbase + (size_t)tc * a.n_in;
+            const float* p = xbase + (size_t)tc * frow + (g >= 2 ? a.n_in : 0);      // groups 2, 3: the batch's delta columns
 #pragma unroll
-            for (int i = 0; i < 8; ++i) if (valid && 8 * g + i < a.n_in) v[i] = p[8 * g + i];
-        } else if (g < 2) {
-            const float* p = (MODE == kRing)
-                ? xbase + (size_t)((first + (uint32_t)tc) & mask) * kTileStreams * kRowFloats + 8 * g
-                : xbase + (size_t)tc * kRowFloats + 8 * g;
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+            for (int i = 0; i < 8; ++i) if (valid && (g < 2 || delta) && fg + i < a.n_in) v[i] = p[fg + i];
+            return pack_bf16(v);
+        }
+        if (g < 2 || delta) {
+            if (MODE == kRing && a.ring_bf16) {
+                const __bf16* p = reinterpret_cast<const __bf16*>(xbase) + (size_t)((first + (uint32_t)tc) & mask) * kTileStreams * kRowFloats + fg;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { v[i] = lo[i]; v[4 + i] = hi[i]; }
+                for (int i = 0; i < 8; ++i) v[i] = (float)p[i];
+            } else {
+                const float* p = (MODE == kRing)
+                    ? xbase + (size_t)((first + (uint32_t)tc) & mask) * kTileStreams * kRowFloats + fg
+                    : xbase + (size_t)tc * kRowFloats + fg;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[i] = lo[i]; v[4 + i] = hi[i]; }
+            }
+        }
+        if (g >= 2) {                                          // (delta only: otherwise v is zero)
+            float d[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { d[i] = (t > 0 && t < T) ? v[i] - vprev[i] : 0.f; vprev[i] = v[i]; }
+            return pack_bf16(d);
         }
         return pack_bf16(v);
     };

@@ -114,12 +114,22 @@ __global__ __launch_bounds__(64) void gru_bf16_kernel(const GruArgs a) {
     gru_tile_bf16<MODE>(a, blockIdx.x, threadIdx.x);
 }
 
+// Dispatch order of the roles of a fused launch.  Workgroups are handed to the CUs in blockIdx order; `frames_first`
+// puts the (few, long-lived, VALU-bound) frame workgroups in front of the (many, MFMA-bound) network workgroups so
+// that at large batches the two kinds are resident TOGETHER -- with the network first, its workgroups fill every
+// wave slot and the frame role only starts when they drain (the launch then costs the SUM of the two roles).
+// Returns the index in the canonical order [network | frames | bookkeeping].
+__device__ __forceinline__ int role_block(const int b, const int n_gru, const int n_frames, const int frames_first) {
+    if (!frames_first || b >= n_gru + n_frames) return b;
+    return b < n_frames ? n_gru + b : b - n_frames;
+}
+
 // fused update with the bf16 network role (four tiles per GRU workgroup, one wave each)
 template <class R, class SH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_bf16_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
-                                                                const int n_gru_blocks, const int n_frame_blocks, const int n_tiles) {
+                                                                const int n_gru_blocks, const int n_frame_blocks, const int n_tiles, const int frames_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x;
+    const int b = role_block(blockIdx.x, n_gru_blocks, n_frame_blocks, frames_first);
     if (b < n_gru_blocks) {
         const int tile = b * 4 + (threadIdx.x >> 6);
         if (tile < n_tiles) gru_tile_bf16<kRing>(g, tile, threadIdx.x & 63);
@@ -178,9 +188,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 // its four waves share the tile (gru_tile_mw); MW = false: four tiles per GRU workgroup, one wave each.
 template <class R, class SH, int RG, bool MW, bool PROJ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
-                                                           const int n_gru_blocks, const int n_frame_blocks, const int n_tiles) {
+                                                           const int n_gru_blocks, const int n_frame_blocks, const int n_tiles, const int frames_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x;
+    const int b = role_block(blockIdx.x, n_gru_blocks, n_frame_blocks, frames_first);
     if (b < n_gru_blocks) {
         __builtin_amdgcn_s_setprio(3);          // the network role is the long pole: it wins every issue arbitration
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -203,8 +213,9 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
 }
-static int frame_blocks(long long n_tasks, int n_cus) {
-    static const int per_cu = env_int("PE_FRAME_WG_PER_CU", 4);      // tuning knob (tools/): resident frame workgroups per CU
+static int frame_blocks(long long n_tasks, int n_cus, int per_cu_default = 4) {
+    static const int per_cu_env = env_int("PE_FRAME_WG_PER_CU", 0);      // tuning knob (tools/): resident frame workgroups per CU
+    const int per_cu = per_cu_env ? per_cu_env : per_cu_default;
     const long long need = (n_tasks + kFrameWaves - 1) / kFrameWaves;
     const long long cap = (long long)n_cus * per_cu;
     return (int)(need < cap ? (need < 1 ? 1 : need) : cap);
@@ -328,10 +339,16 @@ template <class R, int RG>
 static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R>& t, const GruArgs& g, int n_cus, hipStream_t s) {
     const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
     const size_t lds = frame_lds(t);
-    const int fb = frame_blocks((long long)tiles * kTileStreams * m.n_frame_rows, n_cus);
+    // more network workgroups than the machine holds at once: frames first, three frame workgroups per CU, the network
+    // streams through the remaining wave slots (measured at 16384 / 65536 streams, bf16 network + float32 front end:
+    // 31.8 / 103.8 us against 35.5 / 109.0 us network-first; the float64 front end gains nothing either way -- its
+    // FP64 multiply-adds and the MFMAs do not overlap on a SIMD)
+    static const int ff_env = env_int("PE_FUSED_FRAMES_FIRST", -1);
+    const int frames_first = ff_env >= 0 ? ff_env : (g.waves_per_tile != 4 && tiles >= 4 * n_cus);
+    const int fb = frame_blocks((long long)tiles * kTileStreams * m.n_frame_rows, n_cus, frames_first ? 3 : 4);
     int gru_blocks = g.waves_per_tile == 4 ? tiles : (tiles + 3) / 4;
     static const int skip = env_int("PE_FUSED_SKIP", 0);       // tuning aid: 1 = launch without the MFCC roles, 2 = without the network role
-    if (skip == 1) { hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false>), dim3(gru_blocks), dim3(256), lds, s, m, t, g, gru_blocks, 0, 0); return hipGetLastError(); }
+    if (skip == 1) { hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false>), dim3(gru_blocks), dim3(256), lds, s, m, t, g, gru_blocks, 0, 0, 0); return hipGetLastError(); }
     if (skip == 2) gru_blocks = 0;
     const dim3 grid(gru_blocks + fb + tiles);
     if constexpr (RG == 5) {                 // (projection rows exist for the stock width only)
@@ -340,13 +357,13 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
             return hipGetLastError();
         }
         if (g.proj_ring) {
-            if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
-            else hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
+            if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles, frames_first);
+            else hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles, frames_first);
             return hipGetLastError();
         }
     }
-    if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
-    else hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles);
+    if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles, frames_first);
+    else hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles, frames_first);
     return hipGetLastError();
 }
 
@@ -357,8 +374,10 @@ static hipError_t launch_fused(const MfccStreamArgs<R>& m, const WaveTables<R>& 
     if (g.bf16) {
         const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
         const int gru_blocks = (tiles + 3) / 4;
-        const int fb = frame_blocks((long long)tiles * kTileStreams * m.n_frame_rows, n_cus);
-        hipLaunchKernelGGL((fused_update_bf16_kernel<R, ShapeStock>), dim3(gru_blocks + fb + tiles), dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles);
+        static const int ff_env = env_int("PE_FUSED_FRAMES_FIRST", -1);
+        const int frames_first = ff_env >= 0 ? ff_env : (tiles >= 4 * n_cus);
+        const int fb = frame_blocks((long long)tiles * kTileStreams * m.n_frame_rows, n_cus, frames_first ? 3 : 4);
+        hipLaunchKernelGGL((fused_update_bf16_kernel<R, ShapeStock>), dim3(gru_blocks + fb + tiles), dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles, frames_first);
         return hipGetLastError();
     }
     switch (gru_small_regs(g.units)) {

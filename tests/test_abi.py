@@ -59,12 +59,12 @@ def test_create_argument_validation_without_gpu():
     delta.__dict__['use_delta'] = True
     with pytest.raises(ValueError):                 # use_delta needs a layer with 2 * n_mfcc inputs
         _lib.HipEngine(delta, w, n_streams=1)
-    odd = synth.make_weights(units=(100,))               # neither <= 32 nor a multiple of 64
+    big = synth.make_weights(units=(320,))               # the streamed-weight kernel holds up to 256 units per layer
     with pytest.raises(NotImplementedError):
-        _lib.HipEngine(pr, odd, n_streams=1)
-    uneven = synth.make_weights(units=(128, 64))
+        _lib.HipEngine(pr, big, n_streams=1)
+    deep = synth.make_weights(units=(64, 64, 64))        # one or two GRU layers have kernels
     with pytest.raises(NotImplementedError):
-        _lib.HipEngine(pr, uneven, n_streams=1)
+        _lib.HipEngine(pr, deep, n_streams=1)
 
 
 @pytest.mark.skipif(os.path.exists('/dev/kfd'), reason='a GPU is present')

@@ -23,6 +23,7 @@ from oracle import listener as ol, keras_gru
 pytestmark = pytest.mark.gpu
 
 TOL_RAW = 1e-4          # north_star bar
+TOL_BF16 = 1e-2         # BASELINE configs[4]
 GUARD_RAW = 2e-5        # regression guard: what the kernels actually achieve, with margin
 TOL_FEAT32 = 2e-5       # float32 rounding of |feature| <= 40
 TOL_DECODE = 2e-3       # one LUT bin of ThresholdDecoder (step function of logit(raw))
@@ -580,6 +581,27 @@ def test_use_delta_matches_reference_semantics(tmp_path):
     assert np.abs(engines[0].predict(x) - keras_gru.predict(x, w)).max() <= GUARD_RAW
     for eng in engines:
         eng.close()
+    # the bf16-operand network carries the deltas in the upper half of its K = 32 contraction (tol 1e-2), for float32
+    # and bf16 feature rows; fused == two launches == pe_update_many; explicit batches with their delta columns
+    refs = [ol.OracleListener(w, opr) for _ in range(n)]
+    for ring in ('f32', 'bf16'):
+        eb = [HipEngine(hpr, w, n_streams=n, gru_precision='bf16', ring_precision=ring) for _ in range(3)]
+        eb[1].set_fused(False)
+        eb[2].reserve_updates(4, 1024)
+        outs, worst = [], 0.0
+        for u in range(n_up):
+            got = eb[0].update(pcm[u])
+            assert np.array_equal(got, eb[1].update(pcm[u])), (ring, u)
+            if ring == 'f32':
+                want = np.array([r.update_raw(pcm[u, j].tobytes()) for j, r in enumerate(refs)])
+                worst = max(worst, float(np.abs(got - want).max()))
+            outs.append(got)
+        assert worst <= TOL_BF16, worst
+        for u in range(0, 16, 4):
+            assert np.array_equal(eb[2].update_many(pcm[u:u + 4]), np.stack(outs[u:u + 4])), (ring, u)
+        assert np.abs(eb[0].predict(x) - keras_gru.predict(x, w)).max() <= TOL_BF16
+        for e in eb:
+            e.close()
     # drop-in Listener: model file + .params with use_delta
     saved = dict(P.pr.__dict__)
     try:
@@ -600,8 +622,10 @@ def test_use_delta_matches_reference_semantics(tmp_path):
 
 
 # ---- BASELINE configs[3]: wide / stacked GRU (streamed-weight kernel) ------------------------------------
-@pytest.mark.parametrize('units', [(256, 256), (64,), (128, 128), (192,), (256,)])
+@pytest.mark.parametrize('units', [(256, 256), (64,), (128, 128), (192,), (256,), (33,), (100,), (128, 64), (72, 200), (250, 250)])
 def test_wide_gru_predict_matches_oracle(units):
+    """Widths that are not multiples of 64 (and stacked layers of different widths) run zero-padded to the next
+    multiple: a padded unit's state stays exactly 0."""
     from mycroft_precise_amd._lib import HipEngine
     w = synth.make_weights(units=units, seed=500 + sum(units))
     eng = HipEngine(P.pr, w, n_streams=1)
@@ -611,6 +635,20 @@ def test_wide_gru_predict_matches_oracle(units):
         got, want = eng.predict(x), keras_gru.predict(x, w)
         assert got.shape == want.shape and np.abs(got - want).max() <= GUARD_RAW, (units, n)
     eng.close()
+
+
+def test_wide_gru_update_many_equals_consecutive_updates():
+    """pe_update_many with the streamed-weight network (one network launch per update of the call)."""
+    from mycroft_precise_amd._lib import HipEngine
+    w = synth.make_weights(units=(128, 100), seed=9)
+    n = 37
+    pcm = _stream_batch(['tone_noise'] * (n - 2) + ['zeros', 'square'], 24)
+    a, b = HipEngine(P.pr, w, n_streams=n), HipEngine(P.pr, w, n_streams=n)
+    b.reserve_updates(6, 1024)
+    for u in range(0, 24, 6):
+        want = np.stack([a.update(pcm[u + i]) for i in range(6)])
+        assert np.array_equal(b.update_many(pcm[u:u + 6]), want), u
+    a.close(); b.close()
 
 
 def test_wide_gru_streaming_and_offline_match_oracle():
@@ -641,9 +679,6 @@ def test_wide_gru_streaming_and_offline_match_oracle():
 
 
 # ---- BASELINE configs[4]: bf16 operands, tolerance 1e-2 -------------------------------------------------
-TOL_BF16 = 1e-2
-
-
 @pytest.mark.parametrize('mfcc', ['f32', 'f64'])
 def test_bf16_network_within_1e2_of_oracle(stock_weights, mfcc):
     """gru_precision='bf16': weights / features / hidden state rounded to bf16 as MFMA operands, float32
