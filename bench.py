@@ -14,9 +14,12 @@ probabilities of the timed region are gathered to rank 0 once at its end, inside
 The PCM of all W+K steps is resident in HBM before the timed region starts.
 
 Rank 0 prints ONE JSON line: metric/value (whole-job windows/s), ms_per_step, plus
-  "roofline"       GRU kernel vs the dense fp32 MFMA peak (HIP-event time on the launch stream),
-  "roofline_mfcc"  MFCC kernel vs the HBM peak,
-  "cpu_baseline"   the numpy oracle ("port") timed on this box's host cores (N=1 only).
+  "roofline"       the launch of the timed region (network || MFCC || bookkeeping roles in one kernel) vs the dense
+                   fp32 MFMA peak (HIP-event time on the launch stream); with --gru-precision bf16 (configs[4]) vs the
+                   HBM peak, which is what binds that configuration,
+  "roofline_gru" / "roofline_mfcc"   the two stages launched separately,
+  "cpu_baseline"   the numpy oracle ("port") timed on this box's host cores (N=1 only),
+  "cpu_baseline_single_stream"   one stream through Listener.update the way the reference runs.
 """
 import argparse
 import json
@@ -124,16 +127,16 @@ def _cpu_round(cores, streams_per_core, seconds):
             'value': windows / compute}
 
 
-def cpu_baseline(seconds=6.0):
+def cpu_baseline(seconds=5.0):
     """Oracle ("port" of the reference's sonopy + Keras arithmetic, vectorised over streams) on every host core,
     on a bounded sample of the same workload.  All workers start their timed loops together (barrier after fork /
     import / synthesis) and run for `seconds`; rate = windows of all workers / the longest worker's compute time.
-    Two batch shapes per core are timed -- 1024 streams (the GPU's own regime; on a many-core host its float64
-    temporaries fall out of cache and the cores queue on memory) and 128 streams (cache-resident) -- and the
-    FASTER one is reported as the baseline."""
+    Three batch shapes per core are timed -- 1024 streams (the GPU's own regime; on a many-core host its float64
+    temporaries fall out of cache and the cores queue on memory), 128 and 48 streams (cache-resident) -- and the
+    FASTEST one is reported as the baseline."""
     cores = _affinity_cores()
     n_alone, t_alone = _cpu_worker((0, 1024, 1.0, 8, 42, None))                 # one core, nothing else running
-    rounds = [_cpu_round(cores, spc, seconds) for spc in (1024, 128)]
+    rounds = [_cpu_round(cores, spc, seconds) for spc in (1024, 128, 48)]
     best = max(rounds, key=lambda r: r['value'])
     return {'value': best['value'], 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
             'compute_s': best['compute_s'], 'wall_s': sum(r['wall_s'] for r in rounds),
@@ -197,6 +200,8 @@ def main():
     ap.add_argument('--mfcc-precision', choices=['f64', 'f32'], default='f64')
     ap.add_argument('--gru-precision', choices=['f32', 'bf16'], default='f32',
                     help="bf16 = BASELINE configs[4] arithmetic (bf16 MFMA operands, tol 1e-2); not the headline")
+    ap.add_argument('--ring-precision', choices=['f32', 'bf16'], default='f32',
+                    help="bf16 = 32-byte bf16 feature rows (BASELINE configs[4]: bf16 MFCC+GRU); needs --gru-precision bf16")
     ap.add_argument('--units', default='20', help="GRU widths, e.g. 20 (stock, default) or 256,256 (BASELINE configs[3])")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--resident-updates', type=int, default=256,
@@ -237,7 +242,7 @@ def main():
     stock = units == (20,)
     flop_per_window = 2 * sum(29 * 3 * h * (f + h) for f, h in zip((13,) + units[:-1], units)) + 2 * units[-1]
     engine = HipEngine(pr, weights, n_streams=B, device=dev_index, mfcc_precision=args.mfcc_precision,
-                       gru_precision=args.gru_precision)
+                       gru_precision=args.gru_precision, ring_precision=args.ring_precision)
     first_stream = int(os.environ.get('PE_BENCH_FIRST_STREAM', '0')) + rank * B      # (test aid: shard offset of a solo run)
     pcm = synth_pcm_device(n_res, B, first_stream, device)
     probs = torch.zeros((steps, B), dtype=torch.float32, device=device)
@@ -365,12 +370,22 @@ def main():
         mfcc_name = 'double' if args.mfcc_precision == 'f64' else 'float'
         mfma_peak = MFMA_F32_PEAK_TFLOPS if args.gru_precision == 'f32' else MFMA_BF16_PEAK_TFLOPS
         four_waves = (B + 15) // 16 <= torch.cuda.get_device_properties(device).multi_processor_count   # engine.hip: gru_args
-        fused_name = (('fused_update_kernel<%%s,5,%s>' % ('true' if four_waves else 'false')) if args.gru_precision == 'f32'
-                      else 'fused_update_bf16_kernel<%s>') % mfcc_name
-        gru_name = ('gru_mw_kernel<5>' if four_waves else 'gru_small_kernel<5,1>') if args.gru_precision == 'f32' else 'gru_bf16_kernel<1>'
+        mfcc_kernel = 'mfcc_kernel<%s, ShapeStock>' % mfcc_name
+        fused_name = ('fused_update_kernel<%s, ShapeStock, 5, %s, false>' % (mfcc_name, 'true' if four_waves else 'false')
+                      if args.gru_precision == 'f32' else 'fused_update_bf16_kernel<%s, ShapeStock>' % mfcc_name)
+        gru_name = (('gru_mw_kernel<5, false>' if four_waves else 'gru_small_kernel<5, 1, false>') if args.gru_precision == 'f32'
+                    else 'gru_bf16_kernel<1>')
         if not stock:
-            fused_name = 'mfcc_frames_kernel<%s> + mfcc_book_kernel + gru_wide_kernel<%d,1>' % (mfcc_name, units[0] // 64)
-            gru_name = 'gru_wide_kernel<%d,1>' % (units[0] // 64)
+            fused_name = '%s + gru_wide_kernel<%d, 1, 4>' % (mfcc_kernel, (units[0] + 63) // 64)
+            gru_name = 'gru_wide_kernel<%d, 1, 4>' % ((units[0] + 63) // 64)
+        feat_bytes = 2 if args.ring_precision == 'bf16' else 4
+        bytes_per_window = 2048 + 1.28 * 13 * feat_bytes       # PCM read + feature rows written (2114.6 / 2081.3 B)
+
+        def gbs_w(ms):
+            return bytes_per_window * B / (ms * 1e-3) / 1e9
+        # BASELINE configs[4] (bf16 network): 21 G windows/s of MFMA headroom, so the HBM side of the MFCC stage is the
+        # roofline that binds; every other configuration is priced against the matrix cores
+        hbm_bound = args.gru_precision == 'bf16'
         line = {
             'metric': METRIC, 'value': value, 'unit': 'windows/s',
             'n_gpus': world, 'steps': steps, 'warmup': warmup,
@@ -382,34 +397,37 @@ def main():
                                    % ('stock' if stock else 'wide %s' % 'x'.join(map(str, units)), args.gru_precision, B),
                        'streams_per_gpu': B, 'global_streams': n_global, 'chunk_samples': CHUNK,
                        'gru': 'H=%s, T=29, F=13, ' % args.units + ('f32 MFMA 16x16x4' if args.gru_precision == 'f32' else 'bf16 MFMA 16x16x32, f32 accumulate'),
-                       'mfcc_dtype': args.mfcc_precision,
+                       'mfcc_dtype': args.mfcc_precision, 'feature_rows': args.ring_precision,
                        'parallelism': 'streams sharded over %d rank(s), final RCCL gather of probabilities to rank 0' % world},
             'realtime_streams': value / REALTIME_WINDOWS_PER_S,
             'outputs_finite': finite,
             # dominant kernel of the timed region: the fused launch (GRU role is its long pole)
-            'roofline': {'kernel': fused_name, 'bound': 'mfma',
-                         'achieved': tflops(fused_ms), 'peak': mfma_peak, 'unit': 'TFLOP/s',
-                         'frac': tflops(fused_ms) / mfma_peak,
-                         'traffic': pmc_traffic('fused_update_kernel') if (args.gru_precision == 'f32' and stock) else None, 'traffic_unit': 'bytes/launch (PMC, profiles/pmc_latest.json)',
-                         'avg_launch_ms': fused_ms,
-                         'algorithmic': '%d flop/window x %d windows/launch' % (flop_per_window, B)},
-            # the two roles launched separately (pe_set_fused(0)), for the per-stage picture
+            'roofline': ({'kernel': fused_name, 'bound': 'hbm', 'achieved': gbs_w(fused_ms), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                          'frac': gbs_w(fused_ms) / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': fused_ms,
+                          'algorithmic': '%.1f B/window x %d windows/launch' % (bytes_per_window, B)} if hbm_bound else
+                         {'kernel': fused_name, 'bound': 'mfma',
+                          'achieved': tflops(fused_ms), 'peak': mfma_peak, 'unit': 'TFLOP/s',
+                          'frac': tflops(fused_ms) / mfma_peak,
+                          'traffic': pmc_traffic('fused_update_kernel') if (args.gru_precision == 'f32' and stock) else None,
+                          'traffic_unit': 'bytes/launch (rocprofv3 PMC of this command, committed as profiles/pmc_latest.json; not measured in this run)',
+                          'avg_launch_ms': fused_ms,
+                          'algorithmic': '%d flop/window x %d windows/launch' % (flop_per_window, B)}),
             'roofline_gru': {'kernel': gru_name, 'bound': 'mfma', 'achieved': tflops(gru_ms),
                              'peak': mfma_peak, 'unit': 'TFLOP/s',
-                             'frac': tflops(gru_ms) / mfma_peak, 'traffic': pmc_traffic('gru_mw_kernel') if (args.gru_precision == 'f32' and stock) else None,
+                             'frac': tflops(gru_ms) / mfma_peak, 'traffic': pmc_traffic('gru_mw_kernel') if (args.gru_precision == 'f32' and stock and four_waves) else None,
                              'avg_launch_ms': gru_ms},
-            'roofline_mfcc': {'kernel': 'mfcc_frames_kernel<%s> + mfcc_book_kernel<%s>' % (mfcc_name, mfcc_name), 'bound': 'hbm',
-                              'achieved': gbs(mfcc_ms), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                              'frac': gbs(mfcc_ms) / HBM_PEAK_GBS, 'traffic': pmc_traffic('mfcc_frames_kernel'),
+            'roofline_mfcc': {'kernel': mfcc_kernel, 'bound': 'hbm',
+                              'achieved': gbs_w(mfcc_ms), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                              'frac': gbs_w(mfcc_ms) / HBM_PEAK_GBS, 'traffic': pmc_traffic('mfcc_kernel'),
                               'avg_launch_ms': mfcc_ms,
-                              'algorithmic': '%.1f B/window x %d windows/launch' % (MFCC_BYTES_PER_WINDOW, B)},
+                              'algorithmic': '%.1f B/window x %d windows/launch' % (bytes_per_window, B)},
         }
         try:     # spin / streaming microbenchmarks of the same pool ("also report against measured peaks")
             with open(os.path.join(REPO, 'profiles', 'measured_peaks.json')) as f:
                 mp = json.load(f)
             m_mfma = mp['mfma_f32_16x16x4_tflops'] if args.gru_precision == 'f32' else mp['mfma_bf16_16x16x32_tflops']
             line['measured_peaks'] = {'mfma_tflops': m_mfma, 'hbm_read_gbs': mp['hbm_read_gbs'], 'source': 'profiles/measured_peaks.json',
-                                      'roofline_frac': line['roofline']['achieved'] / m_mfma,
+                                      'roofline_frac': line['roofline']['achieved'] / (mp['hbm_read_gbs'] if hbm_bound else m_mfma),
                                       'roofline_gru_frac': line['roofline_gru']['achieved'] / m_mfma,
                                       'roofline_mfcc_frac': line['roofline_mfcc']['achieved'] / mp['hbm_read_gbs']}
         except (OSError, KeyError, ValueError):

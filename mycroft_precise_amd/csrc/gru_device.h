@@ -170,16 +170,29 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
         for (int tl = 0; tl < G::NT; ++tl) p[tl] = q[tl];
     };
     f32x4 x = {0.f, 0.f, 0.f, 0.f};
-    f32x4 pn[G::NT];
-    if (PROJ) load_p(0, pn); else x = load_x(0);
+    // projection rows are requested PD timesteps ahead: at a few thousand streams they come from the other XCDs' L2 /
+    // the Infinity Cache (the rows of one engine exceed one XCD's 4 MB), a microsecond away, and a single wave per SIMD
+    // has nothing else to hide that behind
+    constexpr int PD = 3;
+    f32x4 pq[PD][G::NT];
+    if (PROJ) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) load_p(d, pq[d]);
+    } else {
+        x = load_x(0);
+    }
     f32x4 xprev = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < T; ++t) {
         f32x4 xn = {0.f, 0.f, 0.f, 0.f};
         f32x4 acc[G::NT];
         if (PROJ) {
 #pragma unroll
-            for (int tl = 0; tl < G::NT; ++tl) acc[tl] = pn[tl];
-            load_p(t + 1, pn);                   // prefetch next timestep's projections
+            for (int tl = 0; tl < G::NT; ++tl) acc[tl] = pq[0][tl];
+#pragma unroll
+            for (int d = 0; d + 1 < PD; ++d)
+#pragma unroll
+                for (int tl = 0; tl < G::NT; ++tl) pq[d][tl] = pq[d + 1][tl];
+            load_p(t + PD, pq[PD - 1]);          // prefetch
         } else {
             xn = load_x(t + 1);                  // prefetch next timestep's features
             // input projection, bias as the initial accumulator
