@@ -32,6 +32,7 @@ __device__ __forceinline__ bf16x8 pack_bf16(const float (&v)[8]) {
 // MODE as in gru_device.h (kFeats / kRing / kRows).  Tiles: 0,1 = z, 2,3 = r, 4,5 = candidate.
 template <int MODE>
 __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, const int lane) {
+#pragma clang fp contract(off)      // every fusion in the gate arithmetic is spelled out: all kernel shapes round alike
     const int g = lane >> 4, j = lane & 15;
     const long long stream = (long long)tile * kTileStreams + j;
     const bool valid = stream < a.n_streams;
@@ -150,7 +151,7 @@ __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, 
 #pragma unroll
         for (int tl = 4; tl < 6; ++tl) acc[tl] = mfma_bf16(wr[tl], rhb, acc[tl]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) h[i] = z[i] * h[i] + (1.0f - z[i]) * acc[4 + (i >> 2)][i & 3];
+        for (int i = 0; i < 8; ++i) h[i] = gru_blend(z[i], h[i], acc[4 + (i >> 2)][i & 3]);
         x = xn;
     }
 

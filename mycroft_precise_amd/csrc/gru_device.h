@@ -30,11 +30,18 @@ namespace pe {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float hard_sigmoid(float v) {
-    // Keras/TF: clip(0.2 * x + 0.5, 0, 1).  hipcc contracts the multiply-add into one v_fma_f32
-    // with the clamp modifier (one rounding instead of TF's two: <= 1 ulp apart, inside the
-    // 1e-4 parity budget by three orders of magnitude).
-    const float y = 0.2f * v + 0.5f;
-    return __builtin_amdgcn_fmed3f(y, 0.0f, 1.0f);
+    // Keras/TF: clip(0.2 * x + 0.5, 0, 1), as ONE fused multiply-add with the clamp (one rounding where TF does two:
+    // <= 1 ulp apart, inside the 1e-4 parity budget by three orders of magnitude).  The fusion is spelled out: left to
+    // the compiler's contraction it came out fused in one kernel shape and as multiply + add in another, and the
+    // shapes then differed in the last bit.
+    return __builtin_amdgcn_fmed3f(__builtin_fmaf(0.2f, v, 0.5f), 0.0f, 1.0f);
+}
+
+// h' = z h + (1 - z) c with a fixed sequence of roundings (subtract, multiply, fused multiply-add), for the same reason
+__device__ __forceinline__ float gru_blend(float z, float h, float c) {
+#pragma clang fp contract(off)
+    const float t = (1.0f - z) * c;
+    return __builtin_fmaf(z, h, t);
 }
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
@@ -57,18 +64,22 @@ enum GruInput {
                     // [w*stride, w*stride + T)                               (simulate.py:92-104)
 };
 
-// Address of the input-projection row of (tile, stream j) for lane group g; slot `s` of the ring is
-// s * kTileStreams * kProjRow floats further.  Row layout [g][output tile][q]: a lane's 4 accumulators of tile tl are
-// one float4 at +4 tl.
+// Input projections of one (stream tile, ring slot): 4 KB laid out [output tile tl][stream j][lane group g][q], so
+// that the float4 a lane (g, j) needs for output tile tl sits at ((tl * 16 + j) * 4 + g) * 4 floats and ONE wave-wide
+// load of a tile's accumulators reads 1 KB contiguous (a row-per-stream layout made every lane touch its own 64-byte
+// segment: 340 cycles of address processing per timestep in the one-wave kernel).  Slot `s` of the ring is
+// s * kTileStreams * kProjRow floats further; output tile tl adds tl * kTileStreams * 16 floats.
 __device__ __forceinline__ const float* proj_base(const GruArgs& a, int tile, int j, int g) {
-    return a.proj_ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kProjRow + 16 * g;
+    return a.proj_ring + (size_t)tile * a.ring_slots * kTileStreams * kProjRow + (size_t)(j * 4 + g) * 4;
 }
+constexpr int kProjTileStride = kTileStreams * 16;       // floats between the accumulators of consecutive output tiles
 
 // One wave = one tile of 16 streams, whole window, weights resident in registers.
 // PROJ: every timestep starts from the input projection x.W + b that the MFCC stage stored beside the feature row
 // (a.proj_ring), instead of recomputing it with 4 MFMAs per output tile.
 template <int R, int MODE, bool PROJ = false>
 __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const int lane) {
+#pragma clang fp contract(off)      // every fusion in the gate arithmetic is spelled out: all kernel shapes round alike
     constexpr bool FROM_RING = MODE == kRing;
     static_assert(!PROJ || (MODE == kRing && GruShape<R>::NT <= 4), "projection rows hold 4 output tiles");
     using G = GruShape<R>;
@@ -167,7 +178,7 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
         const uint32_t slot = (first + (uint32_t)tc) & mask;
         const f32x4* q = reinterpret_cast<const f32x4*>(pbase + (size_t)slot * kTileStreams * kProjRow);
 #pragma unroll
-        for (int tl = 0; tl < G::NT; ++tl) p[tl] = q[tl];
+        for (int tl = 0; tl < G::NT; ++tl) p[tl] = q[tl * (kProjTileStride / 4)];
     };
     f32x4 x = {0.f, 0.f, 0.f, 0.f};
     // projection rows are requested PD timesteps ahead: at a few thousand streams they come from the other XCDs' L2 /
@@ -188,11 +199,14 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
         if (PROJ) {
 #pragma unroll
             for (int tl = 0; tl < G::NT; ++tl) acc[tl] = pq[0][tl];
+
 #pragma unroll
             for (int d = 0; d + 1 < PD; ++d)
 #pragma unroll
                 for (int tl = 0; tl < G::NT; ++tl) pq[d][tl] = pq[d + 1][tl];
+#ifndef PE_GRU_ABL_NOLOAD
             load_p(t + PD, pq[PD - 1]);          // prefetch
+#endif
         } else {
             xn = load_x(t + 1);                  // prefetch next timestep's features
             // input projection, bias as the initial accumulator
@@ -217,28 +231,39 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
         // tiles: this k-outer order 65.4 us; tile-outer runs of R dependent MFMAs 66-67 us; each chain split
         // into two independent halves added at the end 69.3 us, and 16.9 instead of 15.6 us for the 4-wave
         // kernel -- the extra adds and hazards cost more than the shorter dependent chain saves.)
+        // Issue order: the tiles that hold r rows first -- r is all the candidate phase waits for -- and the tiles that
+        // hold ONLY z rows (z is not needed before the state update) between the candidate MFMAs, where their
+        // five-deep dependent chain costs nothing and fills the matrix pipe while the VALU forms r * h.  Per accumulator
+        // the order of the MFMAs is unchanged, so every kernel shape still produces the same bits.
+        constexpr int ZT_END = R / 4;                  // tiles [0, ZT_END) hold z slots only
 #pragma unroll
         for (int rho = 0; rho < R; ++rho)
 #pragma unroll
-            for (int tl = 0; tl < G::P1_END; ++tl) acc[tl] = mfma(wr1[tl][rho], h[rho], acc[tl]);
+            for (int tl = ZT_END; tl < G::P1_END; ++tl) acc[tl] = mfma(wr1[tl][rho], h[rho], acc[tl]);
         float z[R], rh[R];
 #pragma unroll
         for (int rho = 0; rho < R; ++rho) {
-            const int sz = rho, sr = R + rho;
-            z[rho] = hard_sigmoid(acc[sz >> 2][sz & 3]);
+            const int sr = R + rho;
             const float r = hard_sigmoid(acc[sr >> 2][sr & 3]);
             rh[rho] = r * h[rho];
         }
-        // phase 2: + (r*h) . U for the candidate rows
+        // phase 2: + (r*h) . U for the candidate rows (+ the z-only tiles' share of phase 1)
 #pragma unroll
-        for (int rho = 0; rho < R; ++rho)
+        for (int rho = 0; rho < R; ++rho) {
+#ifndef PE_GRU_ABL_NOPHASE2
 #pragma unroll
             for (int tl = G::P2_BEGIN; tl < G::NT; ++tl) acc[tl] = mfma(wr2[tl - G::P2_BEGIN][rho], rh[rho], acc[tl]);
+#endif
+#pragma unroll
+            for (int tl = 0; tl < ZT_END; ++tl) acc[tl] = mfma(wr1[tl][rho], h[rho], acc[tl]);
+        }
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) z[rho] = hard_sigmoid(acc[rho >> 2][rho & 3]);
 #pragma unroll
         for (int rho = 0; rho < R; ++rho) {
             const int sh = 2 * R + rho;
             const float hh = acc[sh >> 2][sh & 3];
-            h[rho] = z[rho] * h[rho] + (1.0f - z[rho]) * hh;
+            h[rho] = gru_blend(z[rho], h[rho], hh);
         }
         x = xn;
     }
@@ -269,6 +294,7 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
 template <int R, bool PROJ = false>
 __device__ __forceinline__ void gru_tile_mw(const GruArgs& a, const int tile, const int wave, const int lane,
                                             float* S /* [3R][64] floats of LDS */) {
+#pragma clang fp contract(off)      // every fusion in the gate arithmetic is spelled out: all kernel shapes round alike
     using G = GruShape<R>;
     constexpr int MAXT = (G::NT + 3) / 4;
     static_assert(!PROJ || MAXT == 1, "projection rows hold 4 output tiles");
@@ -313,7 +339,7 @@ __device__ __forceinline__ void gru_tile_mw(const GruArgs& a, const int tile, co
     const uint32_t first = ke - (uint32_t)T;
     const uint32_t mask = (uint32_t)(a.ring_slots - 1);
     const float* xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats + 4 * g;
-    const float* pbase = PROJ ? proj_base(a, tile, j, g) + 4 * (wave < G::NT ? wave : 0) : nullptr;
+    const float* pbase = PROJ ? proj_base(a, tile, j, g) + kProjTileStride * (wave < G::NT ? wave : 0) : nullptr;
     auto load_x = [&](int t) -> f32x4 {
         const int tc = t < T ? t : T - 1;
         const uint32_t slot = (first + (uint32_t)tc) & mask;
@@ -380,7 +406,7 @@ __device__ __forceinline__ void gru_tile_mw(const GruArgs& a, const int tile, co
         xproj(x, acc);
         x = xn;
 #pragma unroll
-        for (int rho = 0; rho < R; ++rho) h[rho] = z[rho] * h[rho] + (1.0f - z[rho]) * hh[rho];
+        for (int rho = 0; rho < R; ++rho) h[rho] = gru_blend(z[rho], h[rho], hh[rho]);
     }
 
     if (wave == 0) {
@@ -402,6 +428,7 @@ __device__ __forceinline__ void gru_tile_mw(const GruArgs& a, const int tile, co
 template <bool PROJ>
 __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, const int wave, const int lane,
                                              float* S /* [15][64] gate slots + [64][4] tile-2 projection */) {
+#pragma clang fp contract(off)      // every fusion in the gate arithmetic is spelled out: all kernel shapes round alike
     constexpr int R = 5;
     float* X2 = S + 3 * R * 64;
     const int g = lane >> 4, j = lane & 15;
@@ -442,7 +469,7 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
     const uint32_t mask = (uint32_t)(a.ring_slots - 1);
     // what a wave fetches per timestep: the feature row (4 features per lane) -- or, PROJ, the input projection of
     // ITS OWN output tile as the MFCC stage stored it (then no wave computes projections and nothing is handed over)
-    const float* xbase = PROJ ? proj_base(a, tile, j, g) + 4 * wave
+    const float* xbase = PROJ ? proj_base(a, tile, j, g) + kProjTileStride * wave
                               : a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats + 4 * g;
     const size_t xstride = (size_t)kTileStreams * (PROJ ? kProjRow : kRowFloats);
     auto load_x = [&](int t) -> f32x4 {
@@ -522,7 +549,7 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
 #pragma unroll
         for (int rho = 0; rho < R; ++rho) hh[rho] = Sl[(2 * R + rho) * 64];
 #pragma unroll
-        for (int rho = 0; rho < R; ++rho) h[rho] = z[rho] * h[rho] + (1.0f - z[rho]) * hh[rho];
+        for (int rho = 0; rho < R; ++rho) h[rho] = gru_blend(z[rho], h[rho], hh[rho]);
     }
 
     if (wave == 0) {

@@ -92,6 +92,7 @@ __device__ __forceinline__ void dpp_source_units(const int unit_a, const int uni
 // One workgroup (256 threads) = one tile of 16 streams; wave w serves streams 4w .. 4w+3 of the tile.
 // a.rk: the Keras recurrent kernel [H][3H] as uploaded (gate order z | r | h); a.wd_plain: dense kernel [H].
 __device__ __forceinline__ void gru_tile_dpp(const GruArgs& a, const int tile, const int wave, const int lane) {
+#pragma clang fp contract(off)      // every fusion in the gate arithmetic is spelled out: all kernel shapes round alike
     const int H = a.units, T = a.n_features;
     const int row = lane >> 4, i = lane & 15;
     const int j = 4 * wave + row;                              // stream within the tile
@@ -136,17 +137,22 @@ __device__ __forceinline__ void gru_tile_dpp(const GruArgs& a, const int tile, c
     }
     const uint32_t first = ke - (uint32_t)T;
     const uint32_t mask = (uint32_t)(a.ring_slots - 1);
-    // projection row of (tile, stream): element 16 g + slot, slot = gate * 5 + rho, unit = 4 rho + g
+    // projection of (gate, unit): slot = gate * 5 + rho, unit = 4 rho + g, output tile slot / 4, accumulator slot % 4;
+    // the (tile, slot-of-the-ring) block is laid out [output tile][stream][g][q] (gru_device.h: proj_base)
     const int tile_c = valid ? tile : 0, j_c = valid ? j : 0;
-    const float* prow = a.proj_ring + ((size_t)tile_c * a.ring_slots * kTileStreams + j_c) * kProjRow;
-    const int eA = 16 * (uA & 3) + (uA >> 2), eB = 16 * (uB & 3) + (uB >> 2);
+    const float* prow = a.proj_ring + (size_t)tile_c * a.ring_slots * kTileStreams * kProjRow;
+    auto elem = [&](int gate, int u) -> int {
+        const int slot = gate * 5 + (u >> 2), g = u & 3;
+        return (slot >> 2) * kProjTileStride + (j_c * 4 + g) * 4 + (slot & 3);
+    };
+    const int ezA = elem(0, uA), erA = elem(1, uA), ecA = elem(2, uA), ezB = elem(0, uB), erB = elem(1, uB), ecB = elem(2, uB);
     struct Proj { float zA, rA, cA, zB, rB, cB; };
     auto load_p = [&](int t) -> Proj {
         const int tc = t < T ? t : T - 1;
         const float* p = prow + (size_t)((first + (uint32_t)tc) & mask) * kTileStreams * kProjRow;
         Proj r;
-        r.zA = p[eA]; r.rA = p[eA + 5]; r.cA = p[eA + 10];
-        r.zB = p[eB]; r.rB = p[eB + 5]; r.cB = p[eB + 10];
+        r.zA = p[ezA]; r.rA = p[erA]; r.cA = p[ecA];
+        r.zB = p[ezB]; r.rB = p[erB]; r.cB = p[ecB];
         return r;
     };
 
@@ -160,8 +166,8 @@ __device__ __forceinline__ void gru_tile_dpp(const GruArgs& a, const int tile, c
         const float rhA = hard_sigmoid(rA) * hA, rhB = hard_sigmoid(rB) * hB;
         float cA = p0.cA, cB = p0.cB;
         dpp_matvec2(rhA, rhB, wcA, wcB, cA, cB);
-        hA = zA * hA + (1.0f - zA) * cA;
-        hB = hasB ? zB * hB + (1.0f - zB) * cB : 0.f;
+        hA = gru_blend(zA, hA, cA);
+        hB = hasB ? gru_blend(zB, hB, cB) : 0.f;
         p0 = p1; p1 = p2; p2 = p3; p3 = p4;
     }
 

@@ -86,6 +86,7 @@ __device__ __forceinline__ void wide_accumulate_x(f32x4 (&acc)[NT], const float4
 // MODE as in gru_device.h (kFeats / kRing / kRows).  LDS: [layer][HB | RH][H/16][64 lanes][4] floats.
 template <int TPW, int MODE, int WAVES>
 __device__ __forceinline__ void gru_wide_tile(const WideArgs& wa, const int tile, const int wave, const int lane, float* lds) {
+#pragma clang fp contract(off)      // every fusion in the gate arithmetic is spelled out: all kernel shapes round alike
     const GruArgs& a = wa.base;
     constexpr int H = 16 * TPW * WAVES, H16 = H / 16;
     const int g = lane >> 4, j = lane & 15;
@@ -186,7 +187,7 @@ __device__ __forceinline__ void gru_wide_tile(const WideArgs& wa, const int tile
             for (int tp = 0; tp < TPW; ++tp) {
                 float4 hn;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) hown[l][tp][q] = z[tp][q] * hown[l][tp][q] + (1.0f - z[tp][q]) * acc2[tp][q];
+                for (int q = 0; q < 4; ++q) hown[l][tp][q] = gru_blend(z[tp][q], hown[l][tp][q], acc2[tp][q]);
                 hn.x = hown[l][tp][0]; hn.y = hown[l][tp][1]; hn.z = hown[l][tp][2]; hn.w = hown[l][tp][3];
                 *reinterpret_cast<float4*>(HB[l] + ((wave * TPW + tp) * 64 + lane) * 4) = hn;
             }

@@ -458,7 +458,8 @@ __global__ void clear_kernel(const ClearArgs a) {
     if (a.proj_ring)            // the projection of an all-zero frame is the bias row
         for (int i = threadIdx.x; i < a.ring_slots * kProjRow; i += blockDim.x) {
             const int slot = i / kProjRow, o = i % kProjRow;
-            a.proj_ring[(((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kProjRow + o] = a.proj_b[o];
+            // element o = 16 g + 4 tl + q of stream j sits at [tl][j][g][q] inside the (tile, slot) block
+            a.proj_ring[((size_t)tile * a.ring_slots + slot) * kTileStreams * kProjRow + (size_t)((o >> 2) & 3) * (kTileStreams * 16) + j * 16 + (o >> 4) * 4 + (o & 3)] = a.proj_b[o];
         }
 }
 
@@ -468,7 +469,9 @@ __global__ void project_rows_kernel(const float* ring, float* proj, const float*
     if (row >= n_rows) return;
     float acc = b[o];
     for (int c = 0; c < n_mfcc; ++c) acc = fmaf(ring[row * kRowFloats + c], w[c * kProjRow + o], acc);
-    proj[row * kProjRow + o] = acc;
+    const long long block = row / kTileStreams;          // (tile, slot) block; row % 16 = stream j
+    const int j = (int)(row % kTileStreams);
+    proj[block * kTileStreams * kProjRow + (size_t)((o >> 2) & 3) * (kTileStreams * 16) + j * 16 + (o >> 4) * 4 + (o & 3)] = acc;
 }
 
 hipError_t launch_project_rows(const float* ring, float* proj, const float* w, const float* b, int n_mfcc, long long n_rows, hipStream_t s) {

@@ -390,7 +390,8 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
             const size_t cell = ((size_t)tile * slots + slot) * kTileStreams + j;
             f.ring_row = a.ring_bf16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(a.ring) + cell * kRowFloats)
                                      : a.ring + cell * kRowFloats;
-            f.proj_row = a.proj_ring ? a.proj_ring + cell * kProjRow : nullptr;
+            // projection rows: [tile][slot] blocks of 4 KB laid out [output tile][stream][g][q] (gru_device.h: proj_base)
+            f.proj_row = a.proj_ring ? a.proj_ring + ((size_t)tile * slots + slot) * kTileStreams * kProjRow + (size_t)j * 16 : nullptr;
             return true;
         }
         return false;
@@ -452,7 +453,7 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
                 group_sync();
                 float acc = tab.proj_b[lane];
                 for (int cc = 0; cc < tab.proj_rows; ++cc) acc = fmaf(XF[cc], tab.proj_w[cc * kProjRow + lane], acc);
-                prow_cur[lane] = acc;
+                prow_cur[(size_t)((lane >> 2) & 3) * (kTileStreams * 16) + (lane >> 4) * 4 + (lane & 3)] = acc;   // o = 16 g + 4 tl + q
                 group_sync();
             }
         }
