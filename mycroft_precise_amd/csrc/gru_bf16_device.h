@@ -30,7 +30,9 @@ __device__ __forceinline__ bf16x8 pack_bf16(const float (&v)[8]) {
 }
 
 // MODE as in gru_device.h (kFeats / kRing / kRows).  Tiles: 0,1 = z, 2,3 = r, 4,5 = candidate.
-template <int MODE>
+// DELTA (use_delta) is a compile-time switch: the first differences consume a loaded row as soon as it is loaded, which
+// would put a wait for the row prefetch in front of every timestep's MFMAs of the plain network as well.
+template <int MODE, bool DELTA = false>
 __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, const int lane) {
 #pragma clang fp contract(off)      // every fusion in the gate arithmetic is spelled out: all kernel shapes round alike
     const int g = lane >> 4, j = lane & 15;
@@ -81,49 +83,58 @@ __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, 
     // use_delta (vectorization.py:53-59): K = 32 holds the 13 features in k = 0..15 AND their first differences in
     // k = 16..31, so the same single MFMA per output tile covers the doubled input; lane groups 2, 3 form x_t - x_(t-1)
     // from the rows they fetch (zero at the first timestep); an explicit batch carries its delta columns
-    const bool delta = a.use_delta != 0;
+    constexpr bool delta = DELTA;
     const int frow = delta ? 2 * a.n_in : a.n_in;
-    // lane group g supplies k = 8 g .. 8 g + 7: features 8 (g & 1) .. + 7 (groups 0, 1), zeros or deltas (groups 2, 3)
+    // lane group g supplies k = 8 g .. 8 g + 7: features 8 (g & 1) .. + 7 (groups 0, 1), zeros or deltas (groups 2, 3).
+    // A row is REQUESTED one timestep ahead and only turned into an operand (converted, differenced) at the top of the
+    // step that uses it: anything that touches a loaded value earlier puts the L2 round trip into every timestep.
+    struct XRaw { float v[8]; uint4 u; };
+    const int fg = 8 * (g & 1);                                // first feature of this lane group's slice
+    const bool wants = g < 2 || delta;
+    auto request_x = [&](int t) -> XRaw {
+        XRaw r;
+        r.u = uint4{0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.v[i] = 0.f;
+        const int tc = t < T ? t : T - 1;
+        if (MODE == kRing && a.ring_bf16) {
+            // bf16 rows: the 16 bytes a lane group needs ARE its MFMA operand
+            const __bf16* p = reinterpret_cast<const __bf16*>(xbase) + (size_t)((first + (uint32_t)tc) & mask) * kTileStreams * kRowFloats + fg;
+            if (wants) r.u = *reinterpret_cast<const uint4*>(p);
+        } else if (MODE == kFeats) {
+            const float* p = xbase + (size_t)tc * frow + (g >= 2 ? a.n_in : 0);      // groups 2, 3: the batch's delta columns
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (valid && wants && fg + i < a.n_in) r.v[i] = p[fg + i];
+        } else if (wants) {
+            const float* p = (MODE == kRing)
+                ? xbase + (size_t)((first + (uint32_t)tc) & mask) * kTileStreams * kRowFloats + fg
+                : xbase + (size_t)tc * kRowFloats + fg;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { r.v[i] = lo[i]; r.v[4 + i] = hi[i]; }
+        }
+        return r;
+    };
     float vprev[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) vprev[i] = 0.f;
-    auto load_x = [&](int t) -> bf16x8 {
-        if (MODE == kRing && a.ring_bf16 && !delta) {
-            // bf16 rows: the 16 bytes a lane group needs ARE its MFMA operand (groups 2, 3 supply zeros)
-            const int tc = t < T ? t : T - 1;
-            const __bf16* p = reinterpret_cast<const __bf16*>(xbase) + (size_t)((first + (uint32_t)tc) & mask) * kTileStreams * kRowFloats + 8 * (g & 1);
-            const uint4 u = *reinterpret_cast<const uint4*>(p);
-            return g < 2 ? __builtin_bit_cast(bf16x8, u) : __builtin_bit_cast(bf16x8, uint4{0, 0, 0, 0});
-        }
+    auto make_x = [&](const XRaw& r, int t) -> bf16x8 {
+        const bool from_bf16 = MODE == kRing && a.ring_bf16;
+        if (from_bf16 && !delta) return __builtin_bit_cast(bf16x8, r.u);             // (zeros for groups 2, 3)
+        if (MODE == kFeats) return pack_bf16(r.v);                                    // (an explicit batch carries its delta columns)
         float v[8];
+        if (from_bf16) {
+            const bf16x8 b = __builtin_bit_cast(bf16x8, r.u);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = 0.f;
-        const int tc = t < T ? t : T - 1;
-        const int fg = 8 * (g & 1);                            // first feature of this lane group's slice
-        if (MODE == kFeats) {
-            const float* p = xbase + (size_t)tc * frow + (g >= 2 ? a.n_in : 0);      // groups 2, 3: the batch's delta columns
+            for (int i = 0; i < 8; ++i) v[i] = (float)b[i];
+        } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) if (valid && (g < 2 || delta) && fg + i < a.n_in) v[i] = p[fg + i];
-            return pack_bf16(v);
+            for (int i = 0; i < 8; ++i) v[i] = r.v[i];
         }
-        if (g < 2 || delta) {
-            if (MODE == kRing && a.ring_bf16) {
-                const __bf16* p = reinterpret_cast<const __bf16*>(xbase) + (size_t)((first + (uint32_t)tc) & mask) * kTileStreams * kRowFloats + fg;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = (float)p[i];
-            } else {
-                const float* p = (MODE == kRing)
-                    ? xbase + (size_t)((first + (uint32_t)tc) & mask) * kTileStreams * kRowFloats + fg
-                    : xbase + (size_t)tc * kRowFloats + fg;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { v[i] = lo[i]; v[4 + i] = hi[i]; }
-            }
-        }
-        if (g >= 2) {                                          // (delta only: otherwise v is zero)
+        if (delta && g >= 2) {
             float d[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { d[i] = (t > 0 && t < T) ? v[i] - vprev[i] : 0.f; vprev[i] = v[i]; }
+            for (int i = 0; i < 8; ++i) { d[i] = t > 0 ? v[i] - vprev[i] : 0.f; vprev[i] = v[i]; }
             return pack_bf16(d);
         }
         return pack_bf16(v);
@@ -132,9 +143,10 @@ __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, 
     float h[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) h[i] = 0.f;
-    bf16x8 x = load_x(0);
+    XRaw raw = request_x(0);
     for (int t = 0; t < T; ++t) {
-        const bf16x8 xn = load_x(t + 1);
+        const bf16x8 x = make_x(raw, t);
+        raw = request_x(t + 1);
         f32x4 acc[6];
 #pragma unroll
         for (int tl = 0; tl < 6; ++tl) acc[tl] = mfma_bf16(wx[tl], x, bias[tl]);
@@ -152,7 +164,6 @@ __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, 
         for (int tl = 4; tl < 6; ++tl) acc[tl] = mfma_bf16(wr[tl], rhb, acc[tl]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) h[i] = gru_blend(z[i], h[i], acc[4 + (i >> 2)][i & 3]);
-        x = xn;
     }
 
     float part = 0.f;

@@ -48,13 +48,14 @@ __global__ __launch_bounds__(256) void gru_many_mw_kernel(const GruArgs a, const
     gru_tile_mw_any<R, PROJ>(b, tile, wave, threadIdx.x & 63, S);
 }
 
+template <bool DELTA>
 __global__ __launch_bounds__(64) void gru_many_bf16_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
     const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
     GruArgs b = a;
     b.st_ke = a.st_ke + (size_t)u * n_padded;
     b.out = a.out + (size_t)u * a.n_streams;
     b.predict_ke = 0;
-    gru_tile_bf16<kRing>(b, tile, threadIdx.x);
+    gru_tile_bf16<kRing, DELTA>(b, tile, threadIdx.x);
 }
 
 template <class R, class SH>
@@ -109,9 +110,9 @@ hipError_t launch_gru_wide(const WideArgs& a, int mode, hipStream_t s) {
 }
 
 // ---- GRU, bf16 operands: one wave per 16-stream tile --------------------------------------------------
-template <int MODE>
+template <int MODE, bool DELTA>
 __global__ __launch_bounds__(64) void gru_bf16_kernel(const GruArgs a) {
-    gru_tile_bf16<MODE>(a, blockIdx.x, threadIdx.x);
+    gru_tile_bf16<MODE, DELTA>(a, blockIdx.x, threadIdx.x);
 }
 
 // Dispatch order of the roles of a fused launch.  Workgroups are handed to the CUs in blockIdx order; `frames_first`
@@ -125,14 +126,14 @@ __device__ __forceinline__ int role_block(const int b, const int n_gru, const in
 }
 
 // fused update with the bf16 network role (four tiles per GRU workgroup, one wave each)
-template <class R, class SH>
+template <class R, class SH, bool DELTA>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_bf16_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
                                                                 const int n_gru_blocks, const int n_frame_blocks, const int n_tiles, const int frames_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = role_block(blockIdx.x, n_gru_blocks, n_frame_blocks, frames_first);
     if (b < n_gru_blocks) {
         const int tile = b * 4 + (threadIdx.x >> 6);
-        if (tile < n_tiles) gru_tile_bf16<kRing>(g, tile, threadIdx.x & 63);
+        if (tile < n_tiles) gru_tile_bf16<kRing, DELTA>(g, tile, threadIdx.x & 63);
     } else if (b < n_gru_blocks + n_frame_blocks) {
         mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
     } else {
@@ -221,14 +222,22 @@ static int frame_blocks(long long n_tasks, int n_cus, int per_cu_default = 4) {
     return (int)(need < cap ? (need < 1 ? 1 : need) : cap);
 }
 
+// frame workgroups of a streaming launch: every wave owns a contiguous run of streams (mfcc_frame_tasks), as many waves
+// as the resident cap allows, the runs as even as they can be
+static int stream_frame_blocks(int n_streams, int n_cus, int per_cu_default = 4) {
+    const int cap_waves = frame_blocks((long long)n_streams, n_cus, per_cu_default) * kFrameWaves;
+    const int per_wave = (n_streams + cap_waves - 1) / cap_waves;
+    const int waves = (n_streams + per_wave - 1) / per_wave;
+    return (waves + kFrameWaves - 1) / kFrameWaves;
+}
+
 template <class R>
 static size_t frame_lds(const WaveTables<R>& t) { return wave_lds_bytes(sizeof(R), t.L, kFrameWaves); }
 
 template <class R>
 static hipError_t launch_mfcc(const MfccStreamArgs<R>& a, const WaveTables<R>& t, int n_cus, hipStream_t s) {
     const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
-    const long long n_tasks = (long long)tiles * kTileStreams * a.n_frame_rows;
-    const int fb = frame_blocks(n_tasks, n_cus);
+    const int fb = stream_frame_blocks(a.geo.n_streams, n_cus);
     if (t.L.mel_pad == ShapeStock::MEL) hipLaunchKernelGGL((mfcc_kernel<R, ShapeStock>), dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
     else hipLaunchKernelGGL((mfcc_kernel<R, ShapeAny>), dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
     return hipGetLastError();
@@ -275,9 +284,15 @@ hipError_t launch_gru_small(const GruArgs& a, int from_ring, hipStream_t s) {
     if (a.bf16) {
         const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
         if (tiles == 0) return hipSuccess;
-        if (from_ring == kRing) hipLaunchKernelGGL((gru_bf16_kernel<kRing>), dim3(tiles), dim3(64), 0, s, a);
-        else if (from_ring == kRows) hipLaunchKernelGGL((gru_bf16_kernel<kRows>), dim3(tiles), dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((gru_bf16_kernel<kFeats>), dim3(tiles), dim3(64), 0, s, a);
+        if (a.use_delta) {
+            if (from_ring == kRing) hipLaunchKernelGGL((gru_bf16_kernel<kRing, true>), dim3(tiles), dim3(64), 0, s, a);
+            else if (from_ring == kRows) hipLaunchKernelGGL((gru_bf16_kernel<kRows, true>), dim3(tiles), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((gru_bf16_kernel<kFeats, true>), dim3(tiles), dim3(64), 0, s, a);
+        } else {
+            if (from_ring == kRing) hipLaunchKernelGGL((gru_bf16_kernel<kRing, false>), dim3(tiles), dim3(64), 0, s, a);
+            else if (from_ring == kRows) hipLaunchKernelGGL((gru_bf16_kernel<kRows, false>), dim3(tiles), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((gru_bf16_kernel<kFeats, false>), dim3(tiles), dim3(64), 0, s, a);
+        }
         return hipGetLastError();
     }
     switch (gru_small_regs(a.units)) {
@@ -319,7 +334,8 @@ hipError_t launch_gru_many(const GruArgs& a, int n_updates, int n_padded, hipStr
     const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
     if (tiles == 0 || n_updates == 0) return hipSuccess;
     if (a.bf16) {
-        hipLaunchKernelGGL(gru_many_bf16_kernel, dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
+        if (a.use_delta) hipLaunchKernelGGL(gru_many_bf16_kernel<true>, dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
+        else hipLaunchKernelGGL(gru_many_bf16_kernel<false>, dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
         return hipGetLastError();
     }
     switch (gru_small_regs(a.units)) {
@@ -345,7 +361,7 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
     // FP64 multiply-adds and the MFMAs do not overlap on a SIMD)
     static const int ff_env = env_int("PE_FUSED_FRAMES_FIRST", -1);
     const int frames_first = ff_env >= 0 ? ff_env : (g.waves_per_tile != 4 && tiles >= 4 * n_cus);
-    const int fb = frame_blocks((long long)tiles * kTileStreams * m.n_frame_rows, n_cus, frames_first ? 3 : 4);
+    const int fb = stream_frame_blocks(m.geo.n_streams, n_cus, frames_first ? 3 : 4);
     int gru_blocks = g.waves_per_tile == 4 ? tiles : (tiles + 3) / 4;
     static const int skip = env_int("PE_FUSED_SKIP", 0);       // tuning aid: 1 = launch without the MFCC roles, 2 = without the network role
     if (skip == 1) { hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false>), dim3(gru_blocks), dim3(256), lds, s, m, t, g, gru_blocks, 0, 0, 0); return hipGetLastError(); }
@@ -376,8 +392,9 @@ static hipError_t launch_fused(const MfccStreamArgs<R>& m, const WaveTables<R>& 
         const int gru_blocks = (tiles + 3) / 4;
         static const int ff_env = env_int("PE_FUSED_FRAMES_FIRST", -1);
         const int frames_first = ff_env >= 0 ? ff_env : (tiles >= 4 * n_cus);
-        const int fb = frame_blocks((long long)tiles * kTileStreams * m.n_frame_rows, n_cus, frames_first ? 3 : 4);
-        hipLaunchKernelGGL((fused_update_bf16_kernel<R, ShapeStock>), dim3(gru_blocks + fb + tiles), dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles, frames_first);
+        const int fb = stream_frame_blocks(m.geo.n_streams, n_cus, frames_first ? 3 : 4);
+        if (g.use_delta) hipLaunchKernelGGL((fused_update_bf16_kernel<R, ShapeStock, true>), dim3(gru_blocks + fb + tiles), dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles, frames_first);
+        else hipLaunchKernelGGL((fused_update_bf16_kernel<R, ShapeStock, false>), dim3(gru_blocks + fb + tiles), dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles, frames_first);
         return hipGetLastError();
     }
     switch (gru_small_regs(g.units)) {

@@ -26,9 +26,10 @@
 namespace pe {
 
 #ifndef PE_TW_LDS
-#define PE_TW_LDS 1             // 1: the W64 / W16 twiddles (16 / 4 distinct values) are read from LDS per frame instead of
+#define PE_TW_LDS 2             // 1: the W64 / W16 twiddles (16 / 4 distinct values) are read from LDS per frame instead of
 #endif                          //    living in 24 registers (measured: 109 vs 126 us per update at 65536 streams -- the registers
-                                //    buy a fourth wave per SIMD)
+                                //    buy a fourth wave per SIMD); 2: so are the per-lane W256 / W512 ones (20 more registers
+                                //    in float64: what keeps the frame loop free of scratch spills under the 128-register cap)
 #ifndef PE_XCHG_B_LDS
 #define PE_XCHG_B_LDS 0         // 1: digit b also goes through LDS (debug / cross-check of the permlane path)
 #endif
@@ -45,14 +46,14 @@ constexpr int kWaveScratchReals = pe_wave::kScratchReals;
 
 // The LDS image of a workgroup: the blob from the logarithm table on (mel / DCT weights, run starts, ...); the twiddle
 // sections before it are read once per wave straight from global memory into registers (LaneConsts).
-__host__ __device__ inline int wave_lds_skip(const pe_wave::Layout& L) { return PE_TW_LDS ? L.tw2 : L.logtab; }
+__host__ __device__ inline int wave_lds_skip(const pe_wave::Layout& L) { return PE_TW_LDS == 2 ? L.tw1 : PE_TW_LDS ? L.tw2 : L.logtab; }
 __host__ __device__ inline size_t wave_lds_bytes(int real_size, const pe_wave::Layout& L, int waves) {
     return (size_t)(L.total - wave_lds_skip(L)) + (size_t)waves * kWaveScratchReals * real_size;
 }
 
 // workgroup-wide copy of the table image into LDS in two steps, so that the global loads can be issued at the very
 // top of a kernel and the LDS stores + barrier placed where the tables are first needed
-constexpr int kTabRegs = 2;                 // 16-byte pieces per thread held in flight (256 threads: 8 KB)
+constexpr int kTabRegs = PE_TW_LDS == 2 ? 5 : 2;    // 16-byte pieces per thread held in flight (256 threads: 20 / 8 KB)
 struct TabRegs { uint4 v[kTabRegs]; };
 
 template <class R>
@@ -162,6 +163,14 @@ template <class R> __device__ __forceinline__ R wave_sum(R x) {
     return a + b;
 }
 
+// buffer descriptor over `bytes` bytes at p; every input is forced into SGPRs (wave-uniform by construction)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_rsrc(const void* p, int bytes) {
+    const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 // One frame on one wave.  pcm[a] = the int16 pair (samples 2n, 2n+1 in the low / high half) of point n = lane + 64 a,
 // already zero beyond the frame length -- or, FROM_REAL, re[]/im[] hold the samples as reals (offline form).
 // Returns coefficient c in the four lanes 4c..4c+3 (c < n_mfcc).  S: this wave's scratch; after the call
@@ -170,14 +179,32 @@ template <class R> __device__ __forceinline__ R wave_sum(R x) {
 struct ShapeStock { static constexpr int MEL = 10, DCT = 5, NP = 8; };      // 20 filters (sonopy 9 / 5 / 8, speechpy 4 / 5 / 7)
 struct ShapeAny { static constexpr int MEL = 16, DCT = 16, NP = 16; };
 
+// table entries a lane needs in every frame, read once per wave (the compiler cannot keep an LDS read across the
+// scratch writes of a frame on its own): each saves a dependent LDS round trip per frame
+struct LaneRuns { int mel_start, p0, np, partner; };
+template <class R>
+__device__ __forceinline__ LaneRuns lane_runs(const pe_wave::Tab<R>& t, int lane, int n_filt) {
+    LaneRuns r;
+    r.mel_start = t.mel_start[lane];
+    const int f = lane < n_filt ? lane : 0;
+    r.p0 = t.pstart[f];
+    r.np = t.pstart[f + 1] - r.p0;
+    r.partner = t.partner[lane];
+    return r;
+}
+
 template <class R, class SH>
-__device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, const pe_wave::LaneConsts<R>& lc, R* S, const int lane,
+__device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, const pe_wave::LaneConsts<R>& lc, const LaneRuns& lr, R* S, const int lane,
                                              const int n_filt, const int n_mfcc, pe_wave::Regs<R>& v, const R pscale, const int log_mode) {
     using K = RealK<R>;
     using namespace pe_wave;
     cx<R>* X = reinterpret_cast<cx<R>*>(S);
     PE_T(3);
+#if PE_TW_LDS == 2
+    { radix4(v); twiddle3(v, t.tw1[lane], t.tw1[64 + lane], t.tw1[128 + lane]); }
+#else
     pass_a(v, lc);
+#endif
 #if PE_XCHG_B_LDS
     exchange_lds(v, X, lane, 4);
 #else
@@ -199,9 +226,13 @@ __device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, const pe_
     X[xchg_index(lane, 0)] = cx<R>{v.re[2], v.im[2]};
     X[xchg_index(lane, 1)] = cx<R>{v.re[3], v.im[3]};
     group_sync();
-    const int pl = lc.partner;
+    const int pl = lr.partner;
     cx<R> zq0 = X[xchg_index(pl, 1)], zq1 = X[xchg_index(pl, 0)];
+#if PE_TW_LDS == 2
+    const cx<R> w0 = t.w512[lane], w1 = t.w512[64 + lane];
+#else
     const cx<R> w0 = lc.w512[0], w1 = lc.w512[1];
+#endif
     group_sync();
     const bool lane0 = kbase_of(lane) == 0;
     if (lane0) { zq0 = cx<R>{v.re[0], v.im[0]}; zq1 = cx<R>{v.re[3], v.im[3]}; }
@@ -225,7 +256,7 @@ __device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, const pe_
     PE_T(6);
     // mel filterbank: this lane's run of one filter (all table reads first, then the FMA chain)
     {
-        const int s = t.mel_start[lane];
+        const int s = lr.mel_start;
         constexpr int HALF = (SH::MEL + 1) / 2;        // two batches of reads: half the registers in flight
         R acc = R(0);
 #pragma unroll
@@ -253,10 +284,10 @@ __device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, const pe_
         const bool takes_total = lane == 63 && n_filt < 64;
         R x = R(1);
         if (has_filter) {
-            const int p0 = t.pstart[lane], np = t.pstart[lane + 1] - p0;
+            const int p0 = lr.p0, np = lr.np;
             R pv[SH::NP];
 #pragma unroll
-            for (int i = 0; i < SH::NP; ++i) pv[i] = PART[p0 + i < 64 ? p0 + i : 63];
+            for (int i = 0; i < SH::NP; ++i) pv[i] = PART[p0 + i];         // (past the last run: log-mel slots, not added)
             x = R(0);
 #pragma unroll
             for (int i = 0; i < SH::NP; ++i) x += i < np ? pv[i] : R(0);
@@ -280,16 +311,15 @@ __device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, const pe_
         R lv[SH::DCT], dv[SH::DCT];
 #pragma unroll
         for (int i = 0; i < SH::DCT; ++i) {
-            const int n = t.dct_len * q + i;
-            lv[i] = LM[n < n_filt ? n : n_filt - 1];
+            lv[i] = LM[t.dct_len * q + i];           // (terms past n_filt: finite leftovers of the scratch times a zero weight)
             dv[i] = t.dct_w[i * 64 + lane];
         }
 #pragma unroll
         for (int i = 0; i < SH::DCT; ++i) part = real_fma(dv[i], lv[i], part);
     }
     const R c0 = LM[n_filt];
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
+    part += dpp_mov<0xB1>(part);            // quad_perm:[1,0,3,2]
+    part += dpp_mov<0x4E>(part);            // quad_perm:[2,3,0,1]: all four lanes of a quad hold the coefficient
     group_sync();                           // the scratch may be rewritten by the next frame
     PE_T(9);
     return lane < 4 ? c0 : part;
@@ -299,11 +329,13 @@ __device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, const pe_
 // Which samples form which frame is closed-form integer arithmetic over the virtual stream
 //     [carry (q samples)] ++ chunk 0 ++ chunk 1 ++ ... ++ chunk n_updates-1,
 // so the frames a call completes are independent tasks (row kb, stream): frame kb of that stream, if the call
-// completes that many.  Waves take tasks round-robin; the bookkeeping (leftover samples, counters, per-update
-// emitted-frame history) is a separate small role (mfcc_book_tile), which writes the OTHER carry buffer.
+// completes that many.  Every wave owns a contiguous run of streams and works through their due frames; the
+// bookkeeping (leftover samples, counters, per-update emitted-frame history) is a separate small role
+// (mfcc_book_tile), which writes the OTHER carry buffer.
 //
-// Latency plan: a wave keeps the NEXT due frame's PCM (4 dwords per lane) and the counters of the task after that
-// in flight while it transforms the current frame, so that only the first frame of a wave waits for HBM.
+// Latency plan: a wave keeps the NEXT due frame's PCM (4-8 dwords per lane) in flight while it transforms the
+// current frame, and nothing between the request and the conversion of those samples waits on the vector-memory
+// counter (the task generator reads its counters from registers), so only the first frame of a wave waits for HBM.
 template <class R>
 struct FrameTask {          // wave-uniform description of one due frame
     const int16_t* car;     // this stream's carry
@@ -312,6 +344,9 @@ struct FrameTask {          // wave-uniform description of one due frame
     float* proj_row;        // where the input projection of the frame goes (may be null)
     int vb, q, off0;        // first virtual sample; carry length; offset of vb in chunk u0 (negative: inside the carry)
 };
+
+// a frame's int16 sample pairs in flight: up to two bounds-checked parts per register (OR-ed when converted)
+struct PcmRegs { int a0, a1, a2, a3, b0, b1, b2, b3; bool two; };
 
 // the rare PCM path (odd chunk lengths, unaligned buffers, chunks shorter than a frame): one sample at a time
 struct RawFrame { int v[4]; };
@@ -342,131 +377,185 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
     const StreamGeom& geo = a.geo;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_kb = a.n_frame_rows;
-    const int row_tasks = ((geo.n_streams + kTileStreams - 1) / kTileStreams) * kTileStreams;
     const int C = a.chunk, hop = geo.hop, flen = geo.frame_len, slots = geo.ring_slots, U = a.n_updates;
     const size_t update_stride = (size_t)geo.n_streams * C;
-    const ptrdiff_t wrap = (ptrdiff_t)update_stride - C;
     // dword loads of (even, odd) sample pairs need every quantity that shifts a pair boundary to be even; a frame
     // may cross at most one chunk boundary (always true for a single update: its samples are carry ++ one chunk)
     const bool pairs = a.pcm_pairs_ok && ((hop | C | flen) & 1) == 0 && (C >= flen || U == 1);
 
-    // ---- task stream of this wave: (row kb, stream s), frame-row major (rows few streams reach come last);
-    //      the counters of the next task are requested one step ahead ---------------------------------------
-    int s_next = first_task + wave, kb_next = 0;
-    while (s_next >= row_tasks && kb_next < n_kb) { s_next -= row_tasks; ++kb_next; }
-    // the counters of the next TWO tasks are kept in flight (a wave's second task is often a frame row its stream does
-    // not reach in this call: skipping it must not cost a memory round trip before the first frame starts)
-    int s_req = s_next, kb_req = kb_next;                  // task the next request_counters() call fetches for
-    int pq0 = 0, pkc0 = 0, pq1 = 0, pkc1 = 0;              // [0]: counters of task (s_next, kb_next), [1]: of the one after
-    auto request_counters = [&](int& pq, int& pkc) {
-        if (kb_req < n_kb && s_req < geo.n_streams) { pq = a.st_q[s_req]; pkc = (int)a.st_kc[s_req]; }
-        s_req += task_stride;
-        while (s_req >= row_tasks && kb_req < n_kb) { s_req -= row_tasks; ++kb_req; }
+    // ---- task stream of this wave: a contiguous run of streams [s_begin, s_end), all of its due frames, frame row by
+    //      frame row.  The counters of up to 64 of those streams sit in two registers (lane i <-> stream base + i), how
+    //      many frames each completes is computed per lane, and the due (row, stream) pairs of a row are the set bits
+    //      of one ballot: picking the next task costs a few scalar instructions and no memory access ----------------
+    const int n_waves = task_stride;
+    const int per_wave = (geo.n_streams + n_waves - 1) / n_waves;
+    const int s_begin = (first_task + wave) * per_wave;
+    const int s_end = s_begin + per_wave < geo.n_streams ? s_begin + per_wave : geo.n_streams;
+    int base = s_begin, kb_next = -1;
+    int vq = 0, vkc = 0, v_first = 0, v_nnew = 0;           // per lane: counters, first frame row worth computing, frames completed
+    unsigned long long due = 0;
+    auto load_counters = [&]() {
+        const int s = base + lane;
+        vq = 0; vkc = 0;
+        if (s < s_end) { vq = a.st_q[s]; vkc = (int)a.st_kc[s]; }
     };
-    // advance to the next DUE frame of this wave's task sequence; false when the sequence is exhausted
+    auto lane_frames = [&]() {                                // (after the counters arrived)
+        const int avail = vq + U * C;
+        v_nnew = (base + lane < s_end && avail >= flen) ? 1 + (int)a.div_hop.div((uint32_t)(avail - flen)) : 0;
+        v_first = v_nnew > slots ? v_nnew - slots : 0;       // older frames would be overwritten anyway
+    };
+    // advance to the next DUE frame of the current batch of (up to 64) streams; false when the batch is exhausted
+    // (no memory access in here: the frame loop must not wait on the vector-memory counter between a PCM request and
+    //  the conversion of those samples)
     auto next_frame = [&](FrameTask<R>& f) -> bool {
-        while (kb_next < n_kb) {
-            const int kb = kb_next, s = s_next;
-            const int q = __builtin_amdgcn_readfirstlane(pq0);
-            const uint32_t kc = (uint32_t)__builtin_amdgcn_readfirstlane(pkc0);
-            s_next += task_stride;
-            while (s_next >= row_tasks && kb_next < n_kb) { s_next -= row_tasks; ++kb_next; }
-            pq0 = pq1; pkc0 = pkc1;
-            request_counters(pq1, pkc1);
-            if (s >= geo.n_streams) continue;
-            const int avail = q + U * C;
-            const int nnew = avail >= flen ? 1 + (int)a.div_hop.div((uint32_t)(avail - flen)) : 0;
-            const int f_first = nnew > slots ? nnew - slots : 0;       // older frames would be overwritten anyway
-            if (kb < f_first || kb >= nnew) continue;
-            const int tile = s >> 4, j = s & 15;
-            f.car = a.carry + (size_t)s * kCarryCap;
-            f.vb = kb * hop; f.q = q;
-            const int w0 = f.vb - q;
-            int u0 = 0;
-            f.off0 = w0;
-            if (w0 >= 0 && U > 1) { u0 = (int)a.div_chunk.div((uint32_t)w0); f.off0 = w0 - u0 * C; }
-            f.row = a.pcm + (size_t)s * C + (size_t)u0 * update_stride;
-            const int slot = (int)((kc + (uint32_t)kb) & (uint32_t)(slots - 1));
-            const size_t cell = ((size_t)tile * slots + slot) * kTileStreams + j;
-            f.ring_row = a.ring_bf16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(a.ring) + cell * kRowFloats)
-                                     : a.ring + cell * kRowFloats;
-            // projection rows: [tile][slot] blocks of 4 KB laid out [output tile][stream][g][q] (gru_device.h: proj_base)
-            f.proj_row = a.proj_ring ? a.proj_ring + ((size_t)tile * slots + slot) * kTileStreams * kProjRow + (size_t)j * 16 : nullptr;
-            return true;
+        while (due == 0) {
+            ++kb_next;
+            if (kb_next >= n_kb) return false;
+            due = __ballot(kb_next >= v_first && kb_next < v_nnew);
         }
-        return false;
+        const int i = __builtin_ctzll(due);
+        due &= due - 1;
+        const int kb = kb_next, s = base + i;
+        const int q = __builtin_amdgcn_readlane(vq, i);
+        const uint32_t kc = (uint32_t)__builtin_amdgcn_readlane(vkc, i);
+        const int tile = s >> 4, j = s & 15;
+        f.car = a.carry + (size_t)s * kCarryCap;
+        f.vb = kb * hop; f.q = q;
+        const int w0 = f.vb - q;
+        int u0 = 0;
+        f.off0 = w0;
+        if (w0 >= 0 && U > 1) { u0 = (int)a.div_chunk.div((uint32_t)w0); f.off0 = w0 - u0 * C; }
+        f.row = a.pcm + (size_t)s * C + (size_t)u0 * update_stride;
+        const int slot = (int)((kc + (uint32_t)kb) & (uint32_t)(slots - 1));
+        const size_t cell = ((size_t)tile * slots + slot) * kTileStreams + j;
+        f.ring_row = a.ring_bf16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(a.ring) + cell * kRowFloats)
+                                 : a.ring + cell * kRowFloats;
+        // projection rows: [tile][slot] blocks of 4 KB laid out [output tile][stream][g][q] (gru_device.h: proj_base)
+        f.proj_row = a.proj_ring ? a.proj_ring + ((size_t)tile * slots + slot) * kTileStreams * kProjRow + (size_t)j * 16 : nullptr;
+        return true;
     };
-    // the frame's samples as int16 pairs: point n = lane + 64 a4 <-> samples 2n, 2n+1 (zero beyond the frame length)
-    auto request_pcm = [&](const FrameTask<R>& f, int (&raw)[4]) {
+    // The frame's samples as int16 pairs: point n = lane + 64 a4 <-> samples 2n, 2n+1 (zero beyond the frame length).
+    // A frame is cut from up to three places (sample m of the frame, 0 <= m < flen):
+    //     [0, qa)      the carry, from its sample vb on          qa = q - vb  (> 0 only for the first frame of a call)
+    //     [qa, nb)     the chunk row, from off0 + m on           nb = min(flen, C - off0)
+    //     [nb, flen)   the same stream's row of the NEXT update  (several updates per call only; never together with
+    //                  a carry part: that would take a chunk shorter than a frame, which a multi-update call sends
+    //                  down the sample-by-sample path)
+    // Each part is ONE bounds-checked buffer load per a4 with the part's start folded into the lane offset: lanes
+    // before the part wrap to a huge unsigned offset, lanes behind it exceed num_records, and both read 0 -- no
+    // per-lane pointer selection, no masks; the parts are OR-ed when the samples are converted.  Nothing here
+    // consumes a loaded value, so the loads stay in flight while the current frame is transformed.
+    // (the wave-uniform part of an offset is made opaque: folded into the instruction's immediate offset it would be
+    //  added AFTER the unsigned wrap the scheme relies on)
+    auto part_offset = [](int shift, int a4) -> int {
+        int sh = shift + 256 * a4;
+        asm volatile("" : "+s"(sh));
+        return sh;
+    };
+    auto request_pcm = [&](const FrameTask<R>& f) -> PcmRegs {
+        PcmRegs r;                  // (b0..b3 stay unset unless `two`: touching them here would wait for the loads)
+        r.two = false;
         if (pairs && (f.q & 1) == 0) {
-#pragma unroll
-            for (int a4 = 0; a4 < 4; ++a4) {
-                const int n = 2 * (lane + 64 * a4);
-                const int nn = n < flen ? n : 0;                       // clamped address, masked result: no branch
-                const int vv = f.vb + nn, off = f.off0 + nn;
-                const uintptr_t pc = reinterpret_cast<uintptr_t>(f.car + vv);
-                const uintptr_t pr = reinterpret_cast<uintptr_t>(f.row + off + (off >= C ? wrap : 0));
-                const int val = *reinterpret_cast<const int*>(vv < f.q ? pc : pr);
-                raw[a4] = n < flen ? val : 0;
+            const int qa = f.q - f.vb;
+            const int over = f.off0 + flen - C;
+            const int in_row = f.off0 + flen < C ? f.off0 + flen : C;
+            const __amdgpu_buffer_rsrc_t rb = wave_rsrc(f.row, 2 * (in_row > 0 ? in_row : 0));
+            const int shift = 2 * f.off0;
+            r.a0 = __builtin_amdgcn_raw_buffer_load_b32(rb, 4 * lane + part_offset(shift, 0), 0, 0);
+            r.a1 = __builtin_amdgcn_raw_buffer_load_b32(rb, 4 * lane + part_offset(shift, 1), 0, 0);
+            r.a2 = __builtin_amdgcn_raw_buffer_load_b32(rb, 4 * lane + part_offset(shift, 2), 0, 0);
+            r.a3 = __builtin_amdgcn_raw_buffer_load_b32(rb, 4 * lane + part_offset(shift, 3), 0, 0);
+            if (qa > 0 || over > 0) {
+                const bool head = qa > 0;
+                const __amdgpu_buffer_rsrc_t r2 = head ? wave_rsrc(f.car + f.vb, 2 * (qa < flen ? qa : flen))
+                                                       : wave_rsrc(f.row + update_stride, 2 * over);
+                const int shift2 = head ? 0 : 2 * (f.off0 - C);
+                r.b0 = __builtin_amdgcn_raw_buffer_load_b32(r2, 4 * lane + part_offset(shift2, 0), 0, 0);
+                r.b1 = __builtin_amdgcn_raw_buffer_load_b32(r2, 4 * lane + part_offset(shift2, 1), 0, 0);
+                r.b2 = __builtin_amdgcn_raw_buffer_load_b32(r2, 4 * lane + part_offset(shift2, 2), 0, 0);
+                r.b3 = __builtin_amdgcn_raw_buffer_load_b32(r2, 4 * lane + part_offset(shift2, 3), 0, 0);
+                r.two = true;
             }
-        } else {
-            const RawFrame r = fetch_frame_slow<R>(f, lane, flen, C, update_stride);
-#pragma unroll
-            for (int a4 = 0; a4 < 4; ++a4) raw[a4] = r.v[a4];
+            return r;
         }
+        const RawFrame sl = fetch_frame_slow<R>(f, lane, flen, C, update_stride);
+        r.a0 = sl.v[0]; r.a1 = sl.v[1]; r.a2 = sl.v[2]; r.a3 = sl.v[3];
+        return r;
+    };
+
+    // int16 pairs -> the complex points of the packed real FFT (the first consumer of a requested frame)
+    auto convert = [&](PcmRegs& p, pe_wave::Regs<R>& v) {
+        if (p.two) { p.a0 |= p.b0; p.a1 |= p.b1; p.a2 |= p.b2; p.a3 |= p.b3; }
+        v.re[0] = (R)(int)(short)(p.a0 & 0xffff); v.im[0] = (R)(p.a0 >> 16);
+        v.re[1] = (R)(int)(short)(p.a1 & 0xffff); v.im[1] = (R)(p.a1 >> 16);
+        v.re[2] = (R)(int)(short)(p.a2 & 0xffff); v.im[2] = (R)(p.a2 >> 16);
+        v.re[3] = (R)(int)(short)(p.a3 & 0xffff); v.im[3] = (R)(p.a3 >> 16);
+        PE_T(2);
     };
 
     PE_T(0);
     // ---- kernel top: everything whose address is known without a dependent load goes out first ------------------
-    request_counters(pq0, pkc0);
-    request_counters(pq1, pkc1);
+    if (base < s_end) load_counters();
     const TabRegs tab_regs = wave_tables_issue<R>(wt);                 // table image for LDS
     // this lane's twiddles, straight from the global image (once per wave)
+#if PE_TW_LDS == 2
+    const pe_wave::LaneConsts<R> lc{};
+#else
     const pe_wave::LaneConsts<R> lc = pe_wave::lane_consts(pe_wave::bind<R>(static_cast<const unsigned char*>(wt.blob), wt.L), lane);
+#endif
     const pe_wave::Tab<R> tab = pe_wave::bind<R>(smem, wt.L, wave_lds_skip(wt.L));
     R* const S = reinterpret_cast<R*>(smem + (wt.L.total - wave_lds_skip(wt.L))) + (size_t)wave * kWaveScratchReals;
-    const int c = lane >> 2;
-    pe_wave::Regs<R> v;
-    float* row_cur = nullptr;
-    float* prow_cur = nullptr;
-    int raw[4] = {0, 0, 0, 0};
-    bool have_cur = false;
     wave_tables_commit<R>(smem, wt, tab_regs);
+    const LaneRuns lr = lane_runs(tab, lane, geo.n_filt);
     PE_T(1);
-    for (;;) {
-        FrameTask<R> nxt;
-        const bool have_next = next_frame(nxt);
-        if (have_next) request_pcm(nxt, raw);              // lands while the current frame is transformed
-        if (have_cur) {
-            const R coeff = mfcc_wave_frame<R, SH>(tab, lc, S, lane, geo.n_filt, geo.n_mfcc, v, K::PSCALE_I16, geo.log_mode);
-            const float xf = c < geo.n_mfcc ? (float)coeff : 0.0f;
-            if ((lane & 3) == 0) {
-                if (a.ring_bf16) reinterpret_cast<__bf16*>(row_cur)[c] = (__bf16)xf;     // round to nearest even where the row is stored
-                else row_cur[c] = xf;
+    for (; base < s_end; base += 64) {                 // (one batch unless a wave owns more than 64 streams)
+        if (base != s_begin) load_counters();
+        lane_frames();
+        kb_next = -1; due = 0;
+        FrameTask<R> cur;
+        if (!next_frame(cur)) continue;
+        PcmRegs pcm = request_pcm(cur);
+        // the row of a frame is stored one frame late, right after the wait for the next frame's samples: at that wait
+        // only loads are outstanding, and nothing ever waits for a store
+        float xf_prev = 0.0f;
+        float* row_prev = nullptr;
+        auto store_row = [&]() {
+            if (lane < kRowFloats) {
+                if (a.ring_bf16) reinterpret_cast<__bf16*>(row_prev)[lane] = (__bf16)xf_prev;    // round to nearest even where the row is stored
+                else row_prev[lane] = xf_prev;
             }
+        };
+        for (;;) {
+            pe_wave::Regs<R> v;
+            convert(pcm, v);                                            // the wait for this frame's samples
+            asm volatile("" : "+v"(v.re[0]), "+v"(v.re[3]) : : "memory");  // (the store below must stay below that wait)
+            __builtin_amdgcn_sched_barrier(0);
+            if (row_prev) store_row();
+            FrameTask<R> nxt;
+            const bool have_next = next_frame(nxt);
+            if (have_next) pcm = request_pcm(nxt);                      // lands while the current frame is transformed
+            const R coeff = mfcc_wave_frame<R, SH>(tab, lc, lr, S, lane, geo.n_filt, geo.n_mfcc, v, K::PSCALE_I16, geo.log_mode);
+            // coefficient c sits in lanes 4c .. 4c+3: lane c fetches it, and the first 16 lanes store the row as ONE
+            // contiguous 64-byte (bf16: 32-byte) write -- 13 coefficients + zero padding, as the clear kernel left it
+            const float mine = (lane >> 2) < geo.n_mfcc ? (float)coeff : 0.0f;
+            const float xf = __shfl(mine, (lane & 15) * 4, 64);
+            xf_prev = xf; row_prev = cur.ring_row;
             PE_T(10);
-            if (prow_cur) {
+            if (cur.proj_row) {
                 // input projection of this frame, once, for every window it will appear in: row[o] = b[o] + sum_c x[c] W[c][o]
                 // (o in MFMA slot order); the rounded float32 features are what the network would have read
                 float* XF = reinterpret_cast<float*>(S);
-                if ((lane & 3) == 0) XF[c] = xf;
+                if (lane < kRowFloats) XF[lane] = xf;
                 group_sync();
                 float acc = tab.proj_b[lane];
                 for (int cc = 0; cc < tab.proj_rows; ++cc) acc = fmaf(XF[cc], tab.proj_w[cc * kProjRow + lane], acc);
-                prow_cur[(size_t)((lane >> 2) & 3) * (kTileStreams * 16) + (lane >> 4) * 4 + (lane & 3)] = acc;   // o = 16 g + 4 tl + q
+                cur.proj_row[(size_t)((lane >> 2) & 3) * (kTileStreams * 16) + (lane >> 4) * 4 + (lane & 3)] = acc;   // o = 16 g + 4 tl + q
                 group_sync();
             }
+            if (!have_next) break;
+            cur = nxt;
         }
-        if (!have_next) break;
-#pragma unroll
-        for (int a4 = 0; a4 < 4; ++a4) {
-            v.re[a4] = (R)(int)(short)(raw[a4] & 0xffff);
-            v.im[a4] = (R)(raw[a4] >> 16);
-        }
-        PE_T(2);
-        row_cur = nxt.ring_row;
-        prow_cur = nxt.proj_row;
-        have_cur = true;
+        store_row();
     }
     PE_T(15);
 }
@@ -480,7 +569,12 @@ __device__ __forceinline__ void mfcc_offline_frames(const MfccOfflineArgs<R>& a,
     wave_tables_commit<R>(smem, wt, tab_regs);
     const pe_wave::Tab<R> tab = pe_wave::bind<R>(smem, wt.L, wave_lds_skip(wt.L));
     R* S = reinterpret_cast<R*>(smem + (wt.L.total - wave_lds_skip(wt.L))) + (size_t)wave * kWaveScratchReals;
+#if PE_TW_LDS == 2
+    const pe_wave::LaneConsts<R> lc{};
+#else
     const pe_wave::LaneConsts<R> lc = pe_wave::lane_consts(pe_wave::bind<R>(static_cast<const unsigned char*>(wt.blob), wt.L), lane);
+#endif
+    const LaneRuns lr = lane_runs(tab, lane, geo.n_filt);
     const int flen = geo.frame_len;
     for (long long fr = (long long)blockIdx.x * waves + wave; fr < a.n_frames; fr += (long long)gridDim.x * waves) {
         const double* x = a.audio + fr * geo.hop;
@@ -491,7 +585,7 @@ __device__ __forceinline__ void mfcc_offline_frames(const MfccOfflineArgs<R>& a,
             v.re[a4] = n < flen ? (R)x[n] : R(0);
             v.im[a4] = n + 1 < flen ? (R)x[n + 1] : R(0);
         }
-        const R coeff = mfcc_wave_frame<R, SH>(tab, lc, S, lane, geo.n_filt, geo.n_mfcc, v, RealK<R>::INV_FFT, geo.log_mode);
+        const R coeff = mfcc_wave_frame<R, SH>(tab, lc, lr, S, lane, geo.n_filt, geo.n_mfcc, v, RealK<R>::INV_FFT, geo.log_mode);
         const int c = lane >> 2;
         if ((lane & 3) == 0) {
             if (a.out && c < geo.n_mfcc) a.out[fr * geo.n_mfcc + c] = (double)coeff;
