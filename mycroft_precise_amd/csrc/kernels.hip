@@ -238,6 +238,9 @@ template <class R>
 static hipError_t launch_mfcc(const MfccStreamArgs<R>& a, const WaveTables<R>& t, int n_cus, hipStream_t s) {
     const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
     const int fb = stream_frame_blocks(a.geo.n_streams, n_cus);
+    static const int skip = env_int("PE_MFCC_SKIP", 0);        // tuning aid (wrong results): 1 = frame role only, 2 = bookkeeping role only
+    if (skip == 1) { hipLaunchKernelGGL((mfcc_kernel<R, ShapeStock>), dim3(fb), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb); return hipGetLastError(); }
+    if (skip == 2) { hipLaunchKernelGGL((mfcc_kernel<R, ShapeStock>), dim3(tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, 0); return hipGetLastError(); }
     if (t.L.mel_pad == ShapeStock::MEL) hipLaunchKernelGGL((mfcc_kernel<R, ShapeStock>), dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
     else hipLaunchKernelGGL((mfcc_kernel<R, ShapeAny>), dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
     return hipGetLastError();

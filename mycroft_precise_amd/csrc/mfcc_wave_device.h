@@ -495,7 +495,7 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
 
     PE_T(0);
     // ---- kernel top: everything whose address is known without a dependent load goes out first ------------------
-    if (base < s_end) load_counters();
+    load_counters();
     const TabRegs tab_regs = wave_tables_issue<R>(wt);                 // table image for LDS
     // this lane's twiddles, straight from the global image (once per wave)
 #if PE_TW_LDS == 2
@@ -505,16 +505,18 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
 #endif
     const pe_wave::Tab<R> tab = pe_wave::bind<R>(smem, wt.L, wave_lds_skip(wt.L));
     R* const S = reinterpret_cast<R*>(smem + (wt.L.total - wave_lds_skip(wt.L))) + (size_t)wave * kWaveScratchReals;
+    // the wave's first frame is requested BEFORE the table image is waited for: the HBM round trip of its samples and
+    // the L2 round trip of the tables overlap (a 4096-stream update is one or two frames per wave: this is its latency)
+    lane_frames();
+    FrameTask<R> cur;
+    bool have = next_frame(cur);
+    PcmRegs pcm;
+    if (have) pcm = request_pcm(cur);
     wave_tables_commit<R>(smem, wt, tab_regs);
     const LaneRuns lr = lane_runs(tab, lane, geo.n_filt);
     PE_T(1);
-    for (; base < s_end; base += 64) {                 // (one batch unless a wave owns more than 64 streams)
-        if (base != s_begin) load_counters();
-        lane_frames();
-        kb_next = -1; due = 0;
-        FrameTask<R> cur;
-        if (!next_frame(cur)) continue;
-        PcmRegs pcm = request_pcm(cur);
+    for (;;) {                                          // batches of up to 64 streams (one, unless a wave owns more)
+        if (have) {
         // the row of a frame is stored one frame late, right after the wait for the next frame's samples: at that wait
         // only loads are outstanding, and nothing ever waits for a store
         float xf_prev = 0.0f;
@@ -556,6 +558,14 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
             cur = nxt;
         }
         store_row();
+        }
+        base += 64;
+        if (base >= s_end) break;
+        load_counters();
+        lane_frames();
+        kb_next = -1; due = 0;
+        have = next_frame(cur);
+        if (have) pcm = request_pcm(cur);
     }
     PE_T(15);
 }
