@@ -364,7 +364,11 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
     // FP64 multiply-adds and the MFMAs do not overlap on a SIMD)
     static const int ff_env = env_int("PE_FUSED_FRAMES_FIRST", -1);
     const int frames_first = ff_env >= 0 ? ff_env : (g.waves_per_tile != 4 && tiles >= 4 * n_cus);
-    const int fb = stream_frame_blocks(m.geo.n_streams, n_cus, frames_first ? 3 : 4);
+    // resident frame workgroups per compute unit: at one network tile per compute unit the launch lasts as long as the
+    // network's dependent chain, and two frame workgroups (two streams per wave, the second one's samples prefetched)
+    // disturb that chain less than four (measured, 4096 streams: 20.6 vs 20.9 us in phase, 21.1 vs 22.5 us with
+    // desynchronised streams); larger batches want every wave slot
+    const int fb = stream_frame_blocks(m.geo.n_streams, n_cus, tiles <= n_cus ? 2 : frames_first ? 3 : 4);
     int gru_blocks = g.waves_per_tile == 4 ? tiles : (tiles + 3) / 4;
     static const int skip = env_int("PE_FUSED_SKIP", 0);       // tuning aid: 1 = launch without the MFCC roles, 2 = without the network role
     if (skip == 1) { hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false>), dim3(gru_blocks), dim3(256), lds, s, m, t, g, gru_blocks, 0, 0, 0); return hipGetLastError(); }
