@@ -204,6 +204,7 @@ def main():
                     help="bf16 = 32-byte bf16 feature rows (BASELINE configs[4]: bf16 MFCC+GRU); needs --gru-precision bf16")
     ap.add_argument('--units', default='20', help="GRU widths, e.g. 20 (stock, default) or 256,256 (BASELINE configs[3])")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-batched', action='store_true', help='skip the pe_update_many extra (profiling runs: keeps per-kernel means clean)')
     ap.add_argument('--resident-updates', type=int, default=256,
                     help='distinct PCM chunks kept in HBM per stream (reused cyclically beyond that)')
     args = ap.parse_args()
@@ -325,7 +326,7 @@ def main():
     # at once.  Results are bit-identical to single updates; a caller pays 8 chunks of buffering latency.
     time_batched = None
     depth = 8
-    if world == 1 and (stock or args.gru_precision == 'bf16') and n_res >= 2 * depth:      # N = 1 only: no collectives outside the timed region
+    if world == 1 and not args.no_batched and (stock or args.gru_precision == 'bf16') and n_res >= 2 * depth:      # N = 1 only: no collectives outside the timed region
         try:
             engine.reserve_updates(depth, CHUNK)
             many_out = torch.zeros((depth, B), dtype=torch.float32, device=device)

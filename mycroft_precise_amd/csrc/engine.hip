@@ -72,7 +72,7 @@ struct pe_engine {
     int wide_kx4[2] = {1, 1};
     float* wide_wd = nullptr;
     // bf16-operand network (pe_params.gru_precision = 1)
-    uint16_t* wx_bf16 = nullptr; uint16_t* wr_bf16 = nullptr; float* bias_bf16 = nullptr; float* wd_bf16 = nullptr;
+    uint16_t* wx_bf16 = nullptr; uint16_t* wr_bf16 = nullptr; float* wd_bf16 = nullptr;
     // on-device ThresholdDecoder / TriggerDetector (pe_set_decoder / pe_set_trigger)
     double* cd = nullptr; int cd_len = 0, dec_min_out = 0, dec_out_range = 0; double dec_center = 0.5;
     int32_t* activation = nullptr; double trig_threshold = 0.5; int trig_level = 3, trig_rearm = -8; bool trig_on = false;
@@ -245,8 +245,9 @@ int pack_gru_weights_bf16(pe_engine* e, const pe_gru_layer& L, const float* dens
     // with use_delta the layer has 2 F inputs: features in k = 0..15, their first differences in k = 16..31
     const bool delta = e->prm.use_delta != 0;
     const int H = L.units, F = delta ? L.n_in / 2 : L.n_in;
+    if (delta && F > 14) return fail(e, PE_ERR_UNSUPPORTED, "bf16 network with use_delta takes n_mfcc <= 14 (k slots 30, 31 of the input contraction carry the biases)");
     std::vector<uint16_t> wx((size_t)6 * 64 * 8, 0), wr((size_t)6 * 64 * 8, 0);
-    std::vector<float> bias((size_t)6 * 4 * 64, 0.f), wd((size_t)8 * 64, 0.f);
+    std::vector<float> wd((size_t)8 * 64, 0.f);
     for (int tl = 0; tl < 6; ++tl) {
         const int gate = tl >> 1, t = tl & 1;
         for (int lane = 0; lane < 64; ++lane) {
@@ -261,10 +262,15 @@ int pack_gru_weights_bf16(pe_engine* e, const pe_gru_layer& L, const float* dens
                     if (delta && k >= 16 && k - 16 < F) wx[((size_t)tl * 64 + lane) * 8 + ek] = to_bf16(L.kernel[(size_t)(F + k - 16) * 3 * H + col]);
                     if (k < H) wr[((size_t)tl * 64 + lane) * 8 + ek] = to_bf16(L.recurrent_kernel[(size_t)k * 3 * H + col]);
                 }
-            }
-            for (int q = 0; q < 4; ++q) {                            // C rows 4 g + q of this lane
-                const int ub = 8 * g + 4 * t + q;
-                if (ub < H) bias[((size_t)tl * 4 + q) * 64 + lane] = L.bias[gate * H + ub];
+                if (g == 3) {                                        // k = 30, 31: the bias as hi + lo against x = 1.0
+                    const float b = L.bias[col];
+                    const uint16_t hi = to_bf16(b);
+                    uint32_t hb = (uint32_t)hi << 16;
+                    float hif;
+                    std::memcpy(&hif, &hb, 4);
+                    wx[((size_t)tl * 64 + lane) * 8 + 6] = hi;
+                    wx[((size_t)tl * 64 + lane) * 8 + 7] = to_bf16(b - hif);
+                }
             }
         }
     }
@@ -276,7 +282,6 @@ int pack_gru_weights_bf16(pe_engine* e, const pe_gru_layer& L, const float* dens
     int rc;
     if ((rc = dev_upload(e, &e->wx_bf16, wx))) return rc;
     if ((rc = dev_upload(e, &e->wr_bf16, wr))) return rc;
-    if ((rc = dev_upload(e, &e->bias_bf16, bias))) return rc;
     if ((rc = dev_upload(e, &e->wd_bf16, wd))) return rc;
     return PE_OK;
 }
@@ -428,7 +433,7 @@ GruArgs gru_args(const pe_engine* e) {
     a.window = emit_window(e->prm); a.hop = e->prm.hop_samples;
     a.frame_len = frame_len_of(e->prm);
     a.bf16 = e->prm.gru_precision == 1;
-    a.wx_bf16 = e->wx_bf16; a.wr_bf16 = e->wr_bf16; a.bias_bf16 = e->bias_bf16; a.wd_bf16 = e->wd_bf16;
+    a.wx_bf16 = e->wx_bf16; a.wr_bf16 = e->wr_bf16; a.wd_bf16 = e->wd_bf16;
     a.feats = nullptr; a.out = nullptr; a.row_stride = 0;
     // Four waves per tile cut the latency of a tile's chain; that only pays while every tile gets a CU of its
     // own next to one MFCC workgroup.  Measured (fused, f64 front end; tools/gpu_policy.py): 4096 streams

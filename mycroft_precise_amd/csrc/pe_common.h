@@ -122,9 +122,8 @@ struct GruArgs {
     const float* wd_plain;  // [H]     dense kernel
     // bf16-operand variant (gru_bf16_device.h): unit 8 g + i, tiles z0 z1 r0 r1 c0 c1
     int bf16;               // != 0: run the bf16 kernel
-    const void* wx_bf16;    // [6][64] x 8 bf16    input kernel, k = 8 g + e <-> feature
+    const void* wx_bf16;    // [6][64] x 8 bf16    input kernel, k = 8 g + e <-> feature; k = 30, 31: bias hi, lo
     const void* wr_bf16;    // [6][64] x 8 bf16    recurrent kernel, k = 8 g + e <-> unit
-    const float* bias_bf16; // [6][4][64]
     const float* wd_bf16;   // [8][64]
     // input: either the feature ring (+ per-stream emitted-frame counters) ...
     const float* ring;

@@ -19,7 +19,7 @@ rm -rf $OUT/${tag}_prof
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_prof -o trace -- python $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/${tag}_bench_prof.json 2> $OUT/${tag}_rocprof.err
 for f in $(find $OUT/${tag}_prof -name "*kernel_stats.csv"); do grep -E "Name|pe::" $f | cut -c1-220 > $OUT/${tag}_kernel_stats.csv; cat $OUT/${tag}_kernel_stats.csv; done
 echo "== PMC passes"
-ARGS="--no-cpu-baseline --steps 40 --warmup 40 $*"
+ARGS="--no-cpu-baseline --no-batched --steps 40 --warmup 40 $*"
 i=0
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
@@ -27,7 +27,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES S
   timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/${tag}_pmc_$i -o pmc -- python $ROOT/bench.py $ARGS > /dev/null 2> $OUT/${tag}_pmc_$i.err
   echo "== pass $i ($pass): rc=$?"
 done
-python3 - "$tag" <<'PY'
+python3 - "$tag" "$@" <<'PY'
 import csv, glob, os, sys, collections
 tag = sys.argv[1]
 out = os.environ.get('GRAFT_REPO_ROOT', os.getcwd()) + '/gpurun_out'
@@ -37,6 +37,16 @@ for f in glob.glob(out + '/%s_pmc_*/**/*counter_collection.csv' % tag, recursive
         k = r.get('Kernel_Name', '')
         if 'pe::' not in k or 'clear' in k: continue
         agg[k.split('(')[0].replace('void ', '')][r['Counter_Name']].append(float(r['Counter_Value']))
+import json
+traffic = {'source': 'tools/gpu_round.sh %s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bench.py --no-batched --steps 40, mean per dispatch' % tag,
+           'note': 'bytes = (FETCH_SIZE + WRITE_SIZE) * 1024, raw counters; see profiles/README.md for the calibration of this access pattern'}
+for k in agg:
+    if 'FETCH_SIZE' in agg[k] and 'WRITE_SIZE' in agg[k]:
+        f, w = agg[k]['FETCH_SIZE'], agg[k]['WRITE_SIZE']
+        traffic[k.split('<')[0].replace('pe::', '')] = {'fetch_kb': round(sum(f) / len(f), 1), 'write_kb': round(sum(w) / len(w), 1), 'kernel': k}
+rest = sys.argv[2:]
+traffic['streams'] = int(rest[rest.index('--streams') + 1]) if '--streams' in rest else 4096
+json.dump(traffic, open(out + '/%s_pmc_latest.json' % tag, 'w'), indent=1)
 with open(out + '/%s_pmc_summary.csv' % tag, 'w') as fo:
     fo.write('kernel,counter,dispatches,mean_per_dispatch\n')
     for k in sorted(agg):
