@@ -69,8 +69,8 @@ typedef struct pe_params {
 /* One Keras GRU layer (precise/model.py:77-81), Keras weight layout, gate order z|r|h. */
 typedef struct pe_gru_layer {
     int32_t n_in;                    /* F (13) for layer 0, units of the previous layer after */
-    int32_t units;                   /* H (20): 1..32 register-resident kernels; 64..256 (multiples of
-                                        64) the streamed-weight kernel                            */
+    int32_t units;                   /* H (20): 1..32 register-resident kernels; 33..256 the streamed-weight
+                                        kernel (zero-padded to a multiple of 64 inside)           */
     const float* kernel;             /* [n_in][3*units] row-major                              */
     const float* recurrent_kernel;   /* [units][3*units]                                       */
     const float* bias;               /* [3*units]                                              */
@@ -78,8 +78,8 @@ typedef struct pe_gru_layer {
 
 /* Sequential([GRU..., Dense(1, sigmoid)])   (precise/model.py:76-82) */
 typedef struct pe_weights {
-    int32_t n_layers;                /* 1 in the reference; 2 = GRU(H, return_sequences) -> GRU(H) with
-                                        equal widths H in {64,128,192,256} (BASELINE configs[3])  */
+    int32_t n_layers;                /* 1 in the reference; 2 = GRU(H1, return_sequences) -> GRU(H2), widths
+                                        33..256 (BASELINE configs[3]: 256, 256)                   */
     const pe_gru_layer* layers;
     const float* dense_kernel;       /* [units_last]                                           */
     float dense_bias;
@@ -206,15 +206,17 @@ int pe_set_fused(pe_engine* e, int32_t enabled);
 
 /* Input projections: 1 = the MFCC stage stores x.W + b of every frame beside its feature row (256 bytes per frame and
  * stream) and the network starts each timestep from that row instead of recomputing the projection in each of the
- * n_features windows a frame appears in (16 of its 41 MFMAs per timestep); 0 = recompute.  Default: on for the
- * float32 network of 17..20 units without delta features while the engine has <= 16384 streams (the rows stay
- * cache-resident).  Both settings agree to float32 rounding (different summation order), each is deterministic;
- * changing the setting restarts all streams. */
+ * n_features windows a frame appears in (16 of its 41 MFMAs per timestep); 0 = recompute (the default: measured, the
+ * rows cost more to load every timestep than the MFMAs they save).  Available for the float32
+ * network of 17..20 units without delta features.  Both settings agree to float32 rounding (different summation
+ * order), each is deterministic; changing the setting restarts all streams. */
 int pe_set_input_projection(pe_engine* e, int32_t enabled);
 
 /* Network kernel shape: 0 (default) = automatic (four waves share each 16-stream tile while the
  * engine has no more tiles than the device has compute units -- 256 on MI355X, i.e. 4096 streams -- one wave
- * per tile beyond; use_delta networks always take the one-wave kernel), 1 / 4 = forced.  Results are identical. */
+ * per tile beyond; use_delta networks always take the one-wave kernel), 1 / 4 = forced: results are bit-identical.
+ * 16 = sixteen lanes per stream without matrix cores (needs pe_set_input_projection(e, 1); its own summation order:
+ * agrees to ~5e-6; slower, kept for measurement). */
 int pe_set_gru_waves(pe_engine* e, int32_t waves_per_tile);
 
 /* HIP-event timing of the kernels launched by the last *_device/host update on this engine
