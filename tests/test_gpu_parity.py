@@ -1024,6 +1024,17 @@ def test_bench_two_ranks_on_one_gpu_shards_streams_correctly():
     assert not np.array_equal(both[:, :512], both[:, 512:])          # the two shards really are different streams
 
 
+def test_waves_owning_more_than_64_streams():
+    """mfcc_frame_tasks keeps the counters of 64 streams per wave in registers and refills them batch by batch when a
+    wave owns more: with one resident frame workgroup per compute unit (PE_FRAME_WG_PER_CU=1: 1024 waves) that starts
+    above 65536 streams.  tests/many_streams_check.py: oracle on seeded streams, identical input => identical output
+    in either batch of a wave, fused == two launches, at 66000 streams."""
+    env = dict(os.environ, PE_FRAME_WG_PER_CU='1', PYTHONPATH=REPO + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'tests', 'many_streams_check.py'), '66000'], env=env, cwd=REPO,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.startswith('ok'), (out.stdout[-500:], out.stderr[-2000:])
+
+
 # ---- BASELINE configs[0]: one stream through the engine executable (plumbing) ------------------------
 def test_precise_engine_subprocess_protocol(model_file, stock_weights):
     """PreciseEngine + `python -m mycroft_precise_amd.scripts.engine`: raw int16 on stdin, one ASCII
