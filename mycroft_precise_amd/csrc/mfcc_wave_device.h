@@ -189,6 +189,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_rsrc(const void* p, int b
                                              __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+// The exchange area has one complex slot per lane that no exchange ever writes (the stride-5 padding).  The tail of a
+// frame may READ such a slot as a term with weight zero (DCT terms past n_filt in the wide table shape), so it must
+// hold a finite number: zeroed once per wave -- left alone it is whatever the previous workgroup left in LDS.
+template <class R>
+__device__ __forceinline__ void wave_scratch_init(R* S, int lane) {
+    reinterpret_cast<pe_wave::cx<R>*>(S)[pe_wave::xchg_index(lane, pe_wave::kXchgStride - 1)] = pe_wave::cx<R>{R(0), R(0)};
+    group_sync();
+}
+
 // One frame on one wave.  pcm[a] = the int16 pair (samples 2n, 2n+1 in the low / high half) of point n = lane + 64 a,
 // already zero beyond the frame length -- or, FROM_REAL, re[]/im[] hold the samples as reals (offline form).
 // Returns coefficient c in the four lanes 4c..4c+3 (c < n_mfcc).  S: this wave's scratch; after the call
@@ -532,6 +541,7 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
     if (have) pcm = request_pcm(cur);
     wave_tables_commit<R>(smem, wt, tab_regs);
     const LaneRuns lr = lane_runs(tab, lane, geo.n_filt);
+    wave_scratch_init(S, lane);
     PE_T(1);
     for (;;) {                                          // batches of up to 64 streams (one, unless a wave owns more)
         if (have) {
@@ -603,6 +613,7 @@ __device__ __forceinline__ void mfcc_offline_frames(const MfccOfflineArgs<R>& a,
     const pe_wave::LaneConsts<R> lc = pe_wave::lane_consts(pe_wave::bind<R>(static_cast<const unsigned char*>(wt.blob), wt.L), lane);
 #endif
     const LaneRuns lr = lane_runs(tab, lane, geo.n_filt);
+    wave_scratch_init(S, lane);
     const int flen = geo.frame_len;
     for (long long fr = (long long)blockIdx.x * waves + wave; fr < a.n_frames; fr += (long long)gridDim.x * waves) {
         const double* x = a.audio + fr * geo.hop;
