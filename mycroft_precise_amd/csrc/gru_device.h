@@ -121,7 +121,7 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
         uint32_t ke = valid ? a.st_ke[stream] : 0u;
         if (a.predict_ke && valid) {
             // running beside the MFCC role of the same update: derive the emitted-frame count this
-            // update will produce from the state before it (same arithmetic as mfcc_stream_tile)
+            // update will produce from the state before it (same arithmetic as mfcc_book_tile)
             const int q = a.st_q[stream];
             const uint32_t kc = a.st_kc[stream];
             const int avail = q + a.chunk;

@@ -80,7 +80,7 @@ struct MfccStreamArgs {
     float* ring;            // [n_tiles][ring_slots][16 streams][16 floats] -- or, ring_bf16, 16 bf16 per row (32 bytes)
     int ring_bf16;
     float* proj_ring;       // [n_tiles][ring_slots][16 streams][64 floats] x.W + b of every frame, or null
-    // several updates per launch (mfcc_many_tile): chunk u of stream s at pcm + (u*n_streams + s)*chunk
+    // several updates per launch (pe_update_many): chunk u of stream s at pcm + (u*n_streams + s)*chunk
     int n_updates;
     int n_frame_rows;       // frame tasks per stream: the most frames one stream can complete in this call
     FastDiv div_hop, div_chunk;   // division by hop_samples / by the chunk length
