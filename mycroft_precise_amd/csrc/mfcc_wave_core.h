@@ -133,10 +133,11 @@ PE_HD void split_power(const Regs<R>& v, const cx<R>& zq0, const cx<R>& zq1, con
     }
 }
 
-// bins of the four powers of lane l
+// scratch slots (ppos) of the four powers of lane l: bins kbase, kbase + 64, 256 - kbase, 192 - kbase
+template <class R>
 PE_HD void power_bins(int l, int (&bins)[4]) {
     const int kb = kbase_of(l);
-    bins[0] = kb; bins[1] = kb + 64; bins[2] = 256 - kb; bins[3] = 192 - kb;
+    bins[0] = ppos<R>(kb); bins[1] = ppos<R>(kb + 64); bins[2] = ppos<R>(256 - kb); bins[3] = ppos<R>(192 - kb);
 }
 
 // log(x), x > 0.  float64: table-driven -- x = m 2^e, m in [0.5, 1) falls in one of 128 intervals with centre c;

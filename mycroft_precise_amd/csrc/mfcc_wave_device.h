@@ -270,13 +270,13 @@ __device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, const pe_
     R* PART = S + kPartOff;
     R* LM = S + kLogMelOff;
     int bins[4];
-    power_bins(lane, bins);
+    power_bins<R>(lane, bins);
 #pragma unroll
     for (int j = 0; j < 4; ++j) P[bins[j]] = pw[j];
     R psum = (pw[0] + pw[1]) + (pw[2] + pw[3]);
     if (lane0) {
         const R p128 = (v.re[2] * v.re[2] + v.im[2] * v.im[2]) * pscale;
-        P[128] = p128;
+        P[ppos<R>(128)] = p128;
         psum += p128;
     }
     group_sync();

@@ -37,9 +37,10 @@ constexpr int kLogTab = 128;        // intervals of the mantissa in the table-dr
 // sums and the log-mel energies
 constexpr int kXchgStride = 5;                        // complex elements per lane
 constexpr int kScratchReals = kLanes * kXchgStride * 2;
-constexpr int kPowerOff = 0;                          // P[0..256]
-constexpr int kPartOff = 264;                         // PART[0..63]
-constexpr int kLogMelOff = 328;                       // LM[0..n_filt] (n_filt <= 64)
+constexpr int kPowerOff = 0;                          // P[ppos(0) .. ppos(256)]: the power spectrum, one idle slot after every 16 bins
+constexpr int kPowerSlots = 257 + 16;                 // upper bound of power_slots<R>()
+constexpr int kPartOff = 288;                         // PART[0..63]
+constexpr int kLogMelOff = 352;                       // LM[0..n_filt] (n_filt <= 64)
 static_assert(kLogMelOff + kMaxFilt + 1 <= kScratchReals, "scratch layout");
 
 #if defined(__HIPCC__)
@@ -48,6 +49,13 @@ static_assert(kLogMelOff + kMaxFilt + 1 <= kScratchReals, "scratch layout");
 #define PE_WAVE_HD
 #endif
 PE_WAVE_HD inline int kbase_of(int l) { return (l >> 4) + 4 * ((l >> 2) & 3) + 16 * (l & 3); }
+// Slot of bin k in the scratch.  The lanes of a 16-lane store group own bins 4 c + 16 d (+ const): packed densely, the
+// four d's of a c would fall on the same LDS banks (a 4-way conflict on every power store); skewed by one slot per 16
+// bins they do not.  The filterbank runs are laid out in slot space; an idle slot inside a run carries weight 0.
+// (float32: the 4-byte stores of a 32-lane group cover 32 different banks as they are -- no skew, one register less)
+template <class R> PE_WAVE_HD inline int ppos(int k) { return sizeof(R) == 8 ? k + (k >> 4) : k; }
+template <class R> PE_WAVE_HD inline int bin_of_slot(int p) { return sizeof(R) == 8 ? ((p % 17 == 16) ? -1 : 16 * (p / 17) + p % 17) : p; }
+template <class R> PE_WAVE_HD inline int power_slots() { return ppos<R>(256) + 1; }
 
 struct Layout {          // byte offsets into the blob (16-byte aligned sections)
     int tw1, tw2, tw3, w512, logtab, mel_w, dct_w, mel_start, pstart, partner, proj_w, proj_b, total;
@@ -98,33 +106,46 @@ std::string build(const double* mel_filters, int n_filt, int n_mfcc, std::vector
         if (a < 0) { a = 0; b = 0; }                     // an empty filter: its energy is 0 -> log(eps)
         lo[f] = a; hi[f] = b;
     }
-    int mel_len = 0;
-    for (int len = 1; len <= kMaxMelLen && !mel_len; ++len) {
-        int lanes = 0;
-        for (int f = 0; f < n_filt; ++f) { const int n = hi[f] - lo[f]; lanes += n > 0 ? (n + len - 1) / len : 1; }
-        if (lanes <= kLanes) mel_len = len;
-    }
-    if (!mel_len) return "mel filterbank too wide for one wave: the non-zero runs need more than 64 lanes of 16 bins";
+    // runs of a filter's support, cut so that a run spans at most `len` SLOTS (ppos) of the scratch
+    auto cut = [&](int len, std::vector<int>* f_of, std::vector<int>* lo_of, std::vector<int>* n_of, std::vector<int>* first_of, int* parts_max) {
+        int runs = 0, pmax = 1;
+        for (int f = 0; f < n_filt; ++f) {
+            if (first_of) (*first_of)[f] = runs;
+            int parts = 0;
+            if (hi[f] == lo[f]) {
+                if (f_of && runs < 64) { (*f_of)[runs] = f; (*lo_of)[runs] = lo[f]; (*n_of)[runs] = 0; }
+                ++runs; parts = 1;
+            }
+            for (int k = lo[f]; k < hi[f];) {
+                int e = k;
+                while (e + 1 < hi[f] && ppos<R>(e + 1) - ppos<R>(k) + 1 <= len) ++e;
+                if (f_of && runs < 64) { (*f_of)[runs] = f; (*lo_of)[runs] = k; (*n_of)[runs] = e - k + 1; }
+                ++runs; ++parts;
+                k = e + 1;
+            }
+            if (parts > pmax) pmax = parts;
+        }
+        if (parts_max) *parts_max = pmax;
+        return runs;
+    };
+    // the kernel's run loop has a compile-time trip count (10 slots in the stock shape, 16 in the wide one), so a run
+    // may as well use all of it: the stock length first, the wide one if that does not fit 64 lanes / 8 runs per filter
     const int dct_len = (n_filt + 3) / 4;
+    int mel_len = 0;
+    {
+        int pm = 0;
+        if (dct_len <= 5 && cut(10, nullptr, nullptr, nullptr, nullptr, &pm) <= kLanes && pm <= 8) mel_len = 10;
+        else if (cut(kMaxMelLen, nullptr, nullptr, nullptr, nullptr, &pm) <= kLanes) mel_len = kMaxMelLen;
+    }
+    if (!mel_len) return "mel filterbank too wide for one wave: the non-zero runs need more than 64 lanes of 16 slots";
     // the kernel's table-driven loops have compile-time bounds: "stock" (10 / 5 / 8) when everything fits, else 16 / 16 / 16
+    std::vector<int> pstart(kMaxFilt + 1, 0), mel_start(64, 0), seg_lo(64, 0), seg_n(64, 0), seg_f(64, -1);
     int np_needed = 1;
-    for (int f = 0; f < n_filt; ++f) { const int n = hi[f] - lo[f]; np_needed = std::max(np_needed, n > 0 ? (n + mel_len - 1) / mel_len : 1); }
+    int lane = cut(mel_len, &seg_f, &seg_lo, &seg_n, &pstart, &np_needed);
+    const int np_max = np_needed;
     const bool stock = mel_len <= 10 && dct_len <= 5 && np_needed <= 8;
     const int mel_pad = stock ? 10 : 16, dct_pad = stock ? 5 : 16, np_pad = stock ? 8 : 16;
     if (np_needed > np_pad) return "mel filterbank: a filter is spread over more than 16 lanes";
-    std::vector<int> pstart(kMaxFilt + 1, 0), mel_start(64, 0), seg_lo(64, 0), seg_n(64, 0), seg_f(64, -1);
-    int lane = 0, np_max = 1;
-    for (int f = 0; f < n_filt; ++f) {
-        pstart[f] = lane;
-        const int n = hi[f] - lo[f];
-        const int parts = n > 0 ? (n + mel_len - 1) / mel_len : 1;
-        if (parts > np_max) np_max = parts;
-        for (int t = 0; t < parts; ++t, ++lane) {
-            seg_f[lane] = f;
-            seg_lo[lane] = lo[f] + t * mel_len;
-            seg_n[lane] = n > 0 ? std::min(mel_len, hi[f] - seg_lo[lane]) : 0;
-        }
-    }
     for (int f = n_filt; f <= kMaxFilt; ++f) pstart[f] = lane;
     L = layout((int)sizeof(R), mel_pad, dct_pad, np_max, proj_w ? n_mfcc : 0);
     L.mel_len = mel_len; L.dct_len = dct_len;
@@ -161,14 +182,14 @@ std::string build(const double* mel_filters, int n_filt, int n_mfcc, std::vector
             R v[2] = {(R)inv_c, (R)logc};
             std::memcpy(blob.data() + L.logtab + (size_t)i * 2 * sizeof(R), v, sizeof v);
         }
-    // mel runs: lane reads P[start .. start + mel_pad), fully inside [0, 257)
+    // mel runs: lane reads slots [start, start + mel_pad) of the power spectrum, fully inside [0, kPowerSlots)
     for (int l = 0; l < 64; ++l) {
-        int start = seg_lo[l];
-        if (start + mel_pad > kBins) start = kBins - mel_pad;
+        int start = ppos<R>(seg_lo[l]);
+        if (start + mel_pad > power_slots<R>()) start = power_slots<R>() - mel_pad;
         if (seg_f[l] < 0) start = 0;
         put_i(L.mel_start, l, start);
         for (int i = 0; i < mel_pad; ++i) {
-            const int k = start + i;
+            const int k = bin_of_slot<R>(start + i);
             double w = 0.0;
             if (seg_f[l] >= 0 && k >= seg_lo[l] && k < seg_lo[l] + seg_n[l]) w = mel_filters[(size_t)seg_f[l] * kBins + k];
             put_r(L.mel_w, i * 64 + l, w);

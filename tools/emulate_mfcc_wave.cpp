@@ -79,10 +79,10 @@ static int run(int n_filt, int n_mfcc, int log_mode, const char* ffilt, const ch
         for (int l = 0; l < 64; ++l) {
             R pw[4]; int bins[4];
             split_power(v[l], zq0[l], zq1[l], lc[l].w512[0], lc[l].w512[1], pscale * (R)0.25, pw);
-            power_bins(l, bins);
+            power_bins<R>(l, bins);
             for (int j = 0; j < 4; ++j) P[bins[j]] = pw[j];
             lane_sum[l] = (pw[0] + pw[1]) + (pw[2] + pw[3]);
-            if (kbase_of(l) == 0) { const R p128 = (v[l].re[2] * v[l].re[2] + v[l].im[2] * v[l].im[2]) * pscale; P[128] = p128; lane_sum[l] += p128; }
+            if (kbase_of(l) == 0) { const R p128 = (v[l].re[2] * v[l].re[2] + v[l].im[2] * v[l].im[2]) * pscale; P[ppos<R>(128)] = p128; lane_sum[l] += p128; }
         }
         // xor butterfly over the wave (1, 2, 4, ..., 32), what __shfl_xor does
         for (int o = 1; o < 64; o <<= 1) { R nx[64]; for (int l = 0; l < 64; ++l) nx[l] = lane_sum[l] + lane_sum[l ^ o]; for (int l = 0; l < 64; ++l) lane_sum[l] = nx[l]; }
