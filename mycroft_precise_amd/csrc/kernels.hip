@@ -18,7 +18,7 @@ namespace pe {
 // workgroups [0, n_frame_blocks): frame tasks; the rest: one bookkeeping workgroup per tile (they read what the
 // frame tasks read and write elsewhere, so the two roles share a launch)
 template <class R, class SH>
-__global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void mfcc_kernel(const MfccStreamArgs<R> a, const WaveTables<R> t, const int n_frame_blocks) {
+__global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(SH::WPE))) void mfcc_kernel(const MfccStreamArgs<R> a, const WaveTables<R> t, const int n_frame_blocks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x < n_frame_blocks) mfcc_frame_tasks<R, SH>(a, t, smem, (int)blockIdx.x * kFrameWaves, n_frame_blocks * kFrameWaves);
     else mfcc_book_tile<R>(a, (int)blockIdx.x - n_frame_blocks);
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64) void gru_many_bf16_kernel(const GruArgs a, cons
 }
 
 template <class R, class SH>
-__global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void mfcc_offline_kernel(const MfccOfflineArgs<R> a, const WaveTables<R> t) {
+__global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(SH::WPE))) void mfcc_offline_kernel(const MfccOfflineArgs<R> a, const WaveTables<R> t) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     mfcc_offline_frames<R, SH>(a, t, smem);
 }

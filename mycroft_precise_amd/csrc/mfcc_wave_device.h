@@ -203,8 +203,8 @@ __device__ __forceinline__ void wave_scratch_init(R* S, int lane) {
 // Returns coefficient c in the four lanes 4c..4c+3 (c < n_mfcc).  S: this wave's scratch; after the call
 // S[kLogMelOff + f] holds the log-mel energy of filter f.
 // SH: compile-time bounds of the three table-driven loops (the tables are zero-padded up to them on the host)
-struct ShapeStock { static constexpr int MEL = 10, DCT = 5, NP = 8; };      // 20 filters (sonopy 9 / 5 / 8, speechpy 4 / 5 / 7)
-struct ShapeAny { static constexpr int MEL = 16, DCT = 16, NP = 16; };
+struct ShapeStock { static constexpr int MEL = 10, DCT = 5, NP = 8, WPE = 4; };      // 20 filters (sonopy 9 / 5 / 8, speechpy 4 / 5 / 7)
+struct ShapeAny { static constexpr int MEL = 16, DCT = 16, NP = 16, WPE = 3; };       // (its longer table loops want more than 128 registers)
 
 // table entries a lane needs in every frame, read once per wave (the compiler cannot keep an LDS read across the
 // scratch writes of a frame on its own): each saves a dependent LDS round trip per frame
