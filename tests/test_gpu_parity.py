@@ -1024,6 +1024,35 @@ def test_bench_two_ranks_on_one_gpu_shards_streams_correctly():
     assert not np.array_equal(both[:, :512], both[:, 512:])          # the two shards really are different streams
 
 
+def test_random_chunk_sizes_streams_and_call_shapes(stock_weights):
+    """Seeded sweep over what the frame tasks' addressing depends on: chunk length (even: dword sample pairs through
+    bounds-checked buffer loads; odd: the sample-by-sample path; shorter than a frame; longer than a window, which
+    cannot be fused), batch size (ragged tiles, waves with idle lanes) and updates per call (frames that straddle
+    chunk rows of different updates).  Every raw probability and the final features against the oracle."""
+    from mycroft_precise_amd.network_runner import BatchedListener
+    rng = np.random.default_rng(20260924)
+    kinds_all = ['tone_noise', 'tone_noise', 'quiet', 'square', 'zeros']
+    for case in range(14):
+        chunk = int(rng.choice([rng.integers(60, 500), rng.integers(500, 1100), rng.integers(1100, 4000)]))
+        if case % 3 == 0:
+            chunk &= ~1                                            # make sure the aligned fast path gets its share
+        n = int(rng.integers(1, 70))
+        depth = int(rng.choice([1, 1, 2, 5]))
+        n_up = 12 * depth
+        kinds = [kinds_all[int(k)] for k in rng.integers(0, len(kinds_all), n)]
+        pcm = _stream_batch(kinds, n_up, chunk)
+        hip = BatchedListener(stock_weights, n)
+        ref = ol.BatchedOracle(stock_weights, n)
+        if depth > 1:
+            hip.engine.reserve_updates(depth, chunk)
+        for u in range(0, n_up, depth):
+            want = np.stack([ref.update_raw(pcm[u + i]) for i in range(depth)])
+            got = hip.engine.update_many(pcm[u:u + depth]) if depth > 1 else hip.update_raw(pcm[u])[None]
+            assert np.abs(got.astype(np.float64) - want).max() <= GUARD_RAW, (case, chunk, n, depth, u)
+        assert np.abs(hip.engine.get_vectors().astype(np.float64) - ref.mfccs).max() <= TOL_FEAT32, (case, chunk, n, depth)
+        hip.engine.close()
+
+
 def test_waves_owning_more_than_64_streams():
     """mfcc_frame_tasks keeps the counters of 64 streams per wave in registers and refills them batch by batch when a
     wave owns more: with one resident frame workgroup per compute unit (PE_FRAME_WG_PER_CU=1: 1024 waves) that starts
