@@ -203,6 +203,8 @@ def main():
     ap.add_argument('--ring-precision', choices=['f32', 'bf16'], default='f32',
                     help="bf16 = 32-byte bf16 feature rows (BASELINE configs[4]: bf16 MFCC+GRU); needs --gru-precision bf16")
     ap.add_argument('--units', default='20', help="GRU widths, e.g. 20 (stock, default) or 256,256 (BASELINE configs[3])")
+    ap.add_argument('--gru-tiling', type=int, default=-1, help='pe_set_gru_tiling: -1 automatic (default), 0 classic, 1 re-tiled stock width')
+    ap.add_argument('--gru-waves', type=int, default=0, help='pe_set_gru_waves: 0 automatic (default), 1 or 4 waves per tile')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-batched', action='store_true', help='skip the pe_update_many extra (profiling runs: keeps per-kernel means clean)')
     ap.add_argument('--resident-updates', type=int, default=256,
@@ -244,6 +246,10 @@ def main():
     flop_per_window = 2 * sum(29 * 3 * h * (f + h) for f, h in zip((13,) + units[:-1], units)) + 2 * units[-1]
     engine = HipEngine(pr, weights, n_streams=B, device=dev_index, mfcc_precision=args.mfcc_precision,
                        gru_precision=args.gru_precision, ring_precision=args.ring_precision)
+    if args.gru_tiling != -1:
+        engine.set_gru_tiling(args.gru_tiling)
+    if args.gru_waves:
+        engine.set_gru_waves(args.gru_waves)
     first_stream = int(os.environ.get('PE_BENCH_FIRST_STREAM', '0')) + rank * B      # (test aid: shard offset of a solo run)
     pcm = synth_pcm_device(n_res, B, first_stream, device)
     probs = torch.zeros((steps, B), dtype=torch.float32, device=device)

@@ -219,6 +219,14 @@ int pe_set_input_projection(pe_engine* e, int32_t enabled);
  * agrees to ~5e-6; slower, kept for measurement). */
 int pe_set_gru_waves(pe_engine* e, int32_t waves_per_tile);
 
+/* Tiling of the stock-width float32 network (17..20 units, model.py:76-82): 1 = three full MFMA tiles + partial sums
+ * for units 16..19 (csrc/gru_cw_device.h: shortens the four-wave kernel's timestep), 0 = the classic four tiles,
+ * -1 (default) = automatic (re-tiled while the engine has no more tiles than the device has compute units).  Every
+ * kernel shape of ONE tiling agrees bit for bit (pe_update / pe_update_many / pe_predict / pe_evaluate, one or four
+ * waves, fused or not); the two tilings agree to float32 summation order (<= 1e-6 on the probability).  Ignored by
+ * the other networks (other widths, use_delta, bf16, wide, projection rows). */
+int pe_set_gru_tiling(pe_engine* e, int32_t tiling);
+
 /* HIP-event timing of the kernels launched by the last *_device/host update on this engine
  * (milliseconds; measured on the stream the kernels ran on).  Enabled with pe_set_timing(e,1).
  * With a fused launch mfcc_ms is the whole update and gru_ms is 0. */

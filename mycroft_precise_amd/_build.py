@@ -19,7 +19,10 @@ LIB_PATH = os.path.join(HERE, 'libprecise_engine.so')
 SOURCES = ['engine.hip', 'kernels.hip']
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + \
     [os.path.join(os.path.dirname(HERE), 'include', 'precise_engine.h')]
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950's register file is unified): the gate arithmetic
+# reads them with VALU instructions every timestep, and from AGPRs each read is an extra v_accvgpr_read
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+         '-mllvm', '-amdgpu-mfma-vgpr-form=1']
 
 
 def _hipcc():

@@ -75,6 +75,7 @@ EXPORTS = {
     'pe_get_stream_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pe_set_fused': (C.c_int, [C.c_void_p, C.c_int32]),
     'pe_set_gru_waves': (C.c_int, [C.c_void_p, C.c_int32]),
+    'pe_set_gru_tiling': (C.c_int, [C.c_void_p, C.c_int32]),
     'pe_set_input_projection': (C.c_int, [C.c_void_p, C.c_int32]),
     'pe_set_timing': (C.c_int, [C.c_void_p, C.c_int32]),
     'pe_get_last_timing': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -368,6 +369,10 @@ class HipEngine:
 
     def set_gru_waves(self, waves: int):
         self._check(self._lib.pe_set_gru_waves(self._h, int(waves)))
+
+    def set_gru_tiling(self, tiling: int):
+        """-1 automatic, 0 classic four-tile layout, 1 re-tiled stock width (csrc/gru_cw_device.h)."""
+        self._check(self._lib.pe_set_gru_tiling(self._h, int(tiling)))
 
     def set_timing(self, enabled: bool):
         self._check(self._lib.pe_set_timing(self._h, int(bool(enabled))))

@@ -4,6 +4,7 @@
 // beyond building constant tables once per engine.
 #include "../../include/precise_engine.h"
 #include "pe_common.h"
+#include "gru_cw_pack.h"
 
 #include <algorithm>
 #include <cmath>
@@ -49,6 +50,8 @@ struct pe_engine {
     int cur = 0;
     bool fused = true;      // MFCC || GRU in one launch when the chunk size allows it
     int gru_waves = 0;      // 0 = auto (4 waves per tile while tiles <= CUs, else 1), or forced 1 / 4
+    int gru_tiling = -1;    // stock width: -1 = auto (re-tiled shapes while tiles <= CUs), 0 = classic, 1 = re-tiled (gru_cw_device.h)
+    float* cw_blob = nullptr;
     int n_cus = 256;        // compute units of the device (MI355X: 256)
     float* ring = nullptr;
     // input projections x.W + b of every frame beside its feature row (stock-width float32 network, <= kProjMaxTiles
@@ -228,6 +231,10 @@ int pack_gru_weights(pe_engine* e, const pe_gru_layer& L, const float* dense_ker
     if ((rc = dev_upload(e, &e->wr2, wr2))) return rc;
     if ((rc = dev_upload(e, &e->bias, bias))) return rc;
     if ((rc = dev_upload(e, &e->wd, wd))) return rc;
+    if (R == 5 && !delta) {          // the stock width also in its re-tiled form (gru_cw_device.h)
+        const std::vector<float> blob = pack_gru_cw(L.kernel, L.recurrent_kernel, L.bias, F, H);
+        if ((rc = dev_upload(e, &e->cw_blob, blob))) return rc;
+    }
     return PE_OK;
 }
 
@@ -443,6 +450,13 @@ GruArgs gru_args(const pe_engine* e) {
     a.waves_per_tile = e->gru_waves ? e->gru_waves : (e->n_tiles <= e->n_cus ? 4 : 1);      // (16 = DPP kernel: opt-in)
     if (a.waves_per_tile == 16 && !dpp_ok) a.waves_per_tile = 4;
     if (e->prm.use_delta) a.waves_per_tile = 1;          // only the one-wave kernel carries the delta inputs
+    // Stock width: the re-tiled shapes (three full tiles + partial sums; gru_cw_device.h) cut the four-wave kernel's
+    // timestep (14.2 vs 16.3 us per window chain, stand-alone) but cost the one-wave kernel 5 % in the throughput
+    // regime (two-pass MFMAs + reductions: 81.0 vs 77.3 us at 65 536 streams), so an engine takes ONE tiling for all
+    // of its launches -- every shape of a tiling agrees bit for bit -- by its size.
+    const bool cw_ok = e->cw_blob && !a.proj_ring && !a.bf16 && !e->wide && !e->prm.use_delta && a.waves_per_tile != 16;
+    const bool retile = cw_ok && (e->gru_tiling == 1 || (e->gru_tiling < 0 && e->n_tiles <= e->n_cus));
+    a.cw = retile ? e->cw_blob : nullptr;
     return a;
 }
 
@@ -1075,6 +1089,13 @@ int pe_set_gru_waves(pe_engine* e, int32_t waves) {
     if (!e) return PE_ERR_INVALID;
     if (waves != 0 && waves != 1 && waves != 4 && waves != 16) return fail(e, PE_ERR_INVALID, "gru kernel shape must be 0 (auto), 1, 4 (waves per tile) or 16 (lanes per stream)");
     e->gru_waves = waves;
+    return PE_OK;
+}
+
+int pe_set_gru_tiling(pe_engine* e, int32_t tiling) {
+    if (!e) return PE_ERR_INVALID;
+    if (tiling < -1 || tiling > 1) return fail(e, PE_ERR_INVALID, "gru tiling must be -1 (auto), 0 (classic) or 1 (re-tiled)");
+    e->gru_tiling = tiling;
     return PE_OK;
 }
 

@@ -5,6 +5,7 @@
 #include "mfcc_device.h"
 #include "mfcc_wave_device.h"
 #include "gru_device.h"
+#include "gru_cw_device.h"
 #include "gru_dpp_device.h"
 #include "gru_bf16_device.h"
 #include "gru_wide_device.h"
@@ -48,6 +49,26 @@ __global__ __launch_bounds__(256) void gru_many_mw_kernel(const GruArgs a, const
     gru_tile_mw_any<R, PROJ>(b, tile, wave, threadIdx.x & 63, S);
 }
 
+// the same two for the re-tiled stock width (gru_cw_device.h)
+__global__ __launch_bounds__(64) void gru_many_v_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
+    const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
+    GruArgs b = a;
+    b.st_ke = a.st_ke + (size_t)u * n_padded;
+    b.out = a.out + (size_t)u * a.n_streams;
+    b.predict_ke = 0;
+    gru_tile_v<kRing>(b, tile, threadIdx.x);
+}
+__global__ __launch_bounds__(256) void gru_many_cw_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
+    GruArgs b = a;
+    b.st_ke = a.st_ke + (size_t)u * n_padded;
+    b.out = a.out + (size_t)u * a.n_streams;
+    b.predict_ke = 0;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    gru_tile_cw<false>(b, tile, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
+}
+
 template <bool DELTA>
 __global__ __launch_bounds__(64) void gru_many_bf16_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
     const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
@@ -69,6 +90,19 @@ template <int R, int MODE, bool PROJ = false>
 __global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
     gru_tile<R, MODE, PROJ>(a, blockIdx.x, threadIdx.x);
 }
+
+// ---- GRU, stock width re-tiled (gru_cw_device.h): one wave per tile / four waves per tile ------------------------
+template <int MODE>
+__global__ __launch_bounds__(64) void gru_v_kernel(const GruArgs a) {
+    gru_tile_v<MODE>(a, blockIdx.x, threadIdx.x);
+}
+__global__ __launch_bounds__(256) void gru_cw_kernel(const GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    gru_tile_cw<false>(a, blockIdx.x, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
+}
+// the four-wave shape stages the tile's whole ring in LDS and walks at most 32 timesteps of it
+static bool cw_four_waves_ok(const GruArgs& a) { return a.ring_slots == kCwSlots && a.n_features <= kCwSlots; }
 
 // ---- wide / stacked GRU: one workgroup per 16-stream tile, weights streamed from L2 -------------------
 template <int TPW, int MODE, int WAVES>
@@ -187,7 +221,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 // are dispatched first: the long pole); the next n_frame_blocks compute this update's MFCC frames, one frame task
 // per wave; the last n_tiles move the leftover samples and the counters.  MW = true: one GRU workgroup per tile,
 // its four waves share the tile (gru_tile_mw); MW = false: four tiles per GRU workgroup, one wave each.
-template <class R, class SH, int RG, bool MW, bool PROJ>
+template <class R, class SH, int RG, bool MW, bool PROJ, bool CW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
                                                            const int n_gru_blocks, const int n_frame_blocks, const int n_tiles, const int frames_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -195,7 +229,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
     if (b < n_gru_blocks) {
         __builtin_amdgcn_s_setprio(3);          // the network role is the long pole: it wins every issue arbitration
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        if (MW) {
+        if constexpr (CW) {                     // stock width, re-tiled (gru_cw_device.h)
+            static_assert(RG == 5 && !PROJ, "the re-tiled shapes exist for the stock width, without projection rows");
+            if (MW) {
+                gru_tile_cw<false>(g, b, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
+            } else {
+                const int tile = b * 4 + wave;
+                if (tile < n_tiles) gru_tile_v<kRing>(g, tile, threadIdx.x & 63);
+            }
+        } else if (MW) {
             gru_tile_mw_any<RG, PROJ>(g, b, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
         } else {
             const int tile = b * 4 + wave;
@@ -266,6 +308,13 @@ static hipError_t launch_r(const GruArgs& a, int mode, hipStream_t s) {
     const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
     if (tiles == 0) return hipSuccess;
     if constexpr (R == 5) {
+        if (a.cw) {
+            if (mode == kRing && a.waves_per_tile == 4 && cw_four_waves_ok(a)) hipLaunchKernelGGL(gru_cw_kernel, dim3(tiles), dim3(256), kCwLdsBytes, s, a);
+            else if (mode == kRing) hipLaunchKernelGGL(gru_v_kernel<kRing>, dim3(tiles), dim3(64), 0, s, a);
+            else if (mode == kRows) hipLaunchKernelGGL(gru_v_kernel<kRows>, dim3(tiles), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL(gru_v_kernel<kFeats>, dim3(tiles), dim3(64), 0, s, a);
+            return hipGetLastError();
+        }
         if (mode == kRing && a.proj_ring && a.waves_per_tile == 16) {
             hipLaunchKernelGGL(gru_dpp_kernel, dim3(tiles), dim3(256), 0, s, a);
             return hipGetLastError();
@@ -318,6 +367,11 @@ static hipError_t launch_many_r(const GruArgs& a, int n_updates, int n_padded, h
     // update), from 2 per SIMD on the one-wave kernel does (x 16: 12.5 vs 14.0)
     const bool mw = (long long)tiles * n_updates <= 1536 && !a.use_delta;      // (the delta inputs: one-wave kernel only)
     if constexpr (R == 5) {
+        if (a.cw) {
+            if (mw && cw_four_waves_ok(a)) hipLaunchKernelGGL(gru_many_cw_kernel, dim3(tiles * n_updates), dim3(256), kCwLdsBytes, s, a, tiles, n_padded);
+            else hipLaunchKernelGGL(gru_many_v_kernel, dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
+            return hipGetLastError();
+        }
         if (a.proj_ring && a.waves_per_tile == 16) {       // the engine's single updates use the DPP kernel: so does the batch
             hipLaunchKernelGGL(gru_many_dpp_kernel, dim3(tiles * n_updates), dim3(256), 0, s, a, tiles, n_padded);
             return hipGetLastError();
@@ -374,6 +428,17 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
     if (skip == 1) { hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false>), dim3(gru_blocks), dim3(256), lds, s, m, t, g, gru_blocks, 0, 0, 0); return hipGetLastError(); }
     if (skip == 2) gru_blocks = 0;
     const dim3 grid(gru_blocks + fb + tiles);
+    if constexpr (RG == 5) {
+        if (g.cw) {                          // stock width, re-tiled: the four-wave shape wants its LDS (mailboxes + staged ring)
+            if (g.waves_per_tile == 4 && cw_four_waves_ok(g)) {
+                hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false, true>), grid, dim3(256), lds > kCwLdsBytes ? lds : kCwLdsBytes, s, m, t, g, gru_blocks, fb, tiles, frames_first);
+            } else {
+                const int gb = (tiles + 3) / 4;
+                hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, false, true>), dim3(gb + fb + tiles), dim3(256), lds, s, m, t, g, gb, fb, tiles, frames_first);
+            }
+            return hipGetLastError();
+        }
+    }
     if constexpr (RG == 5) {                 // (projection rows exist for the stock width only)
         if (g.proj_ring && g.waves_per_tile == 16) {
             hipLaunchKernelGGL((fused_update_dpp_kernel<R, ShapeStock>), dim3(tiles + fb + tiles), dim3(256), lds, s, m, t, g, tiles, fb, tiles);

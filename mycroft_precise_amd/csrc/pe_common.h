@@ -117,6 +117,10 @@ struct GruArgs {
     const float* bias;      // [NT][4][64]      accumulator init per output register
     const float* wd;        // [R][64]          dense kernel for unit 4*rho+g
     float dense_bias;
+    // stock width (17 <= H <= 20) re-tiled as three full tiles + partial sums for units 16..19 (gru_cw_device.h,
+    // CwPack): non-null = the launchers take the re-tiled shapes (gru_tile_cw / gru_tile_v), which agree with each
+    // other bit for bit and with the classic tiling to float32 summation order
+    const float* cw;
     // the same matrices as Keras stores them, for the DPP kernel (gru_dpp_device.h), which picks its own order
     const float* rk;        // [H][3H] recurrent kernel, gate order z | r | h
     const float* wd_plain;  // [H]     dense kernel
