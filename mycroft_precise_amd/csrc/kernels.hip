@@ -225,10 +225,17 @@ template <class R, class SH, int RG, bool MW, bool PROJ, bool CW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
                                                            const int n_gru_blocks, const int n_frame_blocks, const int n_tiles, const int frames_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = role_block(blockIdx.x, n_gru_blocks, n_frame_blocks, frames_first);
+    const int b = role_block(blockIdx.x, n_gru_blocks, n_frame_blocks, frames_first & 1);
+#ifdef PE_TUNING_SIMD
+    const int simd = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3;      // HW_ID.SIMD_ID
+#endif
     if (b < n_gru_blocks) {
         __builtin_amdgcn_s_setprio(3);          // the network role is the long pole: it wins every issue arbitration
+#ifdef PE_TUNING_SIMD
+        const int wave = (frames_first & 2) ? simd : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#else
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#endif
         if constexpr (CW) {                     // stock width, re-tiled (gru_cw_device.h)
             static_assert(RG == 5 && !PROJ, "the re-tiled shapes exist for the stock width, without projection rows");
             if (MW) {
@@ -244,17 +251,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
             if (tile < n_tiles) gru_tile<RG, kRing, PROJ>(g, tile, threadIdx.x & 63);
         }
     } else if (b < n_gru_blocks + n_frame_blocks) {
+#ifdef PE_TUNING_SIMD
+        if ((frames_first & 4) && simd == 0) return;        // (timing experiment: the frames of these waves are NOT computed)
+#endif
         mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
     } else {
+#ifdef PE_TUNING_SIMD
+        if ((frames_first & 8) && simd == 0) return;
+#endif
         mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
     }
 }
 
 // Workgroups of the frame role: one wave per task while that fits the machine (4 workgroups of 4 waves per compute
 // unit are resident: LDS and a 128-register budget), more tasks per wave beyond.
+// Launch-shape knobs of the tuning harness (tools/): read from the environment ONLY in -DPE_TUNING builds
+// (tools/build_variants.sh); the product library ignores the environment -- two of the knobs skip a role of the
+// launch on purpose and would yield silently wrong results.
 static int env_int(const char* name, int dflt) {
+#ifdef PE_TUNING
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
 }
 static int frame_blocks(long long n_tasks, int n_cus, int per_cu_default = 4) {
     static const int per_cu_env = env_int("PE_FRAME_WG_PER_CU", 0);      // tuning knob (tools/): resident frame workgroups per CU
@@ -417,41 +438,44 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
     // 31.8 / 103.8 us against 35.5 / 109.0 us network-first; the float64 front end gains nothing either way -- its
     // FP64 multiply-adds and the MFMAs do not overlap on a SIMD)
     static const int ff_env = env_int("PE_FUSED_FRAMES_FIRST", -1);
-    const int frames_first = ff_env >= 0 ? ff_env : (g.waves_per_tile != 4 && tiles >= 4 * n_cus);
+    static const int simd_env = env_int("PE_SIMD_FLAGS", 0);     // (PE_TUNING_SIMD builds: 2 = network roles by SIMD id, 4 / 8 = frame / bookkeeping waves leave SIMD 0)
+    const int frames_first = (ff_env >= 0 ? ff_env : (g.waves_per_tile != 4 && tiles >= 4 * n_cus)) | simd_env;
     // resident frame workgroups per compute unit: at one network tile per compute unit the launch lasts as long as the
     // network's dependent chain, and two frame workgroups (two streams per wave, the second one's samples prefetched)
     // disturb that chain less than four (measured, 4096 streams: 20.6 vs 20.9 us in phase, 21.1 vs 22.5 us with
     // desynchronised streams); larger batches want every wave slot
-    const int fb = stream_frame_blocks(m.geo.n_streams, n_cus, tiles <= n_cus ? 2 : frames_first ? 3 : 4);
+    const int fb = stream_frame_blocks(m.geo.n_streams, n_cus, tiles <= n_cus ? 2 : (frames_first & 1) ? 3 : 4);
     int gru_blocks = g.waves_per_tile == 4 ? tiles : (tiles + 3) / 4;
-    static const int skip = env_int("PE_FUSED_SKIP", 0);       // tuning aid: 1 = launch without the MFCC roles, 2 = without the network role
-    if (skip == 1) { hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false>), dim3(gru_blocks), dim3(256), lds, s, m, t, g, gru_blocks, 0, 0, 0); return hipGetLastError(); }
+    static const int skip = env_int("PE_FUSED_SKIP", 0);       // tuning aid (wrong results): 1 = launch without the MFCC roles, 2 = without the network role, 3 = without the bookkeeping role
+    int fb_ = fb, book = tiles;
+    if (skip == 1) { fb_ = 0; book = 0; }
     if (skip == 2) gru_blocks = 0;
-    const dim3 grid(gru_blocks + fb + tiles);
+    if (skip == 3) book = 0;
+    const dim3 grid(gru_blocks + fb_ + book);
     if constexpr (RG == 5) {
         if (g.cw) {                          // stock width, re-tiled: the four-wave shape wants its LDS (mailboxes + staged ring)
             if (g.waves_per_tile == 4 && cw_four_waves_ok(g)) {
-                hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false, true>), grid, dim3(256), lds > kCwLdsBytes ? lds : kCwLdsBytes, s, m, t, g, gru_blocks, fb, tiles, frames_first);
+                hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false, true>), grid, dim3(256), lds > kCwLdsBytes ? lds : kCwLdsBytes, s, m, t, g, gru_blocks, fb_, tiles, frames_first);
             } else {
-                const int gb = (tiles + 3) / 4;
-                hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, false, true>), dim3(gb + fb + tiles), dim3(256), lds, s, m, t, g, gb, fb, tiles, frames_first);
+                const int gb = skip == 2 ? 0 : (tiles + 3) / 4;
+                hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, false, true>), dim3(gb + fb_ + book), dim3(256), lds, s, m, t, g, gb, fb_, tiles, frames_first);
             }
             return hipGetLastError();
         }
     }
     if constexpr (RG == 5) {                 // (projection rows exist for the stock width only)
         if (g.proj_ring && g.waves_per_tile == 16) {
-            hipLaunchKernelGGL((fused_update_dpp_kernel<R, ShapeStock>), dim3(tiles + fb + tiles), dim3(256), lds, s, m, t, g, tiles, fb, tiles);
+            hipLaunchKernelGGL((fused_update_dpp_kernel<R, ShapeStock>), dim3(tiles + fb_ + book), dim3(256), lds, s, m, t, g, tiles, fb_, tiles);
             return hipGetLastError();
         }
         if (g.proj_ring) {
-            if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles, frames_first);
-            else hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles, frames_first);
+            if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb_, tiles, frames_first);
+            else hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb_, tiles, frames_first);
             return hipGetLastError();
         }
     }
-    if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles, frames_first);
-    else hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb, tiles, frames_first);
+    if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb_, tiles, frames_first);
+    else hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb_, tiles, frames_first);
     return hipGetLastError();
 }
 

@@ -7,8 +7,8 @@ C=$ROOT/mycroft_precise_amd/csrc
 mkdir -p $C/build/variants
 while [ $# -ge 2 ]; do
   tag=$1; flags=$2; shift 2
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c $C/engine.hip -o $C/build/variants/engine_$tag.o &
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c $C/kernels.hip -o $C/build/variants/kernels_$tag.o &
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form=1 -DPE_TUNING $flags -c $C/engine.hip -o $C/build/variants/engine_$tag.o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form=1 -DPE_TUNING $flags -c $C/kernels.hip -o $C/build/variants/kernels_$tag.o &
     wait
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $C/build/variants/libprecise_engine_$tag.so $C/build/variants/engine_$tag.o $C/build/variants/kernels_$tag.o
     rm -f $C/build/variants/*_$tag.o; echo built $tag ) &
