@@ -127,26 +127,25 @@ def _cpu_round(cores, streams_per_core, seconds):
             'value': windows / compute}
 
 
-def cpu_baseline(seconds=5.0):
+def cpu_baseline(seconds=4.0, streams_per_core=128):
     """Oracle ("port" of the reference's sonopy + Keras arithmetic, vectorised over streams) on every host core,
-    on a bounded sample of the same workload.  All workers start their timed loops together (barrier after fork /
-    import / synthesis) and run for `seconds`; rate = windows of all workers / the longest worker's compute time.
-    Three batch shapes per core are timed -- 1024 streams (the GPU's own regime; on a many-core host its float64
-    temporaries fall out of cache and the cores queue on memory), 128 and 48 streams (cache-resident) -- and the
-    FASTEST one is reported as the baseline."""
+    on a bounded sample of the same workload: ONE round at the batch shape that measured fastest on this pool's
+    256-core hosts (128 streams per core: cache-resident; 1024 per core -- the GPU's own regime -- runs at half that
+    rate because the float64 temporaries fall out of cache and the cores queue on memory; 48 per core is 15 % slower).
+    All workers start their timed loops together (barrier after fork / synthesis) and run for `seconds`;
+    rate = windows of all workers / the longest worker's compute time.  One core alone is timed first."""
     cores = _affinity_cores()
+    from oracle import listener as _warm_import      # noqa: F401  (imported once here: the forked workers inherit it)
     n_alone, t_alone = _cpu_worker((0, 1024, 1.0, 8, 42, None))                 # one core, nothing else running
-    rounds = [_cpu_round(cores, spc, seconds) for spc in (1024, 128, 48)]
-    best = max(rounds, key=lambda r: r['value'])
-    return {'value': best['value'], 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
-            'compute_s': best['compute_s'], 'wall_s': sum(r['wall_s'] for r in rounds),
-            'per_core': best['value'] / cores, 'single_core_alone': 1024 * n_alone / t_alone,
-            'rounds': rounds,
-            'sample': 'numpy oracle (float64 MFCC + float32 GRU), one process per core on %d cores, timed loops start '
-                      'together after fork/import/synthesis and run %.0f s; %s; one core alone at 1024 streams: %.0f windows/s'
-                      % (cores, seconds, '; '.join('%d streams/core: %d windows in %.1f s = %.0f windows/s'
-                                                    % (r['streams_per_core'], r['windows'], r['compute_s'], r['value']) for r in rounds),
-                         1024 * n_alone / t_alone)}
+    r = _cpu_round(cores, streams_per_core, seconds)
+    return {'value': r['value'], 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
+            'compute_s': r['compute_s'], 'wall_s': r['wall_s'] + t_alone,
+            'per_core': r['value'] / cores, 'single_core_alone': 1024 * n_alone / t_alone,
+            'rounds': [r],
+            'sample': 'numpy oracle (float64 MFCC + float32 GRU), one process per core on %d cores, %d streams per core, timed '
+                      'loops start together after fork/synthesis and run %.0f s: %d windows in %.1f s = %.0f windows/s; '
+                      'one core alone at 1024 streams: %.0f windows/s'
+                      % (cores, streams_per_core, seconds, r['windows'], r['compute_s'], r['value'], 1024 * n_alone / t_alone)}
 
 
 def cpu_baseline_single_stream(seconds=3.0):
@@ -191,6 +190,88 @@ def cpu_baseline_single_stream(seconds=3.0):
                          "oracle.listener.OracleListener (the reference tree is not on this box)")}
 
 
+def wait_for_gpu(event=None):
+    """End of a timed region: spin on an event query (the host sees the last kernel retire within microseconds; a blocking
+    synchronize wakes tens of microseconds late, which a 20-step timed region of 0.4 ms notices), THEN the contract's
+    torch.cuda.synchronize()."""
+    ev = event or torch.cuda.Event()
+    ev.record()
+    while not ev.query():
+        pass
+    torch.cuda.synchronize()
+
+
+def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_precision, ring_precision, steps, warmup, n_res, tol):
+    """One non-headline BASELINE.json configuration on this GPU (N = 1 only, after the headline's timed region): the same
+    step definition, its own roofline object, and a parity spot-check of the timed region's last probabilities against
+    the oracle (the checker: never inside a timed region) on the first 8 streams."""
+    from oracle import listener as oracle_listener
+    weights = synth.make_weights(units=units)
+    stock = units == (20,)
+    flop_per_window = 2 * sum(29 * 3 * h * (f + h) for f, h in zip((13,) + units[:-1], units)) + 2 * units[-1]
+    engine = HipEngine(pr, weights, n_streams=streams, device=dev_index, mfcc_precision=mfcc_precision,
+                       gru_precision=gru_precision, ring_precision=ring_precision)
+    pcm = synth_pcm_device(n_res, streams, 0, device)
+    out = torch.zeros((streams,), dtype=torch.float32, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    chunk_bytes = streams * CHUNK * 2
+
+    def run(first, n):
+        for i in range(n):
+            engine.update_device(pcm.data_ptr() + ((first + i) % n_res) * chunk_bytes, CHUNK, out.data_ptr(), st)
+
+    run(0, warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(warmup, steps)
+    wait_for_gpu()
+    elapsed = time.perf_counter() - t0
+    got = out[:8].cpu().numpy().astype(np.float64)
+    # launch durations: HIP events on the launch stream (bracket of back-to-back updates; the two stages apart)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n_b = min(steps, 100)
+    ev0.record()
+    run(warmup + steps, n_b)
+    ev1.record()
+    ev1.synchronize()
+    update_ms = ev0.elapsed_time(ev1) / n_b
+    engine.set_fused(False)
+    engine.set_timing(True)
+    g_ms = []
+    for i in range(min(steps, 40)):
+        run(warmup + steps + n_b + i, 1)
+        g_ms.append(engine.last_timing()[1])
+    engine.set_timing(False)
+    engine.close()
+    gru_ms = float(np.mean(g_ms))
+    # parity spot-check: the oracle replays the same chunks for streams 0..7
+    host = pcm[:, :8].cpu().numpy()
+    oracle = oracle_listener.BatchedOracle(weights, 8)
+    want = None
+    for i in range(warmup + steps):
+        want = oracle.update_raw(host[i % n_res])
+    err = float(np.abs(np.asarray(want, dtype=np.float64) - got).max())
+    hbm_bound = gru_precision == 'bf16'
+    bytes_per_window = 2048 + 1.28 * 13 * (2 if ring_precision == 'bf16' else 4)
+    if hbm_bound:
+        ach = bytes_per_window * streams / (update_ms * 1e-3) / 1e9
+        roof = {'kernel': 'fused_update_bf16_kernel<%s, ShapeStock>' % ('double' if mfcc_precision == 'f64' else 'float'), 'bound': 'hbm',
+                'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                'avg_launch_ms': update_ms, 'algorithmic': '%.1f B/window x %d windows/launch' % (bytes_per_window, streams)}
+    else:
+        ach = flop_per_window * streams / (gru_ms * 1e-3) / 1e12
+        roof = {'kernel': 'gru_wide_kernel<%d, 1, 4>' % ((units[0] + 63) // 64) if not stock else 'network launch', 'bound': 'mfma',
+                'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                'avg_launch_ms': gru_ms, 'algorithmic': '%d flop/window x %d windows/launch' % (flop_per_window, streams)}
+    return {'name': name, 'value': streams * steps / elapsed, 'unit': 'windows/s', 'ms_per_step': 1e3 * elapsed / steps,
+            'steps': steps, 'warmup': warmup, 'dtype': gru_precision,
+            'config': {'workload': name, 'streams_per_gpu': streams, 'gru': 'H=%s' % ','.join(map(str, units)),
+                       'mfcc_dtype': mfcc_precision, 'feature_rows': ring_precision},
+            'roofline': roof,
+            'parity': {'max_abs_err': err, 'tol': tol, 'streams_checked': 8, 'ok': bool(err <= tol),
+                       'against': 'oracle.listener.BatchedOracle on the same chunks (checker, outside the timed region)'}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -206,6 +287,7 @@ def main():
     ap.add_argument('--gru-tiling', type=int, default=-1, help='pe_set_gru_tiling: -1 automatic (default), 0 classic, 1 re-tiled stock width')
     ap.add_argument('--gru-waves', type=int, default=0, help='pe_set_gru_waves: 0 automatic (default), 1 or 4 waves per tile')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra-configs', action='store_true', help='skip the non-headline BASELINE configurations (wide 256x2, bf16) after the headline')
     ap.add_argument('--no-batched', action='store_true', help='skip the pe_update_many extra (profiling runs: keeps per-kernel means clean)')
     ap.add_argument('--resident-updates', type=int, default=256,
                     help='distinct PCM chunks kept in HBM per stream (reused cyclically beyond that)')
@@ -281,13 +363,18 @@ def main():
     t0 = time.perf_counter()
     run(warmup, steps, True)
     gathered = gather_probabilities(probs.to(comm_device), n_global, dst=0) if world > 1 else probs      # rank 0 only
-    torch.cuda.synchronize()
+    wait_for_gpu()                               # spin until the last kernel has retired, then torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = [1e3 * elapsed / steps]
+    ranks_seen = 1
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        ranks_seen = dist.get_world_size()
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
+        every = [torch.zeros_like(mine) for _ in range(ranks_seen)]
+        dist.all_gather(every, mine)             # every rank's own clock around the same region
+        rank_ms = [1e3 * float(x.item()) / steps for x in every]
+        elapsed = max(float(x.item()) for x in every)
     if rank == 0:
         assert gathered.shape == (steps, n_global)
     finite = bool(torch.isfinite(gathered if rank == 0 else probs).all().item())
@@ -353,6 +440,17 @@ def main():
         except (ValueError, NotImplementedError):
             time_batched = None
 
+    # ---- the other BASELINE.json configurations that fit one GPU (N = 1 only; each a few seconds) -------------------
+    extras = []
+    if world == 1 and rank == 0 and not args.no_extra_configs and stock and args.gru_precision == 'f32' and B == 4096:
+        for cfg in (('configs[3]: wide GRU 256x2 fp32, batch=4096 synthetic 16 kHz streams on 1 MI355X', (256, 256), 4096, 'f64', 'f32', 'f32', 100, 40, 64, 1e-4),
+                    ('configs[4] shard: bf16 MFCC rows + bf16 GRU (f32 front end), batch=8192 streams per MI355X (65536 / 8)', (20,), 8192, 'f32', 'bf16', 'bf16', 200, 40, 64, 1e-2),
+                    ('configs[4] on one GPU: bf16 MFCC rows + bf16 GRU (f32 front end), batch=65536 streams', (20,), 65536, 'f32', 'bf16', 'bf16', 100, 40, 32, 1e-2)):
+            try:
+                extras.append(extra_config(cfg[0], device, dev_index, *cfg[1:]))
+            except Exception as ex:                                  # noqa: BLE001  (an extra must not cost the headline line)
+                extras.append({'name': cfg[0], 'error': repr(ex)})
+
     def pmc_traffic(kernel):
         """HBM bytes per launch from the committed rocprofv3 PMC summary (bench.py cannot collect PMC
         counters itself); None when the profile is missing or was taken at another batch size."""
@@ -378,9 +476,11 @@ def main():
         mfma_peak = MFMA_F32_PEAK_TFLOPS if args.gru_precision == 'f32' else MFMA_BF16_PEAK_TFLOPS
         four_waves = (B + 15) // 16 <= torch.cuda.get_device_properties(device).multi_processor_count   # engine.hip: gru_args
         mfcc_kernel = 'mfcc_kernel<%s, ShapeStock>' % mfcc_name
-        fused_name = ('fused_update_kernel<%s, ShapeStock, 5, %s, false>' % (mfcc_name, 'true' if four_waves else 'false')
+        retiled = four_waves if args.gru_tiling < 0 else bool(args.gru_tiling)       # engine.hip: gru_args (stock width only)
+        fused_name = ('fused_update_kernel<%s, ShapeStock, 5, %s, false, %s>' % (mfcc_name, 'true' if four_waves else 'false', 'true' if retiled else 'false')
                       if args.gru_precision == 'f32' else 'fused_update_bf16_kernel<%s, ShapeStock>' % mfcc_name)
-        gru_name = (('gru_mw_kernel<5, false>' if four_waves else 'gru_small_kernel<5, 1, false>') if args.gru_precision == 'f32'
+        gru_name = ((('gru_cw_kernel' if retiled else 'gru_mw_kernel<5, false>') if four_waves else
+                     ('gru_v_kernel<1>' if retiled else 'gru_small_kernel<5, 1, false>')) if args.gru_precision == 'f32'
                     else 'gru_bf16_kernel<1>')
         if not stock:
             fused_name = '%s + gru_wide_kernel<%d, 1, 4>' % (mfcc_kernel, (units[0] + 63) // 64)
@@ -408,6 +508,8 @@ def main():
                        'parallelism': 'streams sharded over %d rank(s), final RCCL gather of probabilities to rank 0' % world},
             'realtime_streams': value / REALTIME_WINDOWS_PER_S,
             'outputs_finite': finite,
+            # what the communicator reported and every rank's own clock around the timed region (value uses the max)
+            'ranks_seen': ranks_seen, 'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms)},
             # dominant kernel of the timed region: the fused launch (GRU role is its long pole)
             'roofline': ({'kernel': fused_name, 'bound': 'hbm', 'achieved': gbs_w(fused_ms), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                           'frac': gbs_w(fused_ms) / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': fused_ms,
@@ -421,7 +523,7 @@ def main():
                           'algorithmic': '%d flop/window x %d windows/launch' % (flop_per_window, B)}),
             'roofline_gru': {'kernel': gru_name, 'bound': 'mfma', 'achieved': tflops(gru_ms),
                              'peak': mfma_peak, 'unit': 'TFLOP/s',
-                             'frac': tflops(gru_ms) / mfma_peak, 'traffic': pmc_traffic('gru_mw_kernel') if (args.gru_precision == 'f32' and stock and four_waves) else None,
+                             'frac': tflops(gru_ms) / mfma_peak, 'traffic': pmc_traffic('gru_cw_kernel' if retiled else 'gru_mw_kernel') if (args.gru_precision == 'f32' and stock and four_waves) else None,
                              'avg_launch_ms': gru_ms},
             'roofline_mfcc': {'kernel': mfcc_kernel, 'bound': 'hbm',
                               'achieved': gbs_w(mfcc_ms), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -439,6 +541,8 @@ def main():
                                       'roofline_mfcc_frac': line['roofline_mfcc']['achieved'] / mp['hbm_read_gbs']}
         except (OSError, KeyError, ValueError):
             pass
+        if extras:
+            line['extra_configs'] = extras
         if time_batched is not None:
             line['time_batched'] = time_batched
         if cpu is not None:

@@ -414,8 +414,9 @@ void flip_state(pe_engine* e) {
 
 // MFCC alone: consumes state[cur], publishes state[cur ^ 1], then flips.
 int launch_mfcc(pe_engine* e, const int16_t* pcm_dev, int chunk, hipStream_t s) {
-    if (max_frames_per_call(e, chunk) > kMaxFrameRows)
-        return fail(e, PE_ERR_INVALID, "a call may complete at most %d frames per stream (chunk of %d samples)", kMaxFrameRows, chunk);
+    // (no cap on the frames ONE update may complete: Listener.update takes a chunk of any length,
+    //  network_runner.py:125-146; the frame tasks skip every row that the ring would overwrite again -- v_first in
+    //  mfcc_frame_tasks -- so a long chunk costs its last ring_slots frames plus a scalar walk over the row indices)
     if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_mfcc_f64(mfcc_args<double>(e, pcm_dev, chunk), tables<double>(e), e->n_cus, s));
     else PE_HIP(e, launch_mfcc_f32(mfcc_args<float>(e, pcm_dev, chunk), tables<float>(e), e->n_cus, s));
     flip_state(e);
@@ -501,8 +502,12 @@ int check_chunk(pe_engine* e, const void* pcm, int chunk) {
 // True when no frame computed by an update of `chunk` samples can become visible in that same
 // update (it needs window - frame_len more samples), so the network does not depend on it.
 bool can_fuse(const pe_engine* e, int chunk) {
-    // (the fused kernels exist for the stock table shape: filterbanks whose runs need the wide loop bounds take two launches)
-    return e->fused && !e->wide && e->table_layout.mel_pad == 10 && chunk <= emit_window(e->prm) - frame_len_of(e->prm);
+    // (the fused kernels exist for the stock table shape: filterbanks whose runs need the wide loop bounds take two launches;
+    //  so do networks of 21..32 units on the one-wave kernel: their register-resident weights do not fit beside the
+    //  frame role's 128-register budget -- fused, that shape spilled 96-240 bytes per lane into the time loop)
+    if (!(e->fused && !e->wide && e->table_layout.mel_pad == 10 && chunk <= emit_window(e->prm) - frame_len_of(e->prm))) return false;
+    if (e->prm.gru_precision == 0 && gru_small_regs(e->units) >= 6 && gru_args(e).waves_per_tile != 4) return false;
+    return true;
 }
 
 int do_update(pe_engine* e, const int16_t* pcm_dev, int chunk, float* raw_out_dev, float* feats_out_dev,

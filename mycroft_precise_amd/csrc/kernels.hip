@@ -225,17 +225,10 @@ template <class R, class SH, int RG, bool MW, bool PROJ, bool CW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
                                                            const int n_gru_blocks, const int n_frame_blocks, const int n_tiles, const int frames_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = role_block(blockIdx.x, n_gru_blocks, n_frame_blocks, frames_first & 1);
-#ifdef PE_TUNING_SIMD
-    const int simd = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3;      // HW_ID.SIMD_ID
-#endif
+    const int b = role_block(blockIdx.x, n_gru_blocks, n_frame_blocks, frames_first);
     if (b < n_gru_blocks) {
         __builtin_amdgcn_s_setprio(3);          // the network role is the long pole: it wins every issue arbitration
-#ifdef PE_TUNING_SIMD
-        const int wave = (frames_first & 2) ? simd : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#else
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#endif
         if constexpr (CW) {                     // stock width, re-tiled (gru_cw_device.h)
             static_assert(RG == 5 && !PROJ, "the re-tiled shapes exist for the stock width, without projection rows");
             if (MW) {
@@ -251,14 +244,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
             if (tile < n_tiles) gru_tile<RG, kRing, PROJ>(g, tile, threadIdx.x & 63);
         }
     } else if (b < n_gru_blocks + n_frame_blocks) {
-#ifdef PE_TUNING_SIMD
-        if ((frames_first & 4) && simd == 0) return;        // (timing experiment: the frames of these waves are NOT computed)
-#endif
         mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
     } else {
-#ifdef PE_TUNING_SIMD
-        if ((frames_first & 8) && simd == 0) return;
-#endif
         mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
     }
 }
@@ -438,13 +425,12 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
     // 31.8 / 103.8 us against 35.5 / 109.0 us network-first; the float64 front end gains nothing either way -- its
     // FP64 multiply-adds and the MFMAs do not overlap on a SIMD)
     static const int ff_env = env_int("PE_FUSED_FRAMES_FIRST", -1);
-    static const int simd_env = env_int("PE_SIMD_FLAGS", 0);     // (PE_TUNING_SIMD builds: 2 = network roles by SIMD id, 4 / 8 = frame / bookkeeping waves leave SIMD 0)
-    const int frames_first = (ff_env >= 0 ? ff_env : (g.waves_per_tile != 4 && tiles >= 4 * n_cus)) | simd_env;
+    const int frames_first = ff_env >= 0 ? ff_env : (g.waves_per_tile != 4 && tiles >= 4 * n_cus);
     // resident frame workgroups per compute unit: at one network tile per compute unit the launch lasts as long as the
     // network's dependent chain, and two frame workgroups (two streams per wave, the second one's samples prefetched)
     // disturb that chain less than four (measured, 4096 streams: 20.6 vs 20.9 us in phase, 21.1 vs 22.5 us with
     // desynchronised streams); larger batches want every wave slot
-    const int fb = stream_frame_blocks(m.geo.n_streams, n_cus, tiles <= n_cus ? 2 : (frames_first & 1) ? 3 : 4);
+    const int fb = stream_frame_blocks(m.geo.n_streams, n_cus, tiles <= n_cus ? 2 : frames_first ? 3 : 4);
     int gru_blocks = g.waves_per_tile == 4 ? tiles : (tiles + 3) / 4;
     static const int skip = env_int("PE_FUSED_SKIP", 0);       // tuning aid (wrong results): 1 = launch without the MFCC roles, 2 = without the network role, 3 = without the bookkeeping role
     int fb_ = fb, book = tiles;
@@ -475,7 +461,8 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
         }
     }
     if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb_, tiles, frames_first);
-    else hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb_, tiles, frames_first);
+    else if constexpr (RG <= 5) hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, false>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb_, tiles, frames_first);
+    else return hipErrorInvalidValue;        // (21..32 units on the one-wave kernel: engine.hip takes two launches, can_fuse)
     return hipGetLastError();
 }
 

@@ -27,6 +27,17 @@ TOL_BF16 = 1e-2         # BASELINE configs[4]
 GUARD_RAW = 2e-5        # regression guard: what the kernels actually achieve, with margin
 TOL_FEAT32 = 2e-5       # float32 rounding of |feature| <= 40
 TOL_DECODE = 2e-3       # one LUT bin of ThresholdDecoder (step function of logit(raw))
+# ThresholdDecoder.decode is a step function of logit(raw) (6400-entry LUT): a raw output that differs from the
+# reference's in its last bits can land in the neighbouring bin.  The device decoder itself is exact (fixture grid,
+# below); what is counted here is how many of the fixture's decoded values differ AT ALL because the raw output did.
+# Measured on MI355X with the shipped kernels: none.  A kernel change that moves this number is a numerics change.
+DECODE_FLIPS = {'chunk2048': 0, 'update': 0, 'engine': 0}
+
+
+def _decode_flips(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    assert np.abs(got - want).max() <= TOL_DECODE        # never more than one bin
+    return int(np.count_nonzero(got != want))
 
 
 @pytest.fixture(scope='module')
@@ -48,21 +59,23 @@ def test_listener_matches_reference_listener_chunk2048(model_file):
     """Drop-in Listener(model).update(bytes) vs the reference's Listener on the same PCM."""
     from mycroft_precise_amd.network_runner import Listener
     g = golden('listener_chunk2048.npz')
+    flips = 0
     for i in range(len(g['streams'])):
         lis = Listener(model_file, 2048)
         data = g['pcm'][i].tobytes()
-        worst_raw = worst_dec = 0.0
+        worst_raw = 0.0
+        decs = []
         for u, off in enumerate(range(0, len(data), 2048)):
             raw = lis.update_raw(data[off:off + 2048])
             worst_raw = max(worst_raw, abs(raw - float(g['raw'][i][u])))
-            dec = lis.threshold_decoder.decode(raw)
-            worst_dec = max(worst_dec, abs(dec - float(g['decoded'][i][u])))
+            decs.append(lis.threshold_decoder.decode(raw))
             assert len(lis.window_audio) == g['leftover'][i][u]
             if u == 7:
                 assert np.abs(lis.mfccs - g['ring_u7'][i]).max() <= TOL_FEAT32
         assert np.abs(lis.mfccs - g['ring_last'][i]).max() <= TOL_FEAT32
         assert worst_raw <= TOL_RAW and worst_raw <= GUARD_RAW, (str(g['kinds'][i]), worst_raw)
-        assert worst_dec <= TOL_DECODE, (str(g['kinds'][i]), worst_dec)
+        flips += _decode_flips(decs, g['decoded'][i])
+    assert flips == DECODE_FLIPS['chunk2048'], flips
 
 
 @pytest.mark.parametrize('cb', [1000, 3200, 6400, 20000, 96000])
@@ -77,6 +90,24 @@ def test_listener_matches_reference_odd_chunk_sizes(model_file, cb):
     assert len(lis.window_audio) == g['leftover_%d' % cb][-1]
 
 
+def test_listener_update_takes_a_whole_long_recording(model_file, stock_weights):
+    """Listener.update accepts a chunk of any length (network_runner.py:125-146): more than a minute of audio in ONE
+    call (1 375 frames: the engine computes the last ring's worth and skips the rest), then ordinary chunks."""
+    from mycroft_precise_amd.network_runner import Listener
+    n_long = 1_100_000
+    pcm = synth.stream_pcm(5, n_long + 8 * 1024)
+    lis = Listener(model_file, -1)
+    ref = ol.OracleListener(stock_weights)
+    first = pcm[:n_long].tobytes()
+    assert abs(lis.update_raw(first) - ref.update_raw(first)) <= GUARD_RAW
+    assert np.abs(lis.mfccs - ref.mfccs).max() <= TOL_FEAT32
+    assert len(lis.window_audio) == len(ref.window_audio)
+    for u in range(8):
+        chunk = pcm[n_long + u * 1024:n_long + (u + 1) * 1024].tobytes()
+        assert abs(lis.update_raw(chunk) - ref.update_raw(chunk)) <= GUARD_RAW, u
+    assert np.abs(lis.mfccs - ref.mfccs).max() <= TOL_FEAT32
+
+
 def test_listener_update_decodes_like_reference(model_file):
     from mycroft_precise_amd.network_runner import Listener
     g = golden('listener_chunk2048.npz')
@@ -84,7 +115,7 @@ def test_listener_update_decodes_like_reference(model_file):
     data = g['pcm'][0].tobytes()
     decs = [lis.update(data[off:off + 2048]) for off in range(0, len(data), 2048)]
     assert all(isinstance(d, float) for d in decs)
-    assert np.abs(np.array(decs) - g['decoded'][0]).max() <= TOL_DECODE
+    assert _decode_flips(decs, g['decoded'][0]) == DECODE_FLIPS['update']
 
 
 def test_listener_error_conventions(model_file):
@@ -1078,4 +1109,4 @@ def test_precise_engine_subprocess_protocol(model_file, stock_weights):
         got = [eng.get_prediction(data[off:off + 2048]) for off in range(0, 2048 * 12, 2048)]
     finally:
         eng.stop()
-    assert np.abs(np.array(got) - g['decoded'][0][:12]).max() <= TOL_DECODE
+    assert _decode_flips(got, g['decoded'][0][:12]) == DECODE_FLIPS['engine']
