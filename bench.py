@@ -190,14 +190,10 @@ def cpu_baseline_single_stream(seconds=3.0):
                          "oracle.listener.OracleListener (the reference tree is not on this box)")}
 
 
-def wait_for_gpu(event=None):
-    """End of a timed region: spin on an event query (the host sees the last kernel retire within microseconds; a blocking
-    synchronize wakes tens of microseconds late, which a 20-step timed region of 0.4 ms notices), THEN the contract's
-    torch.cuda.synchronize()."""
-    ev = event or torch.cuda.Event()
-    ev.record()
-    while not ev.query():
-        pass
+def wait_for_gpu():
+    """End of a timed region: the contract's torch.cuda.synchronize().  (Measured, tools/gpu_host_overhead.py: a 20-step
+    region costs the host ~20 us more than the GPU's own first-start-to-last-end time either way; spinning on an event
+    query first and synchronizing afterwards costs 15 us MORE than synchronizing alone.)"""
     torch.cuda.synchronize()
 
 
@@ -363,7 +359,7 @@ def main():
     t0 = time.perf_counter()
     run(warmup, steps, True)
     gathered = gather_probabilities(probs.to(comm_device), n_global, dst=0) if world > 1 else probs      # rank 0 only
-    wait_for_gpu()                               # spin until the last kernel has retired, then torch.cuda.synchronize()
+    wait_for_gpu()
     barrier()
     elapsed = time.perf_counter() - t0
     rank_ms = [1e3 * elapsed / steps]

@@ -330,6 +330,9 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
             h[4] = *(lds_vfloat)(L1 + CwBox::SH1);
             h[0] = h4[0]; h[1] = h4[1]; h[2] = h4[2]; h[3] = h4[3];
             if (__builtin_amdgcn_readfirstlane(tag) == t) break;
+#ifdef PE_POLL_SLEEP
+            __builtin_amdgcn_s_sleep(PE_POLL_SLEEP);
+#endif
         }
     };
     auto partials = [&](const float (&wf)[4][5], const float (&wv)[5], const float (&v)[5]) -> f32x4 {

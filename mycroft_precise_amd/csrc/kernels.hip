@@ -227,8 +227,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = role_block(blockIdx.x, n_gru_blocks, n_frame_blocks, frames_first);
     if (b < n_gru_blocks) {
-        __builtin_amdgcn_s_setprio(3);          // the network role is the long pole: it wins every issue arbitration
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if defined(PE_PRIO_R)
+        if (wave == 0) __builtin_amdgcn_s_setprio(PE_PRIO_R); else __builtin_amdgcn_s_setprio(PE_PRIO_H);
+#else
+        __builtin_amdgcn_s_setprio(3);          // the network role is the long pole: it wins every issue arbitration
+#endif
         if constexpr (CW) {                     // stock width, re-tiled (gru_cw_device.h)
             static_assert(RG == 5 && !PROJ, "the re-tiled shapes exist for the stock width, without projection rows");
             if (MW) {
@@ -272,13 +276,14 @@ static int frame_blocks(long long n_tasks, int n_cus, int per_cu_default = 4) {
     return (int)(need < cap ? (need < 1 ? 1 : need) : cap);
 }
 
-// frame workgroups of a streaming launch: every wave owns a contiguous run of streams (mfcc_frame_tasks), as many waves
-// as the resident cap allows, the runs as even as they can be
+// frame workgroups of a streaming launch: every wave owns a contiguous run of (stream, row parity) slots
+// (mfcc_frame_tasks), as many waves as the resident cap allows, the runs as even as they can be
 static int stream_frame_blocks(int n_streams, int n_cus, int per_cu_default = 4) {
-    const int cap_waves = frame_blocks((long long)n_streams, n_cus, per_cu_default) * kFrameWaves;
-    const int per_wave = (n_streams + cap_waves - 1) / cap_waves;
-    const int waves = (n_streams + per_wave - 1) / per_wave;
-    return (waves + kFrameWaves - 1) / kFrameWaves;
+    const long long slots = 2LL * n_streams;
+    const long long cap_waves = (long long)frame_blocks(slots, n_cus, per_cu_default) * kFrameWaves;
+    const long long per_wave = (slots + cap_waves - 1) / cap_waves;
+    const long long waves = (slots + per_wave - 1) / per_wave;
+    return (int)((waves + kFrameWaves - 1) / kFrameWaves);
 }
 
 template <class R>

@@ -410,14 +410,20 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
     // may cross at most one chunk boundary (always true for a single update: its samples are carry ++ one chunk)
     const bool pairs = a.pcm_pairs_ok && ((hop | C | flen) & 1) == 0 && (C >= flen || U == 1);
 
-    // ---- task stream of this wave: a contiguous run of streams [s_begin, s_end), all of its due frames, frame row by
-    //      frame row.  The counters of up to 64 of those streams sit in two registers (lane i <-> stream base + i), how
-    //      many frames each completes is computed per lane, and the due (row, stream) pairs of a row are the set bits
-    //      of one ballot: picking the next task costs a few scalar instructions and no memory access ----------------
+    // ---- task stream of this wave: a contiguous run of (stream, row parity) SLOTS sigma = 2 s + (kb & 1), i.e. of a
+    //      stream either all of its due frame rows or only the even / odd ones -- an update in which every stream
+    //      completes two frames then spreads evenly over 1.5 x as many waves as there are streams (lock-step batches:
+    //      22.4 -> us for the two-frame updates at 4096 streams), and large batches still get whole streams.  The
+    //      counters of up to 64 streams sit in two registers (lane i <-> stream base + i), how many frames each
+    //      completes is computed per lane, and the due (row, stream) pairs of a row are the set bits of one ballot:
+    //      picking the next task costs a few scalar instructions and no memory access ------------------------------
     const int n_waves = task_stride;
-    const int per_wave = (geo.n_streams + n_waves - 1) / n_waves;
-    const int s_begin = (first_task + wave) * per_wave;
-    const int s_end = s_begin + per_wave < geo.n_streams ? s_begin + per_wave : geo.n_streams;
+    const long long n_slots = 2LL * geo.n_streams;
+    const int per_wave = (int)((n_slots + n_waves - 1) / n_waves);
+    const long long sg_begin = (long long)(first_task + wave) * per_wave;
+    const long long sg_end = sg_begin + per_wave < n_slots ? sg_begin + per_wave : n_slots;
+    const int s_begin = (int)(sg_begin >> 1);
+    const int s_end = sg_end > sg_begin ? (int)((sg_end + 1) >> 1) : s_begin;
     int base = s_begin, kb_next = -1;
     int vq = 0, vkc = 0, v_first = 0, v_nnew = 0;           // per lane: counters, first frame row worth computing, frames completed
     unsigned long long due = 0;
@@ -438,7 +444,8 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
         while (due == 0) {
             ++kb_next;
             if (kb_next >= n_kb) return false;
-            due = __ballot(kb_next >= v_first && kb_next < v_nnew);
+            const long long sg = 2LL * (base + lane) + (kb_next & 1);
+            due = __ballot(kb_next >= v_first && kb_next < v_nnew && sg >= sg_begin && sg < sg_end);
         }
         const int i = __builtin_ctzll(due);
         due &= due - 1;
