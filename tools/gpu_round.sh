@@ -17,9 +17,21 @@ echo "== rocprofv3 kernel trace"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/${tag}_prof
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_prof -o trace -- python $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/${tag}_bench_prof.json 2> $OUT/${tag}_rocprof.err
-for f in $(find $OUT/${tag}_prof -name "*kernel_stats.csv"); do grep -E "Name|pe::" $f | cut -c1-220 > $OUT/${tag}_kernel_stats.csv; cat $OUT/${tag}_kernel_stats.csv; done
+for f in $(find $OUT/${tag}_prof -name "*kernel_stats.csv"); do
+  python3 - "$f" > $OUT/${tag}_kernel_stats.csv <<'PY'
+import csv, re, sys
+rows = list(csv.reader(open(sys.argv[1])))
+print(','.join(rows[0]))
+for r in rows[1:]:
+    if 'pe::' not in r[0]:
+        continue
+    name = re.sub(r'\(pe::.*$', '', r[0]).replace('void ', '')        # kernel name with its template arguments, without the parameter list
+    print(','.join(['"%s"' % name] + r[1:]))
+PY
+  cat $OUT/${tag}_kernel_stats.csv
+done
 echo "== PMC passes"
-ARGS="--no-cpu-baseline --no-batched --steps 40 --warmup 40 $*"
+ARGS="--no-cpu-baseline --no-batched --no-extra-configs --steps 40 --warmup 40 $*"
 i=0
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
