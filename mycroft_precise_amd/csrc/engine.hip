@@ -5,6 +5,7 @@
 #include "../../include/precise_engine.h"
 #include "pe_common.h"
 #include "gru_cw_pack.h"
+#include "mfcc_general_device.h"
 
 #include <algorithm>
 #include <cmath>
@@ -50,6 +51,11 @@ struct pe_engine {
     int cur = 0;
     bool fused = true;      // MFCC || GRU in one launch when the chunk size allows it
     int gru_waves = 0;      // 0 = auto (4 waves per tile while tiles <= CUs, else 1), or forced 1 / 4
+    // general front end (mfcc_general_device.h): any n_fft / n_filt / n_mfcc the stock-shape wave kernel has no tables for
+    bool general = false;
+    int row_floats = kRowFloats;   // floats per feature row: 32 when a frame has 17..32 coefficients
+    int carry_cap = kCarryCap;     // int16 samples of leftover PCM kept per stream (>= frame length)
+    GeneralTables gtab{};
     int gru_tiling = -1;    // stock width: -1 = auto (re-tiled shapes while tiles <= CUs), 0 = classic, 1 = re-tiled (gru_cw_device.h)
     float* cw_blob = nullptr;
     int n_cus = 256;        // compute units of the device (MI355X: 256)
@@ -151,7 +157,7 @@ int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 // floats of HBM behind the feature ring: 16 floats per row, or 16 bf16 (half of it) with ring_precision = 1
 size_t ring_floats(const pe_engine* e) {
     const size_t rows = (size_t)e->n_tiles * e->ring_slots * kTileStreams;
-    return e->prm.ring_precision == 1 ? rows * kRowFloats / 2 : rows * kRowFloats;
+    return e->prm.ring_precision == 1 ? rows * kRowFloats / 2 : rows * (size_t)e->row_floats;
 }
 
 
@@ -164,12 +170,57 @@ int build_tables(pe_engine* e, const double* mel_filters) {
     return dev_upload(e, &e->table_blob, blob);
 }
 
+// Tables of the general front end: twiddles of the packed real FFT, the filterbank as CSR, the DCT-II (ortho) matrix.
+template <class R>
+int build_general_tables(pe_engine* e, const double* mel_filters) {
+    const int N = e->prm.n_fft, M = N / 2, bins = M + 1, nf = e->prm.n_filt, nc = e->prm.n_mfcc;
+    const long double PI = 3.14159265358979323846264338327950288L;
+    std::vector<R> tw((size_t)M), wn((size_t)(M / 2 + 1) * 2);       // tw: M / 2 complex = M reals
+    for (int k = 0; k < M / 2; ++k) {
+        tw[2 * k] = (R)cosl(-2.0L * PI * k / M);
+        tw[2 * k + 1] = (R)sinl(-2.0L * PI * k / M);
+    }
+    for (int k = 0; k <= M / 2; ++k) {
+        wn[2 * k] = (R)cosl(-2.0L * PI * k / N);
+        wn[2 * k + 1] = (R)sinl(-2.0L * PI * k / N);
+    }
+    std::vector<int> ptr(nf + 1, 0), bin;
+    std::vector<R> w;
+    for (int f = 0; f < nf; ++f) {
+        for (int k = 0; k < bins; ++k) {
+            const double v = mel_filters[(size_t)f * bins + k];
+            if (v != 0.0) { bin.push_back(k); w.push_back((R)v); }
+        }
+        ptr[f + 1] = (int)bin.size();
+    }
+    if (bin.empty()) { bin.push_back(0); w.push_back(R(0)); }
+    std::vector<R> dct((size_t)nc * nf);
+    for (int c = 0; c < nc; ++c)           // scipy.fftpack.dct(type 2, norm='ortho'): y[c] = 2 f(c) sum_n x[n] cos(pi c (2 n + 1) / (2 N))
+        for (int f = 0; f < nf; ++f) {
+            const long double scale = c == 0 ? sqrtl(1.0L / (4.0L * nf)) : sqrtl(1.0L / (2.0L * nf));
+            dct[(size_t)c * nf + f] = (R)(2.0L * scale * cosl(PI * c * (2 * f + 1) / (2.0L * nf)));
+        }
+    R* d_tw = nullptr; R* d_wn = nullptr; R* d_w = nullptr; R* d_dct = nullptr; int* d_ptr = nullptr; int* d_bin = nullptr;
+    int rc;
+    if ((rc = dev_upload(e, &d_tw, tw))) return rc;
+    if ((rc = dev_upload(e, &d_wn, wn))) return rc;
+    if ((rc = dev_upload(e, &d_w, w))) return rc;
+    if ((rc = dev_upload(e, &d_dct, dct))) return rc;
+    if ((rc = dev_upload(e, &d_ptr, ptr))) return rc;
+    if ((rc = dev_upload(e, &d_bin, bin))) return rc;
+    int log2m = 0;
+    while ((1 << log2m) < M) ++log2m;
+    e->gtab = GeneralTables{d_tw, d_wn, d_ptr, d_bin, d_w, d_dct, N, log2m, nf, nc, e->prm.vectorizer == 3 ? 1 : 0};
+    return PE_OK;
+}
+
 // Arrange the Keras matrices as MFMA A-operands (see the layout comment in gru_kernels.hip).
 int pack_gru_weights(pe_engine* e, const pe_gru_layer& L, const float* dense_kernel) {
     const int H = L.units, F = e->n_in;          // F = base features; with use_delta the kernel has 2F rows
     const bool delta = e->prm.use_delta != 0;
     const int R = gru_small_regs(H), NT = gru_small_tiles(H);
-    std::vector<float> wx((size_t)NT * 4 * 64, 0.f), wxd((size_t)NT * 4 * 64, 0.f), wr1((size_t)NT * R * 64, 0.f), wr2((size_t)NT * R * 64, 0.f);
+    const int KX = e->row_floats / kRowFloats;      // 16-feature groups of a feature row (2: 17..32 coefficients per frame)
+    std::vector<float> wx((size_t)KX * NT * 4 * 64, 0.f), wxd((size_t)NT * 4 * 64, 0.f), wr1((size_t)NT * R * 64, 0.f), wr2((size_t)NT * R * 64, 0.f);
     std::vector<float> bias((size_t)NT * 4 * 64, 0.f), wd((size_t)R * 64, 0.f);
     for (int tile = 0; tile < NT; ++tile)
         for (int lane = 0; lane < 64; ++lane) {
@@ -180,11 +231,12 @@ int pack_gru_weights(pe_engine* e, const pe_gru_layer& L, const float* dense_ker
                 const int gate = slot / R, rho = slot % R, u = 4 * rho + gout;
                 if (slot < 3 * R && u < H) {
                     const int col = gate * H + u;
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const int phi = 4 * g + kk;
-                        if (phi < F) wx[((size_t)tile * 4 + kk) * 64 + lane] = L.kernel[(size_t)phi * 3 * H + col];
-                        if (phi < F && delta) wxd[((size_t)tile * 4 + kk) * 64 + lane] = L.kernel[(size_t)(F + phi) * 3 * H + col];
-                    }
+                    for (int kx = 0; kx < KX; ++kx)
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const int phi = 16 * kx + 4 * g + kk;
+                            if (phi < F) wx[(((size_t)kx * NT + tile) * 4 + kk) * 64 + lane] = L.kernel[(size_t)phi * 3 * H + col];
+                            if (kx == 0 && phi < F && delta) wxd[((size_t)tile * 4 + kk) * 64 + lane] = L.kernel[(size_t)(F + phi) * 3 * H + col];
+                        }
                     for (int rs = 0; rs < R; ++rs) {
                         const int usrc = 4 * rs + g;
                         if (usrc >= H) continue;
@@ -206,7 +258,7 @@ int pack_gru_weights(pe_engine* e, const pe_gru_layer& L, const float* dense_ker
         }
     // input-projection rows (mfcc_wave_device.h epilogue): element o = 16 g + 4 tile + q of a row is accumulator q of
     // output tile `tile` in lane group g, i.e. slot 4 tile + q, unit 4 rho + g
-    if (NT <= 4 && !delta) {
+    if (NT <= 4 && !delta && KX == 1) {
         e->proj_w_host.assign((size_t)F * kProjRow, 0.f);
         e->proj_b_host.assign(kProjRow, 0.f);
         for (int o = 0; o < kProjRow; ++o) {
@@ -231,7 +283,7 @@ int pack_gru_weights(pe_engine* e, const pe_gru_layer& L, const float* dense_ker
     if ((rc = dev_upload(e, &e->wr2, wr2))) return rc;
     if ((rc = dev_upload(e, &e->bias, bias))) return rc;
     if ((rc = dev_upload(e, &e->wd, wd))) return rc;
-    if (R == 5 && !delta) {          // the stock width also in its re-tiled form (gru_cw_device.h)
+    if (R == 5 && !delta && KX == 1) {          // the stock width also in its re-tiled form (gru_cw_device.h)
         const std::vector<float> blob = pack_gru_cw(L.kernel, L.recurrent_kernel, L.bias, F, H);
         if ((rc = dev_upload(e, &e->cw_blob, blob))) return rc;
     }
@@ -349,7 +401,7 @@ int pack_gru_weights_wide(pe_engine* e, const pe_weights* w) {
 // full window), plus one hop for the legacy speechpy front end, whose stack_frames returns
 // floor((len - window) / hop) frames -- one fewer.
 int emit_window(const pe_params& p) { return p.window_samples + (p.vectorizer == 3 ? p.hop_samples : 0); }
-int frame_len_of(const pe_params& p) { return p.window_samples < kNfft ? p.window_samples : kNfft; }
+int frame_len_of(const pe_params& p) { return p.window_samples < p.n_fft ? p.window_samples : p.n_fft; }
 // frames computed (first frame_len samples arrived) but not yet emitted: at most this many exist at any time
 int pending_frames(const pe_params& p) { return (emit_window(p) - frame_len_of(p) + p.hop_samples - 1) / p.hop_samples; }
 // vectorize_raw on a whole buffer (vectorization.py:46-50): frames the vectorizer returns for n samples
@@ -364,7 +416,7 @@ StreamGeom geom(const pe_engine* e) {
     g.log_mode = e->prm.vectorizer == 3 ? 1 : 0;
     g.window = emit_window(e->prm);
     g.hop = e->prm.hop_samples;
-    g.frame_len = e->prm.window_samples < kNfft ? e->prm.window_samples : kNfft;
+    g.frame_len = frame_len_of(e->prm);
     g.n_filt = e->prm.n_filt;
     g.n_mfcc = e->prm.n_mfcc;
     g.n_features = e->prm.n_features;
@@ -382,7 +434,7 @@ WaveTables<R> tables(const pe_engine* e) {
 
 // the most frames one stream can complete in a call of n_updates chunks (a full carry plus the new samples)
 int max_frames_per_call(const pe_engine* e, long long new_samples) {
-    const long long fmax = ((long long)(kCarryCap - 1) + new_samples - frame_len_of(e->prm)) / e->prm.hop_samples + 1;
+    const long long fmax = ((long long)(e->carry_cap - 1) + new_samples - frame_len_of(e->prm)) / e->prm.hop_samples + 1;
     return (int)(fmax < 1 ? 1 : fmax);
 }
 
@@ -406,6 +458,20 @@ MfccStreamArgs<R> mfcc_args(const pe_engine* e, const int16_t* pcm_dev, int chun
     return a;
 }
 
+template <class R>
+GeneralStreamArgs<R> general_args(const pe_engine* e, const int16_t* pcm_dev, int chunk) {
+    GeneralStreamArgs<R> a{};
+    a.geo = geom(e);
+    a.tab = e->gtab;
+    a.pcm = pcm_dev; a.chunk = chunk;
+    a.carry = e->carry; a.carry_next = e->carry_alt; a.carry_cap = e->carry_cap;
+    const int c = e->cur, n = c ^ 1;
+    a.st_q = e->st_q[c]; a.st_kc = e->st_kc[c]; a.st_ke = e->st_ke[c];
+    a.st_q_next = e->st_q[n]; a.st_kc_next = e->st_kc[n]; a.st_ke_next = e->st_ke[n];
+    a.ring = e->ring; a.row_floats = e->row_floats;
+    return a;
+}
+
 // after a call's MFCC launches: the other counter set and the other carry buffer are the current ones
 void flip_state(pe_engine* e) {
     e->cur ^= 1;
@@ -417,7 +483,10 @@ int launch_mfcc(pe_engine* e, const int16_t* pcm_dev, int chunk, hipStream_t s) 
     // (no cap on the frames ONE update may complete: Listener.update takes a chunk of any length,
     //  network_runner.py:125-146; the frame tasks skip every row that the ring would overwrite again -- v_first in
     //  mfcc_frame_tasks -- so a long chunk costs its last ring_slots frames plus a scalar walk over the row indices)
-    if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_mfcc_f64(mfcc_args<double>(e, pcm_dev, chunk), tables<double>(e), e->n_cus, s));
+    if (e->general) {
+        if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_general_stream_f64(general_args<double>(e, pcm_dev, chunk), s));
+        else PE_HIP(e, launch_general_stream_f32(general_args<float>(e, pcm_dev, chunk), s));
+    } else if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_mfcc_f64(mfcc_args<double>(e, pcm_dev, chunk), tables<double>(e), e->n_cus, s));
     else PE_HIP(e, launch_mfcc_f32(mfcc_args<float>(e, pcm_dev, chunk), tables<float>(e), e->n_cus, s));
     flip_state(e);
     return PE_OK;
@@ -443,6 +512,7 @@ GruArgs gru_args(const pe_engine* e) {
     a.bf16 = e->prm.gru_precision == 1;
     a.wx_bf16 = e->wx_bf16; a.wr_bf16 = e->wr_bf16; a.wd_bf16 = e->wd_bf16;
     a.feats = nullptr; a.out = nullptr; a.row_stride = 0;
+    a.row_floats = e->row_floats;
     // Four waves per tile cut the latency of a tile's chain; that only pays while every tile gets a CU of its
     // own next to one MFCC workgroup.  Measured (fused, f64 front end; tools/gpu_policy.py): 4096 streams
     // 21.9 us (4 waves) vs 32.0 (1); 8192: 41.5 vs 33.5; 16384: 76.0 vs 55.3; 65536: 284 vs 199.
@@ -451,11 +521,12 @@ GruArgs gru_args(const pe_engine* e) {
     a.waves_per_tile = e->gru_waves ? e->gru_waves : (e->n_tiles <= e->n_cus ? 4 : 1);      // (16 = DPP kernel: opt-in)
     if (a.waves_per_tile == 16 && !dpp_ok) a.waves_per_tile = 4;
     if (e->prm.use_delta) a.waves_per_tile = 1;          // only the one-wave kernel carries the delta inputs
+    if (e->row_floats != kRowFloats) a.waves_per_tile = 1;       // ... and the 32-float feature rows
     // Stock width: the re-tiled shapes (three full tiles + partial sums; gru_cw_device.h) cut the four-wave kernel's
     // timestep (14.2 vs 16.3 us per window chain, stand-alone) but cost the one-wave kernel 5 % in the throughput
     // regime (two-pass MFMAs + reductions: 81.0 vs 77.3 us at 65 536 streams), so an engine takes ONE tiling for all
     // of its launches -- every shape of a tiling agrees bit for bit -- by its size.
-    const bool cw_ok = e->cw_blob && !a.proj_ring && !a.bf16 && !e->wide && !e->prm.use_delta && a.waves_per_tile != 16;
+    const bool cw_ok = e->cw_blob && e->row_floats == kRowFloats && !a.proj_ring && !a.bf16 && !e->wide && !e->prm.use_delta && a.waves_per_tile != 16;
     const bool retile = cw_ok && (e->gru_tiling == 1 || (e->gru_tiling < 0 && e->n_tiles <= e->n_cus));
     a.cw = retile ? e->cw_blob : nullptr;
     return a;
@@ -505,7 +576,7 @@ bool can_fuse(const pe_engine* e, int chunk) {
     // (the fused kernels exist for the stock table shape: filterbanks whose runs need the wide loop bounds take two launches;
     //  so do networks of 21..32 units on the one-wave kernel: their register-resident weights do not fit beside the
     //  frame role's 128-register budget -- fused, that shape spilled 96-240 bytes per lane into the time loop)
-    if (!(e->fused && !e->wide && e->table_layout.mel_pad == 10 && chunk <= emit_window(e->prm) - frame_len_of(e->prm))) return false;
+    if (!(e->fused && !e->general && !e->wide && e->table_layout.mel_pad == 10 && chunk <= emit_window(e->prm) - frame_len_of(e->prm))) return false;
     if (e->prm.gru_precision == 0 && gru_small_regs(e->units) >= 6 && gru_args(e).waves_per_tile != 4) return false;
     return true;
 }
@@ -533,7 +604,7 @@ int do_update(pe_engine* e, const int16_t* pcm_dev, int chunk, float* raw_out_de
         if (t) { PE_HIP(e, hipEventRecord(e->ev[2], s)); e->ev_valid = true; e->ev_has_gru = raw_out_dev != nullptr; }
     }
     if (feats_out_dev) {
-        GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, e->st_ke[e->cur], feats_out_dev};
+        GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, e->st_ke[e->cur], feats_out_dev, e->row_floats};
         PE_HIP(e, launch_gather(g, s));
     }
     return PE_OK;
@@ -552,10 +623,14 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     if (!p || !mel_filters || !w || !out) return fail(nullptr, PE_ERR_INVALID, "null argument to pe_create");
     *out = nullptr;
     if (n_streams <= 0) return fail(nullptr, PE_ERR_INVALID, "n_streams must be positive, got %d", n_streams);
-    if (p->n_fft != kNfft) return fail(nullptr, PE_ERR_UNSUPPORTED, "only n_fft=512 has a kernel (got %d)", p->n_fft);
-    if (p->n_mfcc < 1 || p->n_mfcc > kRowFloats) return fail(nullptr, PE_ERR_UNSUPPORTED, "n_mfcc must be in 1..16 (got %d)", p->n_mfcc);
-    if (p->n_filt < 1 || p->n_filt > kMaxFilt || p->n_mfcc > p->n_filt)
-        return fail(nullptr, PE_ERR_UNSUPPORTED, "need 1 <= n_mfcc <= n_filt <= 64 (got n_filt=%d n_mfcc=%d)", p->n_filt, p->n_mfcc);
+    // ListenerParams (params.py:28-118): the stock shape (n_fft = 512, <= 64 filters, <= 16 coefficients) runs on the
+    // one-frame-per-wave kernel, every other shape on the general front end (mfcc_general_device.h)
+    if (p->n_fft < 64 || p->n_fft > kGeneralMaxFft || (p->n_fft & (p->n_fft - 1)) != 0)
+        return fail(nullptr, PE_ERR_UNSUPPORTED, "n_fft must be a power of two in 64..%d (got %d)", kGeneralMaxFft, p->n_fft);
+    if (p->n_mfcc < 1 || p->n_mfcc > kGeneralMaxMfcc) return fail(nullptr, PE_ERR_UNSUPPORTED, "n_mfcc must be in 1..%d (got %d)", kGeneralMaxMfcc, p->n_mfcc);
+    if (p->n_filt < 1 || p->n_filt > kGeneralMaxFilt || p->n_mfcc > p->n_filt)
+        return fail(nullptr, PE_ERR_UNSUPPORTED, "need 1 <= n_mfcc <= n_filt <= %d (got n_filt=%d n_mfcc=%d)", kGeneralMaxFilt, p->n_filt, p->n_mfcc);
+    bool general = p->n_fft != kNfft || p->n_filt > kMaxFilt || p->n_mfcc > kRowFloats;
     if (p->hop_samples < 1 || p->window_samples < 1 || p->n_features < 1)
         return fail(nullptr, PE_ERR_INVALID, "window/hop/n_features must be positive");
     if (p->mfcc_precision != 0 && p->mfcc_precision != 1) return fail(nullptr, PE_ERR_INVALID, "mfcc_precision must be 0 (f64) or 1 (f32)");
@@ -588,9 +663,31 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     hipError_t herr = hipSetDevice(device);
     if (herr != hipSuccess) return fail(nullptr, PE_ERR_HIP, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(herr));
 
+    if (p->n_mfcc > kRowFloats && (wide || p->use_delta || p->gru_precision != 0))
+        return fail(nullptr, PE_ERR_UNSUPPORTED, "more than 16 coefficients per frame feed the float32 network of <= 32 units without delta features only");
+    if (general && (p->gru_precision != 0 || p->ring_precision != 0))
+        return fail(nullptr, PE_ERR_UNSUPPORTED, "the bf16 configuration exists for the stock front-end shape (n_fft = 512, <= 64 filters, <= 16 coefficients)");
+
     pe_engine* e = new pe_engine();
     e->prm = *p;
     e->device = device;
+    if (!general) {
+        // a stock-shape filterbank whose runs need more than the 64 lanes of the wave kernel also takes the general path
+        std::vector<unsigned char> probe;
+        pe_wave::Layout lprobe{};
+        const std::string perr = p->mfcc_precision == 0 ? pe_wave::build<double>(mel_filters, p->n_filt, p->n_mfcc, probe, lprobe)
+                                                        : pe_wave::build<float>(mel_filters, p->n_filt, p->n_mfcc, probe, lprobe);
+        if (!perr.empty()) {
+            if (p->gru_precision != 0 || p->ring_precision != 0) { delete e; return fail(nullptr, PE_ERR_UNSUPPORTED, "%s", perr.c_str()); }
+            general = true;
+        }
+    }
+    e->general = general;
+    e->row_floats = p->n_mfcc > kRowFloats ? 2 * kRowFloats : kRowFloats;
+    {
+        const int fl = frame_len_of(*p);
+        e->carry_cap = general ? ((fl + 63) / 64 * 64 > kCarryCap ? (fl + 63) / 64 * 64 : kCarryCap) : kCarryCap;
+    }
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->n_cus = cus;
@@ -607,8 +704,8 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
 
     int rc = PE_OK;
     do {
-        if ((rc = dev_alloc(e, &e->carry, (size_t)e->n_padded * kCarryCap))) break;
-        if ((rc = dev_alloc(e, &e->carry_alt, (size_t)e->n_padded * kCarryCap))) break;
+        if ((rc = dev_alloc(e, &e->carry, (size_t)e->n_padded * e->carry_cap))) break;
+        if ((rc = dev_alloc(e, &e->carry_alt, (size_t)e->n_padded * e->carry_cap))) break;
         for (int b = 0; b < 2 && !rc; ++b) {
             if ((rc = dev_alloc(e, &e->st_q[b], (size_t)e->n_padded))) break;
             if ((rc = dev_alloc(e, &e->st_kc[b], (size_t)e->n_padded))) break;
@@ -648,13 +745,15 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         // from the ring; they pay while the ring stays cache-resident (256 B per frame and stream)
         e->proj_ok = !wide && p->gru_precision == 0 && !p->use_delta && gru_small_regs(L.units) == 5 && !e->proj_w_host.empty();
         e->proj_on = false;          // opt-in (pe_set_input_projection): measured no gain for the MFMA kernels at <= 4096 streams
-        rc = (p->mfcc_precision == 0) ? build_tables<double>(e, mel_filters) : build_tables<float>(e, mel_filters);
+        if (e->general) rc = (p->mfcc_precision == 0) ? build_general_tables<double>(e, mel_filters) : build_general_tables<float>(e, mel_filters);
+        else rc = (p->mfcc_precision == 0) ? build_tables<double>(e, mel_filters) : build_tables<float>(e, mel_filters);
         if (rc) break;
         if (e->proj_on && (rc = dev_alloc(e, &e->proj_ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kProjRow))) break;
         for (auto& ev : e->ev)
             if (hipEventCreate(&ev) != hipSuccess) { rc = fail(e, PE_ERR_HIP, "hipEventCreate failed"); break; }
         if (rc) break;
-        const size_t lds = (size_t)e->table_layout.total + (size_t)kFrameWaves * pe_wave::kScratchReals * (p->mfcc_precision == 0 ? 8 : 4);
+        const size_t lds = e->general ? general_lds_bytes(p->mfcc_precision == 0 ? 8 : 4, p->n_fft, p->n_filt)
+                                      : (size_t)e->table_layout.total + (size_t)kFrameWaves * pe_wave::kScratchReals * (p->mfcc_precision == 0 ? 8 : 4);
         if (lds > 64 * 1024) { rc = fail(e, PE_ERR_UNSUPPORTED, "MFCC kernel would need %zu bytes of LDS per workgroup", lds); break; }
         if ((rc = pe_clear(e, nullptr))) break;
         hipError_t se = hipDeviceSynchronize();
@@ -692,7 +791,7 @@ int pe_clear(pe_engine* e, const uint8_t* mask_host) {
     }
     ClearArgs a{e->n_padded, e->ring_slots, mask_dev, e->st_q[e->cur], e->st_kc[e->cur], e->st_ke[e->cur], e->ring, e->prm.ring_precision, e->activation,
                 e->proj_on ? e->proj_ring : nullptr,
-                e->proj_on ? reinterpret_cast<const float*>(e->table_blob + e->table_layout.proj_b) : nullptr};
+                e->proj_on ? reinterpret_cast<const float*>(e->table_blob + e->table_layout.proj_b) : nullptr, e->row_floats};
     if (mask_dev) a.n_streams = e->n_streams;
     PE_HIP(e, launch_clear(a, nullptr));
     PE_HIP(e, hipStreamSynchronize(nullptr));
@@ -756,7 +855,7 @@ int pe_get_vectors(pe_engine* e, float* feats_out_host) {
     int rc;
     const size_t feat_bytes = (size_t)e->n_streams * e->prm.n_features * e->prm.n_mfcc * sizeof(float);
     if ((rc = ensure(e, e->st_feats, feat_bytes))) return rc;
-    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, e->st_ke[e->cur], static_cast<float*>(e->st_feats.p)};
+    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, e->st_ke[e->cur], static_cast<float*>(e->st_feats.p), e->row_floats};
     PE_HIP(e, launch_gather(g, nullptr));
     PE_HIP(e, hipMemcpy(feats_out_host, e->st_feats.p, feat_bytes, hipMemcpyDeviceToHost));
     return PE_OK;
@@ -770,7 +869,7 @@ int pe_set_vectors(pe_engine* e, const float* feats_host) {
     const size_t feat_bytes = (size_t)e->n_streams * e->prm.n_features * e->prm.n_mfcc * sizeof(float);
     if ((rc = ensure(e, e->st_feats, feat_bytes))) return rc;
     PE_HIP(e, hipMemcpy(e->st_feats.p, feats_host, feat_bytes, hipMemcpyHostToDevice));
-    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, e->st_ke[e->cur], static_cast<float*>(e->st_feats.p)};
+    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, e->st_ke[e->cur], static_cast<float*>(e->st_feats.p), e->row_floats};
     PE_HIP(e, launch_scatter(g, e->st_q[e->cur], e->st_kc[e->cur], nullptr));
     if (e->proj_on)
         PE_HIP(e, launch_project_rows(e->ring, e->proj_ring, reinterpret_cast<const float*>(e->table_blob + e->table_layout.proj_w),
@@ -826,7 +925,15 @@ int vectorize_buffer(pe_engine* e, const double* audio_host, int64_t n_samples, 
     if ((rc = ensure(e, e->st_mfcc, fb))) return rc;
     PE_HIP(e, hipMemcpy(e->st_audio.p, audio_host, ab, hipMemcpyHostToDevice));
     double* dev_out = static_cast<double*>(e->st_mfcc.p);
-    if (e->prm.mfcc_precision == 0) {
+    if (e->general) {
+        if (e->prm.mfcc_precision == 0) {
+            GeneralOfflineArgs<double> a{geom(e), e->gtab, static_cast<const double*>(e->st_audio.p), n_frames, mels ? nullptr : dev_out, nullptr, mels ? dev_out : nullptr, e->row_floats};
+            PE_HIP(e, launch_general_offline_f64(a, e->n_cus, nullptr));
+        } else {
+            GeneralOfflineArgs<float> a{geom(e), e->gtab, static_cast<const double*>(e->st_audio.p), n_frames, mels ? nullptr : dev_out, nullptr, mels ? dev_out : nullptr, e->row_floats};
+            PE_HIP(e, launch_general_offline_f32(a, e->n_cus, nullptr));
+        }
+    } else if (e->prm.mfcc_precision == 0) {
         MfccOfflineArgs<double> a{geom(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames,
                                   mels ? nullptr : dev_out, nullptr, mels ? dev_out : nullptr};
         PE_HIP(e, launch_mfcc_offline_f64(a, tables<double>(e), e->n_cus, nullptr));
@@ -865,12 +972,20 @@ int pe_evaluate(pe_engine* e, const double* audio_host, int64_t n_samples, int32
     if (n_windows > 0x7fffffff) return fail(e, PE_ERR_INVALID, "too many windows");
     PE_HIP(e, hipSetDevice(e->device));
     int rc;
-    const size_t ab = (size_t)n_samples * sizeof(double), rb = (size_t)n_frames * kRowFloats * sizeof(float);
+    const size_t ab = (size_t)n_samples * sizeof(double), rb = (size_t)n_frames * e->row_floats * sizeof(float);
     if ((rc = ensure(e, e->st_audio, ab))) return rc;
     if ((rc = ensure(e, e->st_feats, rb))) return rc;
     if ((rc = ensure(e, e->st_out, (size_t)n_windows * sizeof(float)))) return rc;
     PE_HIP(e, hipMemcpy(e->st_audio.p, audio_host, ab, hipMemcpyHostToDevice));
-    if (e->prm.mfcc_precision == 0) {
+    if (e->general) {
+        if (e->prm.mfcc_precision == 0) {
+            GeneralOfflineArgs<double> a{geom(e), e->gtab, static_cast<const double*>(e->st_audio.p), n_frames, nullptr, static_cast<float*>(e->st_feats.p), nullptr, e->row_floats};
+            PE_HIP(e, launch_general_offline_f64(a, e->n_cus, nullptr));
+        } else {
+            GeneralOfflineArgs<float> a{geom(e), e->gtab, static_cast<const double*>(e->st_audio.p), n_frames, nullptr, static_cast<float*>(e->st_feats.p), nullptr, e->row_floats};
+            PE_HIP(e, launch_general_offline_f32(a, e->n_cus, nullptr));
+        }
+    } else if (e->prm.mfcc_precision == 0) {
         MfccOfflineArgs<double> a{geom(e), static_cast<const double*>(e->st_audio.p), n_samples, n_frames, nullptr, static_cast<float*>(e->st_feats.p), nullptr};
         PE_HIP(e, launch_mfcc_offline_f64(a, tables<double>(e), e->n_cus, nullptr));
     } else {
@@ -993,6 +1108,13 @@ int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, i
     if ((long long)n_updates * chunk >= (1ll << 30)) return fail(e, PE_ERR_INVALID, "n_updates * chunk_samples must stay below 2^30");
     if (e->prm.n_features + pending + frames > e->ring_slots) return fail(e, PE_ERR_INVALID, "reserved ring too small for %d updates of %d samples", n_updates, chunk);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (e->general) {           // the general front end has no multi-update launch: the same updates, one after the other
+        for (int u = 0; u < n_updates; ++u) {
+            int urc = do_update(e, pcm_dev + (size_t)u * e->n_streams * chunk, chunk, raw_out_dev + (size_t)u * e->n_streams, nullptr, s);
+            if (urc) return urc;
+        }
+        return PE_OK;
+    }
     // frames one stream can complete in this call: one task row per frame, at most kMaxFrameRows rows
     const int rows = max_frames_per_call(e, (long long)n_updates * chunk);
     if (rows > kMaxFrameRows) return fail(e, PE_ERR_INVALID, "a call may complete at most %d frames per stream (%d updates of %d samples: %d)", kMaxFrameRows, n_updates, chunk, rows);
@@ -1051,7 +1173,7 @@ int pe_get_info(const pe_engine* e, pe_info* out) {
     out->units = e->units;
     out->n_layers = e->n_layers;
     out->ring_slots = e->ring_slots;
-    out->carry_capacity = kCarryCap;
+    out->carry_capacity = e->carry_cap;
     out->mfcc_precision = e->prm.mfcc_precision;
     out->gru_precision = e->prm.gru_precision;
     out->device_bytes = e->device_bytes;

@@ -86,11 +86,15 @@ constexpr int kProjTileStride = kTileStreams * 16;       // floats between the a
 // One wave = one tile of 16 streams, whole window, weights resident in registers.
 // PROJ: every timestep starts from the input projection x.W + b that the MFCC stage stored beside the feature row
 // (a.proj_ring), instead of recomputing it with 4 MFMAs per output tile.
-template <int R, int MODE, bool PROJ = false>
+// KX = 2: feature rows of 32 floats (17..32 coefficients per frame: general ListenerParams, params.py:28-118): the input
+// projection runs over two 16-feature groups (8 k-steps per output tile instead of 4)
+template <int R, int MODE, bool PROJ = false, int KX = 1>
 __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const int lane) {
 #pragma clang fp contract(off)      // every fusion in the gate arithmetic is spelled out: all kernel shapes round alike
     constexpr bool FROM_RING = MODE == kRing;
+    constexpr int RF = kRowFloats * KX;           // floats per feature row
     static_assert(!PROJ || (MODE == kRing && GruShape<R>::NT <= 4), "projection rows hold 4 output tiles");
+    static_assert(KX == 1 || !PROJ, "projection rows exist for 16-float feature rows");
     using G = GruShape<R>;
     const int g = lane >> 4, j = lane & 15;
     const long long stream = (long long)tile * kTileStreams + j;
@@ -98,14 +102,15 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
     const int T = a.n_features;
 
     // ---- resident operands ------------------------------------------------------------
-    float wx[G::NT][4], wxd[G::NT][4], wr1[G::P1_END][R], wr2[G::NP2][R], wd[R];
+    float wx[G::NT][4], wx2[KX == 2 ? G::NT : 1][4], wxd[G::NT][4], wr1[G::P1_END][R], wr2[G::NP2][R], wd[R];
     f32x4 bias[G::NT];
-    const bool delta = a.use_delta != 0;      // add_deltas (vectorization.py:53-59): F more inputs = x_t - x_(t-1)
+    const bool delta = KX == 1 && a.use_delta != 0;      // add_deltas (vectorization.py:53-59): F more inputs = x_t - x_(t-1)
 #pragma unroll
     for (int t = 0; t < G::NT; ++t) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             wx[t][kk] = a.wx[(t * 4 + kk) * 64 + lane];
+            if (KX == 2) wx2[t][kk] = a.wx[((G::NT + t) * 4 + kk) * 64 + lane];      // features 16 + 4 g + kk
             wxd[t][kk] = delta ? a.wxd[(t * 4 + kk) * 64 + lane] : 0.f;
         }
 #pragma unroll
@@ -140,33 +145,35 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
             if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
         }
         first = ke - (uint32_t)T;
-        xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats + 4 * g;
+        xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * RF + 4 * g;
     } else if (MODE == kRows) {
         const long long w = valid ? stream : 0;               // padded lanes shadow window 0
-        xbase = a.feats + ((size_t)w * a.row_stride) * kRowFloats + 4 * g;
+        xbase = a.feats + ((size_t)w * a.row_stride) * RF + 4 * g;
     } else {
         xbase = a.feats + (size_t)stream * T * (delta ? 2 * a.n_in : a.n_in);
     }
     const int frow = delta ? 2 * a.n_in : a.n_in;         // floats per timestep of an explicit batch
-    auto load_x = [&](int t) -> f32x4 {
+    // hi = 1: the second 16-feature group of a 32-float row (KX = 2)
+    auto load_xg = [&](int t, const int hi) -> f32x4 {
         if (FROM_RING) {
             // no branch: rows of padded streams exist (zeroed), t is clamped to the last row, so the
             // prefetch stays in flight across the timestep instead of being waited for at a join
             const int tc = t < T ? t : T - 1;
             const uint32_t slot = (first + (uint32_t)tc) & mask;
-            return *reinterpret_cast<const f32x4*>(xbase + (size_t)slot * kTileStreams * kRowFloats);
+            return *reinterpret_cast<const f32x4*>(xbase + (size_t)slot * kTileStreams * RF + 16 * hi);
         }
         if (MODE == kRows) {
             const int tc = t < T ? t : T - 1;
-            return *reinterpret_cast<const f32x4*>(xbase + (size_t)tc * kRowFloats);
+            return *reinterpret_cast<const f32x4*>(xbase + (size_t)tc * RF + 16 * hi);
         }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (!valid || t >= T) return v;
-        const float* p = xbase + (size_t)t * frow + 4 * g;
+        const float* p = xbase + (size_t)t * frow + 16 * hi + 4 * g;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) v[kk] = (4 * g + kk < a.n_in) ? p[kk] : 0.f;
+        for (int kk = 0; kk < 4; ++kk) v[kk] = (16 * hi + 4 * g + kk < a.n_in) ? p[kk] : 0.f;
         return v;
     };
+    auto load_x = [&](int t) -> f32x4 { return load_xg(t, 0); };
     // explicit batches carry their delta columns (Runner.predict receives add_deltas output)
     auto load_d = [&](int t) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -202,8 +209,10 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
         x = load_x(0);
     }
     f32x4 xprev = {0.f, 0.f, 0.f, 0.f};
+    f32x4 xh = {0.f, 0.f, 0.f, 0.f};
+    if (KX == 2) xh = load_xg(0, 1);
     for (int t = 0; t < T; ++t) {
-        f32x4 xn = {0.f, 0.f, 0.f, 0.f};
+        f32x4 xn = {0.f, 0.f, 0.f, 0.f}, xhn = {0.f, 0.f, 0.f, 0.f};
         f32x4 acc[G::NT];
         if (PROJ) {
 #pragma unroll
@@ -218,12 +227,16 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
 #endif
         } else {
             xn = load_x(t + 1);                  // prefetch next timestep's features
+            if (KX == 2) xhn = load_xg(t + 1, 1);
             // input projection, bias as the initial accumulator
 #pragma unroll
             for (int tl = 0; tl < G::NT; ++tl) {
                 acc[tl] = mfma(wx[tl][0], x[0], bias[tl]);
 #pragma unroll
                 for (int kk = 1; kk < 4; ++kk) acc[tl] = mfma(wx[tl][kk], x[kk], acc[tl]);
+                if (KX == 2)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc[tl] = mfma(wx2[tl][kk], xh[kk], acc[tl]);
             }
         }
         if (delta && !PROJ) {
@@ -275,6 +288,7 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
             h[rho] = gru_blend(z[rho], h[rho], hh);
         }
         x = xn;
+        xh = xhn;
     }
 
     // Dense(1) + sigmoid: reduce over this lane's units, then over the four lane groups

@@ -9,6 +9,7 @@
 #include "gru_dpp_device.h"
 #include "gru_bf16_device.h"
 #include "gru_wide_device.h"
+#include "mfcc_general_device.h"
 
 namespace pe {
 
@@ -86,9 +87,9 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
 }
 
 // ---- GRU: one wave per 16-stream tile ----------------------------------------------------------
-template <int R, int MODE, bool PROJ = false>
+template <int R, int MODE, bool PROJ = false, int KX = 1>
 __global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
-    gru_tile<R, MODE, PROJ>(a, blockIdx.x, threadIdx.x);
+    gru_tile<R, MODE, PROJ, KX>(a, blockIdx.x, threadIdx.x);
 }
 
 // ---- GRU, stock width re-tiled (gru_cw_device.h): one wave per tile / four waves per tile ------------------------
@@ -320,6 +321,12 @@ template <int R>
 static hipError_t launch_r(const GruArgs& a, int mode, hipStream_t s) {
     const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
     if (tiles == 0) return hipSuccess;
+    if (a.row_floats == 2 * kRowFloats) {           // 17..32 coefficients per frame: the one-wave kernel over 32-float rows
+        if (mode == kRing) hipLaunchKernelGGL((gru_small_kernel<R, kRing, false, 2>), dim3(tiles), dim3(64), 0, s, a);
+        else if (mode == kRows) hipLaunchKernelGGL((gru_small_kernel<R, kRows, false, 2>), dim3(tiles), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((gru_small_kernel<R, kFeats, false, 2>), dim3(tiles), dim3(64), 0, s, a);
+        return hipGetLastError();
+    }
     if constexpr (R == 5) {
         if (a.cw) {
             if (mode == kRing && a.waves_per_tile == 4 && cw_four_waves_ok(a)) hipLaunchKernelGGL(gru_cw_kernel, dim3(tiles), dim3(256), kCwLdsBytes, s, a);
@@ -501,6 +508,37 @@ static hipError_t launch_fused(const MfccStreamArgs<R>& m, const WaveTables<R>& 
 hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const WaveTables<double>& t, const GruArgs& g, int n_cus, hipStream_t s) { return launch_fused<double>(m, t, g, n_cus, s); }
 hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const WaveTables<float>& t, const GruArgs& g, int n_cus, hipStream_t s) { return launch_fused<float>(m, t, g, n_cus, s); }
 
+// ---- general front end (mfcc_general_device.h): one wave per stream / per frame -------------------------------------
+template <class R>
+__global__ __launch_bounds__(64) void mfcc_general_stream_kernel(const GeneralStreamArgs<R> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = blockIdx.x;
+    if (s < a.geo.n_streams) general_stream<R>(a, reinterpret_cast<R*>(smem), s, threadIdx.x);
+}
+template <class R>
+__global__ __launch_bounds__(64) void mfcc_general_offline_kernel(const GeneralOfflineArgs<R> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    general_offline<R>(a, reinterpret_cast<R*>(smem), blockIdx.x, gridDim.x, threadIdx.x);
+}
+template <class R>
+static hipError_t launch_general_stream_t(const GeneralStreamArgs<R>& a, hipStream_t s) {
+    if (a.geo.n_streams == 0) return hipSuccess;
+    hipLaunchKernelGGL(mfcc_general_stream_kernel<R>, dim3(a.geo.n_streams), dim3(64), general_lds_bytes(sizeof(R), a.tab.n_fft, a.tab.n_filt), s, a);
+    return hipGetLastError();
+}
+template <class R>
+static hipError_t launch_general_offline_t(const GeneralOfflineArgs<R>& a, int n_cus, hipStream_t s) {
+    if (a.n_frames <= 0) return hipSuccess;
+    const long long cap = (long long)n_cus * 16;
+    hipLaunchKernelGGL(mfcc_general_offline_kernel<R>, dim3((unsigned)(a.n_frames < cap ? a.n_frames : cap)), dim3(64),
+                       general_lds_bytes(sizeof(R), a.tab.n_fft, a.tab.n_filt), s, a);
+    return hipGetLastError();
+}
+hipError_t launch_general_stream_f64(const GeneralStreamArgs<double>& a, hipStream_t s) { return launch_general_stream_t<double>(a, s); }
+hipError_t launch_general_stream_f32(const GeneralStreamArgs<float>& a, hipStream_t s) { return launch_general_stream_t<float>(a, s); }
+hipError_t launch_general_offline_f64(const GeneralOfflineArgs<double>& a, int n_cus, hipStream_t s) { return launch_general_offline_t<double>(a, n_cus, s); }
+hipError_t launch_general_offline_f32(const GeneralOfflineArgs<float>& a, int n_cus, hipStream_t s) { return launch_general_offline_t<float>(a, n_cus, s); }
+
 // ---- small utility kernels ---------------------------------------------------------------------
 __global__ void gather_kernel(const GatherArgs a) {
     // out[s][t][f] = ring row of frame (ke - T + t) of stream s      (Listener.mfccs, oldest first)
@@ -513,7 +551,7 @@ __global__ void gather_kernel(const GatherArgs a) {
     const uint32_t slot = (a.st_ke[s] - (uint32_t)a.n_features + (uint32_t)t) & (uint32_t)(a.ring_slots - 1);
     const long long tile = s / kTileStreams;
     const int j = (int)(s % kTileStreams);
-    const size_t at = (((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kRowFloats + f;
+    const size_t at = (((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * a.row_floats + f;
     a.out[idx] = a.ring_bf16 ? (float)reinterpret_cast<const __bf16*>(a.ring)[at] : a.ring[at];
 }
 
@@ -521,15 +559,16 @@ __global__ void scatter_kernel(const GatherArgs a, int32_t* st_q, uint32_t* st_k
     // inverse of gather_kernel: the stream restarts with the given [T][F] window already emitted
     // (frames 0..T-1 in slots 0..T-1, nothing held toward the next frame)
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)a.n_streams * a.n_features * kRowFloats;
+    const int RF = a.row_floats;
+    const long long total = (long long)a.n_streams * a.n_features * RF;
     if (idx >= total) return;
-    const int f = (int)(idx % kRowFloats);
-    const int t = (int)((idx / kRowFloats) % a.n_features);
-    const long long s = idx / ((long long)kRowFloats * a.n_features);
+    const int f = (int)(idx % RF);
+    const int t = (int)((idx / RF) % a.n_features);
+    const long long s = idx / ((long long)RF * a.n_features);
     const long long tile = s / kTileStreams;
     const int j = (int)(s % kTileStreams);
     const float v = f < a.n_mfcc ? a.out[(s * a.n_features + t) * a.n_mfcc + f] : 0.0f;
-    const size_t at = (((size_t)tile * a.ring_slots + t) * kTileStreams + j) * kRowFloats + f;
+    const size_t at = (((size_t)tile * a.ring_slots + t) * kTileStreams + j) * RF + f;
     if (a.ring_bf16) reinterpret_cast<__bf16*>(const_cast<float*>(a.ring))[at] = (__bf16)v;
     else const_cast<float*>(a.ring)[at] = v;
     if (f == 0 && t == 0) {
@@ -540,7 +579,7 @@ __global__ void scatter_kernel(const GatherArgs a, int32_t* st_q, uint32_t* st_k
 }
 
 hipError_t launch_scatter(const GatherArgs& a, int32_t* st_q, uint32_t* st_kc, hipStream_t s) {
-    const long long total = (long long)a.n_streams * a.n_features * kRowFloats;
+    const long long total = (long long)a.n_streams * a.n_features * a.row_floats;
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, st_q, st_kc);
     return hipGetLastError();
@@ -554,9 +593,9 @@ __global__ void clear_kernel(const ClearArgs a) {
     if (threadIdx.x == 0) { a.st_q[s] = 0; a.st_kc[s] = 0u; a.st_ke[s] = 0u; if (a.activation) a.activation[s] = 0; }
     const long long tile = s / kTileStreams;
     const int j = (int)(s % kTileStreams);
-    for (int i = threadIdx.x; i < a.ring_slots * kRowFloats; i += blockDim.x) {
-        const int slot = i / kRowFloats, f = i % kRowFloats;
-        const size_t at = (((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * kRowFloats + f;
+    for (int i = threadIdx.x; i < a.ring_slots * a.row_floats; i += blockDim.x) {
+        const int slot = i / a.row_floats, f = i % a.row_floats;
+        const size_t at = (((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * a.row_floats + f;
         if (a.ring_bf16) reinterpret_cast<__bf16*>(a.ring)[at] = (__bf16)0.0f;
         else a.ring[at] = 0.0f;
     }

@@ -149,6 +149,7 @@ struct GruArgs {
     const float* feats;
     int row_stride;
     float* out;             // [n_streams]
+    int row_floats;         // floats per feature row: 16, or 32 for 17..32 coefficients per frame (one-wave kernel, KX = 2)
     int waves_per_tile;     // 1: one wave per tile (gru_tile);  4: four waves share a tile (gru_tile_mw);
                             // 16: four waves per tile, sixteen LANES per stream (gru_tile_dpp)
 };
@@ -176,6 +177,7 @@ struct GatherArgs {         // ring -> [n][T][F] time-ordered features (update_v
     const float* ring;
     const uint32_t* st_ke;
     float* out;
+    int row_floats = kRowFloats;    // floats per feature row (32 when a frame has 17..32 coefficients)
 };
 
 struct ClearArgs {
@@ -187,6 +189,7 @@ struct ClearArgs {
     int32_t* activation;    // per-stream trigger state, may be null
     float* proj_ring;       // input-projection rows, may be null: a cleared row is the projection of a zero frame = bias
     const float* proj_b;    // [kProjRow]
+    int row_floats = kRowFloats;
 };
 
 // ThresholdDecoder.decode + TriggerDetector.update for every stream (threshold_decoder.py:45-57,

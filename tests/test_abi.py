@@ -52,9 +52,12 @@ def test_create_argument_validation_without_gpu():
     with pytest.raises(ValueError):
         _lib.HipEngine(pr, w, n_streams=0)
     bad = pr.copy()
-    bad.__dict__['n_fft'] = 256
+    bad.__dict__['n_fft'] = 300                     # (any power of two from 64 to 2048 has a kernel)
     with pytest.raises((NotImplementedError, ValueError)):
-        _lib.HipEngine(bad, w, n_streams=1, mel_filters=np.zeros((20, 129)))
+        _lib.HipEngine(bad, w, n_streams=1, mel_filters=np.zeros((20, 151)))
+    bad.__dict__['n_fft'] = 4096
+    with pytest.raises((NotImplementedError, ValueError)):
+        _lib.HipEngine(bad, w, n_streams=1, mel_filters=np.zeros((20, 2049)))
     delta = pr.copy()
     delta.__dict__['use_delta'] = True
     with pytest.raises(ValueError):                 # use_delta needs a layer with 2 * n_mfcc inputs
