@@ -45,6 +45,27 @@ def save_weights(model_name: str, weights: dict):
         np.savez(f, **arrays)
 
 
+def _check_sidecar(net_file: str, sidecar: str):
+    """The side-car must have been exported from THIS .net file: retraining (ModelCheckpoint, train_incremental)
+    rewrites ``<model>.net`` in place, and serving the old export would be silent.  Exports carry the sha256 of
+    their source; older ones are compared by modification time."""
+    import hashlib
+    import warnings
+    from os.path import getmtime, isfile
+    if not isfile(net_file):
+        return                                       # only the export travelled to this machine
+    with np.load(sidecar, allow_pickle=False) as z:
+        want = str(z['source_sha256']) if 'source_sha256' in z.files else None
+    if want is not None:
+        with open(net_file, 'rb') as f:
+            have = hashlib.sha256(f.read()).hexdigest()
+        if have != want:
+            raise ValueError('%s was exported from another version of %s (the model was rewritten since): run '
+                             '`python tools/export_net_to_npz.py %s` again' % (sidecar, net_file, net_file))
+    elif getmtime(net_file) > getmtime(sidecar):
+        warnings.warn('%s is newer than its exported weights %s: re-run tools/export_net_to_npz.py' % (net_file, sidecar))
+
+
 def load_weights(model_name: str) -> dict:
     if model_name.endswith('.pb'):
         from .pb_model import weights_from_pb
@@ -57,7 +78,8 @@ def load_weights(model_name: str) -> dict:
             raise NotImplementedError(
                 'importing %s needs its exported weights %s.npz: run `python tools/export_net_to_npz.py %s` on a '
                 'machine with h5py, or freeze the model with precise-convert to .pb' % (model_name, model_name, model_name))
-        model_name = model_name + '.npz'
+        net_file, model_name = model_name, model_name + '.npz'
+        _check_sidecar(net_file, model_name)
     with np.load(model_name, allow_pickle=False) as z:
         n = int(z['n_layers'])
         layers = [(z['kernel_%d' % i], z['recurrent_kernel_%d' % i], z['bias_%d' % i]) for i in range(n)]

@@ -9,8 +9,9 @@ runner_cls=None)`` with ``update`` / ``update_vectors`` / ``clear`` / ``find_run
 
 Where the work happens:
   * leftover-PCM bookkeeping, framing, MFCC and the [T x F] feature window: ``pe_update*``
-    (mfcc_kernels.hip) -- the state lives in HBM, not in numpy arrays;
-  * the network: ``HipRunner`` -> ``pe_predict`` / fused into ``pe_update`` (gru_kernels.hip);
+    (csrc/mfcc_wave_device.h, mfcc_device.h; any other ListenerParams: mfcc_general_device.h) -- the state lives in
+    HBM, not in numpy arrays;
+  * the network: ``HipRunner`` -> ``pe_predict`` / fused into ``pe_update`` (csrc/gru_device.h, gru_cw_device.h, ...);
   * ``ThresholdDecoder.decode``: host, one float64 per prediction, as in the reference.
 """
 from abc import ABCMeta, abstractmethod
@@ -152,6 +153,20 @@ class Listener:
         if self._mfccs is None:
             self._mfccs = self._engine.get_vectors()[0].astype(np.float64)
         return self._mfccs
+
+    @mfccs.setter
+    def mfccs(self, value):
+        """``listener.mfccs = window`` works on the reference's plain attribute (network_runner.py:104) and leaves
+        ``window_audio`` alone: here the window is installed on the device too (``pe_set_vectors``) and the leftover
+        samples are handed back to it, exactly as when the runner is replaced after construction."""
+        window = np.asarray(value, dtype=np.float64).reshape(self.pr.n_features, self.pr.n_mfcc)
+        self._mfccs = window.copy()
+        if self._float_mode:
+            return                                     # float samples: the window lives on the host (see _update_vectors_float)
+        self._engine.set_vectors(window[np.newaxis].astype(np.float32))
+        if len(self.window_audio):
+            left = np.rint(np.asarray(self.window_audio, dtype=np.float64) * 32768.0).astype('<i2')
+            self._engine.update_vectors(left.reshape(1, -1), want_features=False)
 
     def _read(self, stream):
         """What the reference appends to ``window_audio`` (network_runner.py:126-137) as a pair

@@ -52,8 +52,10 @@ _third_party('sonopy', sonopy_restated)
 _third_party('speechpy', speechpy_restated)
 try:
     import keras                                            # noqa: F401
-    PROVENANCE['keras'] = 'real keras %s available -- NOT used: no KerasRunner fixture path yet' % keras.__version__
+    PROVENANCE['keras'] = 'real keras %s: gen_keras_runner() writes keras_runner.npz from the reference\'s own KerasRunner' % keras.__version__
+    HAVE_KERAS = True
 except ImportError:
+    HAVE_KERAS = False
     PROVENANCE['keras'] = 'restated (oracle/keras_gru.py via the runner_cls seam), real Keras/TensorFlow not importable'
 PROVENANCE['glue'] = 'reference code, unmodified: /root/reference/precise/{network_runner,vectorization,params,util,threshold_decoder,functions}.py, runner/precise_runner/runner.py'
 PROVENANCE['numpy'] = np.__version__
@@ -196,6 +198,26 @@ def gen_float_audio(weights):
     save('listener_float_audio.npz', **out)
 
 
+def gen_keras_runner(weights):
+    """Only where the real Keras is importable (never in the offline build container): the reference's own model
+    builder and KerasRunner (/root/reference/precise/model.py:57-91, network_runner.py:77-95) on the synthetic weights
+    -- the fixture that pins oracle/keras_gru.py (K1-K8) to real Keras bits.  tests/test_oracle.py and the GPU suite
+    pick the file up when it exists."""
+    import tempfile
+    from precise.model import create_model, ModelParams          # reference code
+    from precise.network_runner import KerasRunner                # reference code
+    k, rk, b = weights['gru'][0]
+    model = create_model(None, ModelParams(skip_acc=True))
+    model.set_weights([k, rk, b, weights['dense_kernel'], weights['dense_bias']])
+    rng = np.random.default_rng(11)
+    x = rng.normal(0.0, 3.0, (64, 29, k.shape[0])).astype(np.float32)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, 'synthetic.net')
+        model.save(path)
+        y = KerasRunner(path).predict(x)
+    save('keras_runner.npz', inputs=x, outputs=np.asarray(y, np.float32))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if '--mels-only' in sys.argv:
@@ -306,6 +328,9 @@ def main():
     tr['rws_nochop_read'] = np.frombuffer(s.read(3, timeout=0.2), dtype=np.uint8)
     tr['rws_nochop_len'] = len(s)
     save('precise_runner.npz', **tr)
+
+    if HAVE_KERAS:
+        gen_keras_runner(weights)
 
     # --- weights used by every fixture -----------------------------------------------------
     k, rk, b = weights['gru'][0]

@@ -1002,6 +1002,23 @@ def test_listener_runner_can_be_replaced_after_construction(model_file, stock_we
     assert np.abs(a.mfccs - want_stock.mfccs).max() <= TOL_FEAT32
 
 
+def test_listener_mfccs_can_be_assigned(model_file, stock_weights):
+    """``listener.mfccs = window`` (a plain attribute in the reference, network_runner.py:104): the device's window
+    follows, the leftover samples stay, and the next updates agree with an oracle listener treated the same way."""
+    from mycroft_precise_amd.network_runner import Listener
+    pcm = synth.stream_pcm(8, 30 * 1024)
+    a, ref = Listener(model_file, 2048), ol.OracleListener(stock_weights)
+    window = np.random.default_rng(6).normal(0, 3, (29, 13)).astype(np.float32).astype(np.float64)
+    for u in range(30):
+        chunk = pcm[u * 1024:(u + 1) * 1024].tobytes()
+        if u == 11:
+            a.mfccs = window
+            ref.mfccs = window.copy()
+            assert len(a.window_audio) == len(ref.window_audio)
+        assert abs(a.update_raw(chunk) - ref.update_raw(chunk)) <= GUARD_RAW, u
+    assert np.abs(a.mfccs - ref.mfccs).max() <= TOL_FEAT32
+
+
 # ---- full-size properties (BASELINE configs[1]: 4096 streams on one GPU) ----------------------------
 def test_full_batch_4096_streams_properties(stock_weights):
     from mycroft_precise_amd.network_runner import BatchedListener

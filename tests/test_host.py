@@ -320,6 +320,20 @@ def test_pb_roundtrip_and_load_weights(tmp_path, stock_weights):
     assert 'export_net_to_npz.py' in str(ei.value)
     save_weights(str(tmp_path / 'model.net.npz'), stock_weights)
     w3 = load_weights(str(tmp_path / 'model.net'))
+    # a side-car that was exported from another version of the .net file (retraining rewrites it in place) is refused
+    import hashlib
+    net = tmp_path / 'model.net'
+    net.write_bytes(b'first version of the HDF5 file')
+    with np.load(str(tmp_path / 'model.net.npz')) as z:
+        arrays = {k: z[k] for k in z.files}
+    arrays['source_sha256'] = np.array(hashlib.sha256(net.read_bytes()).hexdigest())
+    with open(str(tmp_path / 'model.net.npz'), 'wb') as f:
+        np.savez(f, **arrays)
+    assert np.array_equal(load_weights(str(net))['dense_kernel'], stock_weights['dense_kernel'])
+    net.write_bytes(b'retrained: another file')
+    with pytest.raises(ValueError) as stale:
+        load_weights(str(net))
+    assert 'export_net_to_npz.py' in str(stale.value)
     assert np.array_equal(w3['gru'][0][0], stock_weights['gru'][0][0])
 
 

@@ -226,3 +226,18 @@ def test_golden_fixtures_carry_their_provenance(capsys):
         assert any(p.startswith('sonopy:') for p in prov) and any(p.startswith('keras:') for p in prov), f
         assert any(p.startswith('glue: reference code, unmodified') for p in prov), f
         print(f, '|', '; '.join(p for p in prov if not p.startswith('glue')))
+
+
+def test_keras_restatement_against_a_real_keras_fixture_when_present():
+    """tests/golden/keras_runner.npz exists only where oracle/gen_golden.py ran with the real Keras importable (it is
+    the reference's own KerasRunner on the synthetic weights).  When it is there, the restated GRU must match it."""
+    import os
+    from conftest import REPO
+    GOLDEN_DIR = os.path.join(REPO, 'tests', 'golden')
+    path = os.path.join(GOLDEN_DIR, 'keras_runner.npz')
+    if not os.path.isfile(path):
+        pytest.skip('no real-Keras fixture on this machine (Keras / TensorFlow are not installable offline)')
+    from oracle import keras_gru
+    g, w = np.load(path), np.load(os.path.join(GOLDEN_DIR, 'weights_stock_seed42.npz'))
+    weights = {'gru': [(w['kernel'], w['recurrent_kernel'], w['bias'])], 'dense_kernel': w['dense_kernel'], 'dense_bias': w['dense_bias']}
+    assert np.abs(keras_gru.predict(g['inputs'], weights) - g['outputs']).max() <= 1e-6

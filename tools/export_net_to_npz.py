@@ -42,7 +42,13 @@ def export(path, out=None):
                 dense = (arrays['kernel'], arrays.get('bias', np.zeros(arrays['kernel'].shape[1], np.float32)))
         if not gru or dense is None:
             raise SystemExit('%s: expected GRU layer(s) followed by a Dense(1) layer, found %r' % (path, layers))
-    arrays = {'n_layers': np.int32(len(gru)), 'dense_kernel': dense[0], 'dense_bias': dense[1]}
+    # what the side-car was made from: load_weights refuses it once the .net file has been rewritten (retraining
+    # through ModelCheckpoint / train_incremental rewrites <model>.net in place)
+    import hashlib
+    with open(path, 'rb') as fsrc:
+        digest = hashlib.sha256(fsrc.read()).hexdigest()
+    arrays = {'n_layers': np.int32(len(gru)), 'dense_kernel': dense[0], 'dense_bias': dense[1],
+              'source_sha256': np.array(digest)}
     for i, (k, rk, b) in enumerate(gru):
         arrays['kernel_%d' % i], arrays['recurrent_kernel_%d' % i], arrays['bias_%d' % i] = k, rk, b
     with open(out, 'wb') as fo:
