@@ -518,16 +518,19 @@ GruArgs gru_args(const pe_engine* e) {
     // 21.9 us (4 waves) vs 32.0 (1); 8192: 41.5 vs 33.5; 16384: 76.0 vs 55.3; 65536: 284 vs 199.
     // The DPP kernel (sixteen lanes per stream, no hand-offs) has the shortest chain of all, and needs the projection rows.
     const bool dpp_ok = e->proj_on && e->units >= 17 && e->units <= 20;
-    a.waves_per_tile = e->gru_waves ? e->gru_waves : (e->n_tiles <= e->n_cus ? 4 : 1);      // (16 = DPP kernel: opt-in)
-    if (a.waves_per_tile == 16 && !dpp_ok) a.waves_per_tile = 4;
-    if (e->prm.use_delta) a.waves_per_tile = 1;          // only the one-wave kernel carries the delta inputs
-    if (e->row_floats != kRowFloats) a.waves_per_tile = 1;       // ... and the 32-float feature rows
     // Stock width: the re-tiled shapes (three full tiles + partial sums; gru_cw_device.h) cut the four-wave kernel's
     // timestep (14.2 vs 16.3 us per window chain, stand-alone) but cost the one-wave kernel 5 % in the throughput
     // regime (two-pass MFMAs + reductions: 81.0 vs 77.3 us at 65 536 streams), so an engine takes ONE tiling for all
-    // of its launches -- every shape of a tiling agrees bit for bit -- by its size.
-    const bool cw_ok = e->cw_blob && e->row_floats == kRowFloats && !a.proj_ring && !a.bf16 && !e->wide && !e->prm.use_delta && a.waves_per_tile != 16;
-    const bool retile = cw_ok && (e->gru_tiling == 1 || (e->gru_tiling < 0 && e->n_tiles <= e->n_cus));
+    // of its launches -- every shape of a tiling agrees bit for bit -- by its size.  The critical-wave kernel still
+    // wins with two tiles per compute unit (8192 streams, fused: 272 vs 254 M windows/s against one wave per tile).
+    const bool cw_ok = e->cw_blob && e->row_floats == kRowFloats && !a.proj_ring && !a.bf16 && !e->wide && !e->prm.use_delta &&
+                       e->gru_waves != 16;
+    const bool retile = cw_ok && (e->gru_tiling == 1 || (e->gru_tiling < 0 && e->n_tiles <= 2 * e->n_cus));
+    const int auto_waves = retile ? (e->n_tiles <= 2 * e->n_cus ? 4 : 1) : (e->n_tiles <= e->n_cus ? 4 : 1);
+    a.waves_per_tile = e->gru_waves ? e->gru_waves : auto_waves;      // (16 = DPP kernel: opt-in)
+    if (a.waves_per_tile == 16 && !dpp_ok) a.waves_per_tile = 4;
+    if (e->prm.use_delta) a.waves_per_tile = 1;          // only the one-wave kernel carries the delta inputs
+    if (e->row_floats != kRowFloats) a.waves_per_tile = 1;       // ... and the 32-float feature rows
     a.cw = retile ? e->cw_blob : nullptr;
     return a;
 }
