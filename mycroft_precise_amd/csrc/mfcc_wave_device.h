@@ -37,9 +37,12 @@ namespace pe {
 // tools/gpu_sections.py reads them): shader-clock stamps of ONE wave; compiled out of the product.
 #ifdef PE_SECTION_TIMERS
 __device__ unsigned long long pe_dbg_timers[32];
+__device__ unsigned long long pe_dbg_wave_times[2 * 8192];      // start / end of every frame wave, 100 MHz wall clock
 #define PE_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) pe_dbg_timers[i] = __builtin_readcyclecounter(); } while (0)
+#define PE_WAVE_T(slot, which) do { if ((threadIdx.x & 63) == 0 && (slot) < 8192) pe_dbg_wave_times[2 * (slot) + (which)] = wall_clock64(); } while (0)
 #else
 #define PE_T(i) do { } while (0)
+#define PE_WAVE_T(slot, which) do { } while (0)
 #endif
 
 // One 8-byte LDS element per instruction.  Two adjacent 8-byte reads merged into ds_read2_b64 cost 8 LDS cycles against
@@ -528,6 +531,7 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
     };
 
     PE_T(0);
+    PE_WAVE_T(first_task + wave, 0);
     // ---- kernel top: everything whose address is known without a dependent load goes out first ------------------
     load_counters();
     const TabRegs tab_regs = wave_tables_issue<R>(wt);                 // table image for LDS
@@ -603,6 +607,7 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
         if (have) pcm = request_pcm(cur);
     }
     PE_T(15);
+    PE_WAVE_T(first_task + wave, 1);
 }
 
 // ---- stateless whole-buffer form (vectorize_raw): one frame per wave, float64 samples in -------------------------

@@ -28,6 +28,16 @@ for u in range(24):
     raw.pe_debug_read_timers(t, 32)
     t = np.array(t[:], dtype=np.int64)
     if u >= 16:
+        nw = 2048
+        wt = (ctypes.c_ulonglong * (2 * nw))()
+        raw.pe_debug_read_wave_times(wt, nw)
+        wt = np.array(wt[:], dtype=np.int64).reshape(nw, 2)
+        ok = wt[:, 1] > wt[:, 0]
+        st_, en = wt[ok, 0], wt[ok, 1]
+        t00 = st_.min()
+        print('   %d frame waves (100 MHz clock, us after the first wave start): starts min 0 / median %.2f / max %.2f; ends min %.2f / median %.2f / max %.2f; durations median %.2f / max %.2f'
+              % (ok.sum(), np.median(st_ - t00) / 100, (st_.max() - t00) / 100, (en.min() - t00) / 100, np.median(en - t00) / 100, (en.max() - t00) / 100,
+                 np.median(en - st_) / 100, (en - st_).max() / 100))
         q, kc, ke = eng.stream_state()
         order = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15]
         print('update %d (frames so far %d): ' % (u, kc[0]) + ', '.join('%s +%d' % (names[k], t[k] - t[0]) for k in order))
