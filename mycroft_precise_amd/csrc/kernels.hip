@@ -680,12 +680,18 @@ hipError_t launch_clear(const ClearArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+#ifdef PE_GRU_TIMERS
+extern "C" int pe_debug_read_gru_timers(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pe_gru_timers), sizeof(unsigned long long) * (n < 256 * 32 ? n : 256 * 32));
+}
+#endif
+
 #ifdef PE_SECTION_TIMERS
 extern "C" int pe_debug_read_timers(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pe_dbg_timers), sizeof(unsigned long long) * (n < 32 ? n : 32));
 }
 extern "C" int pe_debug_read_wave_times(unsigned long long* out, int n_waves) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pe_dbg_wave_times), sizeof(unsigned long long) * 2 * (n_waves < 8192 ? n_waves : 8192));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pe_dbg_wave_times), sizeof(unsigned long long) * 4 * (n_waves < 8192 ? n_waves : 8192));
 }
 #endif
 

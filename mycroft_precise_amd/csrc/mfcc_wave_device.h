@@ -37,9 +37,12 @@ namespace pe {
 // tools/gpu_sections.py reads them): shader-clock stamps of ONE wave; compiled out of the product.
 #ifdef PE_SECTION_TIMERS
 __device__ unsigned long long pe_dbg_timers[32];
-__device__ unsigned long long pe_dbg_wave_times[2 * 8192];      // start / end of every frame wave, 100 MHz wall clock
-#define PE_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) pe_dbg_timers[i] = __builtin_readcyclecounter(); } while (0)
-#define PE_WAVE_T(slot, which) do { if ((threadIdx.x & 63) == 0 && (slot) < 8192) pe_dbg_wave_times[2 * (slot) + (which)] = wall_clock64(); } while (0)
+__device__ unsigned long long pe_dbg_wave_times[4 * 8192];      // start / end of every frame wave: 100 MHz wall clock [0, 1], shader clock [2, 3]
+#ifndef PE_T_BLOCK
+#define PE_T_BLOCK 0            // which workgroup's first wave leaves the section stamps
+#endif
+#define PE_T(i) do { if (threadIdx.x == 0 && blockIdx.x == PE_T_BLOCK) pe_dbg_timers[i] = __builtin_readcyclecounter(); } while (0)
+#define PE_WAVE_T(slot, which) do { if ((threadIdx.x & 63) == 0 && (slot) < 8192) { pe_dbg_wave_times[4 * (slot) + (which)] = wall_clock64(); pe_dbg_wave_times[4 * (slot) + 2 + (which)] = __builtin_readcyclecounter(); } } while (0)
 #else
 #define PE_T(i) do { } while (0)
 #define PE_WAVE_T(slot, which) do { } while (0)

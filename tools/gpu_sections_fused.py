@@ -29,10 +29,12 @@ for u in range(24):
     t = np.array(t[:], dtype=np.int64)
     if u >= 16:
         nw = 2048
-        wt = (ctypes.c_ulonglong * (2 * nw))()
+        wt = (ctypes.c_ulonglong * (4 * nw))()
         raw.pe_debug_read_wave_times(wt, nw)
-        wt = np.array(wt[:], dtype=np.int64).reshape(nw, 2)
+        wt = np.array(wt[:], dtype=np.int64).reshape(nw, 4)
         ok = wt[:, 1] > wt[:, 0]
+        ghz = (wt[ok, 3] - wt[ok, 2]) / ((wt[ok, 1] - wt[ok, 0]) * 10.0) / 1e0
+        print('   shader clock over a frame wave\'s lifetime (cycle counter / wall clock): median %.2f GHz, min %.2f, max %.2f' % (np.median(ghz) / 1e3 * 1e3, ghz.min(), ghz.max()))
         st_, en = wt[ok, 0], wt[ok, 1]
         t00 = st_.min()
         print('   %d frame waves (100 MHz clock, us after the first wave start): starts min 0 / median %.2f / max %.2f; ends min %.2f / median %.2f / max %.2f; durations median %.2f / max %.2f'
