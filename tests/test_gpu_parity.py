@@ -926,6 +926,38 @@ def test_legacy_params_file_selects_speechpy_and_matches_reference(tmp_path, sto
         P.pr.__dict__.clear(); P.pr.__dict__.update(saved)
 
 
+def test_listener_on_a_params_file_with_other_front_end_sizes(tmp_path):
+    """The drop-in Listener on a model whose .params asks for n_fft = 1024, 40 filters, 20 coefficients
+    (params.py:150-165 -> network_runner.py:98-153): the general front end behind the unchanged Python surface,
+    including the `vectorizers` entry and `vectorize`."""
+    import warnings
+    from mycroft_precise_amd.network_runner import Listener
+    from mycroft_precise_amd import vectorization as V
+    from oracle import sonopy_restated as sr
+    kw = dict(n_fft=1024, n_filt=40, n_mfcc=20)
+    params = dict(window_t=0.1, hop_t=0.05, buffer_t=1.5, sample_rate=16000, sample_depth=2, vectorizer=2, use_delta=False, **kw)
+    w = synth.make_weights(n_in=20, units=(20,), seed=13)
+    saved = dict(P.pr.__dict__)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            path = _write_model(tmp_path, w, params, name='wide_front_end.npz')
+            lis = Listener(path, 2048)
+            assert (lis.pr.n_fft, lis.pr.n_filt, lis.pr.n_mfcc) == (1024, 40, 20)
+            ref = ol.OracleListener(w, ol.Params(**kw))
+            pcm = synth.stream_pcm(17, 36 * 1024)
+            for u in range(36):
+                chunk = pcm[u * 1024:(u + 1) * 1024].tobytes()
+                assert abs(lis.update_raw(chunk) - ref.update_raw(chunk)) <= GUARD_RAW, u
+            assert lis.mfccs.shape == (29, 20) and np.abs(lis.mfccs - ref.mfccs).max() <= TOL_FEAT32
+            audio = pcm[:30000].astype(np.float64) / 32768.0
+            want = sr.mfcc_spec(audio, 16000, (1600, 800), 1024, 40, 20)
+            assert np.abs(V.vectorize_raw(audio) - want).max() <= 1e-9
+            assert np.abs(V.vectorize(audio) - want[-29:]).max() <= 1e-9
+    finally:
+        P.pr.__dict__.clear(); P.pr.__dict__.update(saved)
+
+
 def test_speechpy_batched_streams_match_oracle(stock_weights):
     """The same front end for B lock-step streams (fused and two-launch, pe_update_many), vs the oracle."""
     from mycroft_precise_amd.network_runner import BatchedListener
