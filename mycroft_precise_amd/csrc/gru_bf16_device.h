@@ -32,7 +32,9 @@ __device__ __forceinline__ bf16x8 pack_bf16(const float (&v)[8]) {
 // MODE as in gru_device.h (kFeats / kRing / kRows).  Tiles: 0,1 = z, 2,3 = r, 4,5 = candidate.
 // DELTA (use_delta) is a compile-time switch: the first differences consume a loaded row as soon as it is loaded, which
 // would put a wait for the row prefetch in front of every timestep's MFMAs of the plain network as well.
-template <int MODE, bool DELTA = false>
+// RB: the ring holds bf16 rows (ring_precision = 1; a compile-time switch so that the deep row prefetch of that format
+// costs 4 registers per step of distance and the float32-row variant none)
+template <int MODE, bool DELTA = false, bool RB = false>
 __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, const int lane) {
 #pragma clang fp contract(off)      // every fusion in the gate arithmetic is spelled out: all kernel shapes round alike
     const int g = lane >> 4, j = lane & 15;
@@ -70,8 +72,8 @@ __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, 
             if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
         }
         first = ke - (uint32_t)T;
-        xbase = a.ring_bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.ring) + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats)
-                            : a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats;
+        xbase = RB ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.ring) + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats)
+                   : a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats;
     } else if (MODE == kRows) {
         const long long w = valid ? stream : 0;
         xbase = a.feats + ((size_t)w * a.row_stride) * kRowFloats;
@@ -86,20 +88,21 @@ __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, 
     // lane group g supplies k = 8 g .. 8 g + 7: features 8 (g & 1) .. + 7 (groups 0, 1), zeros or deltas (groups 2, 3).
     // A row is REQUESTED one timestep ahead and only turned into an operand (converted, differenced) at the top of the
     // step that uses it: anything that touches a loaded value earlier puts the L2 round trip into every timestep.
-    struct XRaw { float v[8]; uint4 u; };
+    constexpr bool from_bf16 = MODE == kRing && RB;
+    struct XRaw { float v[from_bf16 ? 1 : 8]; uint4 u; };
     const int fg = 8 * (g & 1);                                // first feature of this lane group's slice
     const bool wants = g < 2 || delta;
     auto request_x = [&](int t) -> XRaw {
         XRaw r;
         r.u = uint4{0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r.v[i] = 0.f;
+        for (int i = 0; i < (from_bf16 ? 1 : 8); ++i) r.v[i] = 0.f;
         const int tc = t < T ? t : T - 1;
-        if (MODE == kRing && a.ring_bf16) {
+        if constexpr (from_bf16) {
             // bf16 rows: the 16 bytes a lane group needs ARE its MFMA operand
             const __bf16* p = reinterpret_cast<const __bf16*>(xbase) + (size_t)((first + (uint32_t)tc) & mask) * kTileStreams * kRowFloats + fg;
             if (wants) r.u = *reinterpret_cast<const uint4*>(p);
-        } else if (MODE == kFeats) {
+        } else if constexpr (MODE == kFeats) {
             const float* p = xbase + (size_t)tc * frow + (g >= 2 ? a.n_in : 0);      // groups 2, 3: the batch's delta columns
 #pragma unroll
             for (int i = 0; i < 8; ++i) if (valid && wants && fg + i < a.n_in) r.v[i] = p[fg + i];
@@ -117,17 +120,16 @@ __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, 
 #pragma unroll
     for (int i = 0; i < 8; ++i) vprev[i] = 0.f;
     auto make_x = [&](const XRaw& r, int t) -> bf16x8 {
-        const bool from_bf16 = MODE == kRing && a.ring_bf16;
-        if (from_bf16 && !delta) return __builtin_bit_cast(bf16x8, r.u);             // (zeros for groups 2, 3)
-        if (MODE == kFeats) return pack_bf16(r.v);                                    // (an explicit batch carries its delta columns)
+        if constexpr (from_bf16 && !delta) return __builtin_bit_cast(bf16x8, r.u);   // (zeros for groups 2, 3)
         float v[8];
-        if (from_bf16) {
+        if constexpr (from_bf16) {
             const bf16x8 b = __builtin_bit_cast(bf16x8, r.u);
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = (float)b[i];
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = r.v[i];
+            if (MODE == kFeats) return pack_bf16(v);                                  // (an explicit batch carries its delta columns)
         }
         if (delta && g >= 2) {
             float d[8];
@@ -141,12 +143,20 @@ __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, 
     float h[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) h[i] = 0.f;
-    XRaw raw = request_x(0);
+    // Rows are requested PF timesteps ahead.  With one or two waves per SIMD (8192 streams per GPU: the shard of BASELINE
+    // configs[4]) nothing else hides the L2 / Infinity-Cache round trip of a row: one step ahead, every timestep lasted
+    // as long as that round trip (~980 cycles for 12 MFMAs of 16); bf16 rows cost 4 registers per step of distance.
+    constexpr int PF = from_bf16 ? 3 : 1;
+    XRaw raw[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) raw[d] = request_x(d);
     for (int t = 0; t < T; ++t) {
-        uint4 xu = __builtin_bit_cast(uint4, make_x(raw, t));
+        uint4 xu = __builtin_bit_cast(uint4, make_x(raw[0], t));
         if (g == 3) xu.w = 0x3F803F80u;                          // k = 30, 31: bf16(1.0) against the bias columns
         const bf16x8 x = __builtin_bit_cast(bf16x8, xu);
-        raw = request_x(t + 1);
+#pragma unroll
+        for (int d = 0; d + 1 < PF; ++d) raw[d] = raw[d + 1];
+        raw[PF - 1] = request_x(t + PF);
         f32x4 acc[6];
 #pragma unroll
         for (int tl = 0; tl < 6; ++tl) acc[tl] = mfma_bf16(wx[tl], x, zero4);

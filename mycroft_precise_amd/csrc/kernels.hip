@@ -70,14 +70,14 @@ __global__ __launch_bounds__(256) void gru_many_cw_kernel(const GruArgs a, const
     gru_tile_cw<false>(b, tile, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
 }
 
-template <bool DELTA>
+template <bool DELTA, bool RB>
 __global__ __launch_bounds__(64) void gru_many_bf16_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
     const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
     GruArgs b = a;
     b.st_ke = a.st_ke + (size_t)u * n_padded;
     b.out = a.out + (size_t)u * a.n_streams;
     b.predict_ke = 0;
-    gru_tile_bf16<kRing, DELTA>(b, tile, threadIdx.x);
+    gru_tile_bf16<kRing, DELTA, RB>(b, tile, threadIdx.x);
 }
 
 template <class R, class SH>
@@ -145,9 +145,9 @@ hipError_t launch_gru_wide(const WideArgs& a, int mode, hipStream_t s) {
 }
 
 // ---- GRU, bf16 operands: one wave per 16-stream tile --------------------------------------------------
-template <int MODE, bool DELTA>
+template <int MODE, bool DELTA, bool RB = false>
 __global__ __launch_bounds__(64) void gru_bf16_kernel(const GruArgs a) {
-    gru_tile_bf16<MODE, DELTA>(a, blockIdx.x, threadIdx.x);
+    gru_tile_bf16<MODE, DELTA, RB>(a, blockIdx.x, threadIdx.x);
 }
 
 // Dispatch order of the roles of a fused launch.  Workgroups are handed to the CUs in blockIdx order; `frames_first`
@@ -161,14 +161,14 @@ __device__ __forceinline__ int role_block(const int b, const int n_gru, const in
 }
 
 // fused update with the bf16 network role (four tiles per GRU workgroup, one wave each)
-template <class R, class SH, bool DELTA>
+template <class R, class SH, bool DELTA, bool RB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_bf16_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
                                                                 const int n_gru_blocks, const int n_frame_blocks, const int n_tiles, const int frames_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = role_block(blockIdx.x, n_gru_blocks, n_frame_blocks, frames_first);
     if (b < n_gru_blocks) {
         const int tile = b * 4 + (threadIdx.x >> 6);
-        if (tile < n_tiles) gru_tile_bf16<kRing, DELTA>(g, tile, threadIdx.x & 63);
+        if (tile < n_tiles) gru_tile_bf16<kRing, DELTA, RB>(g, tile, threadIdx.x & 63);
     } else if (b < n_gru_blocks + n_frame_blocks) {
         mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
     } else {
@@ -357,11 +357,13 @@ hipError_t launch_gru_small(const GruArgs& a, int from_ring, hipStream_t s) {
         const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
         if (tiles == 0) return hipSuccess;
         if (a.use_delta) {
-            if (from_ring == kRing) hipLaunchKernelGGL((gru_bf16_kernel<kRing, true>), dim3(tiles), dim3(64), 0, s, a);
+            if (from_ring == kRing && a.ring_bf16) hipLaunchKernelGGL((gru_bf16_kernel<kRing, true, true>), dim3(tiles), dim3(64), 0, s, a);
+            else if (from_ring == kRing) hipLaunchKernelGGL((gru_bf16_kernel<kRing, true>), dim3(tiles), dim3(64), 0, s, a);
             else if (from_ring == kRows) hipLaunchKernelGGL((gru_bf16_kernel<kRows, true>), dim3(tiles), dim3(64), 0, s, a);
             else hipLaunchKernelGGL((gru_bf16_kernel<kFeats, true>), dim3(tiles), dim3(64), 0, s, a);
         } else {
-            if (from_ring == kRing) hipLaunchKernelGGL((gru_bf16_kernel<kRing, false>), dim3(tiles), dim3(64), 0, s, a);
+            if (from_ring == kRing && a.ring_bf16) hipLaunchKernelGGL((gru_bf16_kernel<kRing, false, true>), dim3(tiles), dim3(64), 0, s, a);
+            else if (from_ring == kRing) hipLaunchKernelGGL((gru_bf16_kernel<kRing, false>), dim3(tiles), dim3(64), 0, s, a);
             else if (from_ring == kRows) hipLaunchKernelGGL((gru_bf16_kernel<kRows, false>), dim3(tiles), dim3(64), 0, s, a);
             else hipLaunchKernelGGL((gru_bf16_kernel<kFeats, false>), dim3(tiles), dim3(64), 0, s, a);
         }
@@ -411,8 +413,10 @@ hipError_t launch_gru_many(const GruArgs& a, int n_updates, int n_padded, hipStr
     const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
     if (tiles == 0 || n_updates == 0) return hipSuccess;
     if (a.bf16) {
-        if (a.use_delta) hipLaunchKernelGGL(gru_many_bf16_kernel<true>, dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
-        else hipLaunchKernelGGL(gru_many_bf16_kernel<false>, dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
+        if (a.use_delta && a.ring_bf16) hipLaunchKernelGGL((gru_many_bf16_kernel<true, true>), dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
+        else if (a.use_delta) hipLaunchKernelGGL((gru_many_bf16_kernel<true, false>), dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
+        else if (a.ring_bf16) hipLaunchKernelGGL((gru_many_bf16_kernel<false, true>), dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
+        else hipLaunchKernelGGL((gru_many_bf16_kernel<false, false>), dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
         return hipGetLastError();
     }
     switch (gru_small_regs(a.units)) {
@@ -484,12 +488,19 @@ static hipError_t launch_fused(const MfccStreamArgs<R>& m, const WaveTables<R>& 
     if (t.L.mel_pad != ShapeStock::MEL) return hipErrorInvalidValue;
     if (g.bf16) {
         const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
-        const int gru_blocks = (tiles + 3) / 4;
+        int gru_blocks = (tiles + 3) / 4;
         static const int ff_env = env_int("PE_FUSED_FRAMES_FIRST", -1);
         const int frames_first = ff_env >= 0 ? ff_env : (tiles >= 4 * n_cus);
-        const int fb = stream_frame_blocks(m.geo.n_streams, n_cus, frames_first ? 3 : 4);
-        if (g.use_delta) hipLaunchKernelGGL((fused_update_bf16_kernel<R, ShapeStock, true>), dim3(gru_blocks + fb + tiles), dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles, frames_first);
-        else hipLaunchKernelGGL((fused_update_bf16_kernel<R, ShapeStock, false>), dim3(gru_blocks + fb + tiles), dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles, frames_first);
+        int fb = stream_frame_blocks(m.geo.n_streams, n_cus, frames_first ? 3 : 4);
+        static const int skip = env_int("PE_FUSED_SKIP", 0);       // tuning aid (wrong results), as in launch_fused_rg
+        int book = tiles;
+        if (skip == 1) { fb = 0; book = 0; }
+        if (skip == 2) gru_blocks = 0;
+        const dim3 grid(gru_blocks + fb + book);
+        if (g.use_delta && g.ring_bf16) hipLaunchKernelGGL((fused_update_bf16_kernel<R, ShapeStock, true, true>), grid, dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles, frames_first);
+        else if (g.use_delta) hipLaunchKernelGGL((fused_update_bf16_kernel<R, ShapeStock, true, false>), grid, dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles, frames_first);
+        else if (g.ring_bf16) hipLaunchKernelGGL((fused_update_bf16_kernel<R, ShapeStock, false, true>), grid, dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles, frames_first);
+        else hipLaunchKernelGGL((fused_update_bf16_kernel<R, ShapeStock, false, false>), grid, dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles, frames_first);
         return hipGetLastError();
     }
     switch (gru_small_regs(g.units)) {
