@@ -165,10 +165,14 @@ template <class R, class SH, bool DELTA, bool RB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_bf16_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
                                                                 const int n_gru_blocks, const int n_frame_blocks, const int n_tiles, const int frames_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = role_block(blockIdx.x, n_gru_blocks, n_frame_blocks, frames_first);
+    // frames_first: bit 0 = frame workgroups dispatched first; bits 8.. = network tiles per workgroup (1, 2 or 4: with few
+    // tiles, one or two network waves on EVERY compute unit disturb the frame waves less than four on every second one)
+    const int tpw = frames_first >> 8;
+    const int b = role_block(blockIdx.x, n_gru_blocks, n_frame_blocks, frames_first & 1);
     if (b < n_gru_blocks) {
-        const int tile = b * 4 + (threadIdx.x >> 6);
-        if (tile < n_tiles) gru_tile_bf16<kRing, DELTA, RB>(g, tile, threadIdx.x & 63);
+        const int wave = threadIdx.x >> 6;
+        const int tile = b * tpw + wave;
+        if (wave < tpw && tile < n_tiles) gru_tile_bf16<kRing, DELTA, RB>(g, tile, threadIdx.x & 63);
     } else if (b < n_gru_blocks + n_frame_blocks) {
         mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
     } else {
@@ -488,10 +492,13 @@ static hipError_t launch_fused(const MfccStreamArgs<R>& m, const WaveTables<R>& 
     if (t.L.mel_pad != ShapeStock::MEL) return hipErrorInvalidValue;
     if (g.bf16) {
         const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
-        int gru_blocks = (tiles + 3) / 4;
+        static const int tpw_env = env_int("PE_BF16_TPW", 0);
+        const int tpw = tpw_env ? tpw_env : 4;
+        int gru_blocks = (tiles + tpw - 1) / tpw;
         static const int ff_env = env_int("PE_FUSED_FRAMES_FIRST", -1);
-        const int frames_first = ff_env >= 0 ? ff_env : (tiles >= 4 * n_cus);
-        int fb = stream_frame_blocks(m.geo.n_streams, n_cus, frames_first ? 3 : 4);
+        const int ff = ff_env >= 0 ? ff_env : (tiles >= 4 * n_cus);
+        const int frames_first = (ff & 1) | (tpw << 8);
+        int fb = stream_frame_blocks(m.geo.n_streams, n_cus, ff ? 3 : 4);
         static const int skip = env_int("PE_FUSED_SKIP", 0);       // tuning aid (wrong results), as in launch_fused_rg
         int book = tiles;
         if (skip == 1) { fb = 0; book = 0; }
