@@ -9,25 +9,25 @@
 // partial sums: lane (g, stream) accumulates, over the five source units 4 rho + g its lane group holds, the products
 // for each of the four target units 16 + a -- either as 5 v_mfma_f32_4x4x1_16B_f32 (two passes each; block = (lane
 // group, stream quad), A = U[4 rho + g][16 + (lane & 3)], B = the lane's own h[rho]) or as 20 v_fma_f32 with the same
-// operands in the same order (bit-identical: the f32 MFMA is an fma chain) -- and v_sum4 (two v_permlane swaps, three
-// adds, fixed order) reduces over the four lane groups and delivers unit 16 + g to lane group g.
+// operands in the same order (bit-identical: a K = 1 MFMA is one fma per output; NOT true of the K = 4 form: four chained
+// 4x4x1 MFMAs and one 16x16x4 round differently, measured) -- and v_sum4 (two v_permlane swaps, three adds, fixed order)
+// reduces over the four lane groups and delivers unit 16 + g to lane group g.
 //
 // Two shapes, bit-identical to each other:
-//   * gru_tile_v   one wave per tile (large batches): 15 eight-pass + 15 two-pass recurrent MFMAs per timestep where
-//                  gru_tile<5> issues 25 eight-pass ones;
-//   * gru_tile_cw  few tiles (one per compute unit at 4096 streams): the window is a chain of 29 timesteps x 2
+//   * gru_tile_v   one wave per tile: 15 eight-pass + 15 two-pass recurrent MFMAs per timestep where gru_tile<5> issues
+//                  25 eight-pass ones (what the other launches of a re-tiled engine use; in the throughput regime it is
+//                  5 % slower than gru_tile<5>, so large engines keep the classic tiling);
+//   * gru_tile_cw  few tiles (one or two per compute unit: up to 8192 streams): the window is a chain of 29 timesteps x 2
 //                  dependent mat-vecs, and what counts is the length of ONE timestep on ONE wave.  gru_tile_mw5 splits
 //                  the gate rows of a tile over four waves and pays two workgroup hand-offs (LDS write, s_barrier, LDS
 //                  read: ~190 cycles each, measured with tools/micro/gru_chain.hip) ON that chain every timestep.
-//                  Here the whole recurrence stays on wave R -- no LDS access and no other wave on its dependent
-//                  path -- and the other waves take everything that does NOT depend on h off it: the input
-//                  projections x.W + b of the four tiles (16 of the 41 MFMAs of a timestep), computed two timesteps
-//                  ahead and handed over as ready-made accumulator inits through double-buffered LDS mailboxes; one
-//                  s_barrier per timestep, which R reaches last.  The whole feature ring of the tile (32 slots x
-//                  1 KB) is staged in LDS by all four waves in the SAME round trip as the stream counters (which slot
-//                  is which timestep is decided afterwards, per lane), so the chain contains no global access.
-//                  (First attempt, measured and dropped: z on helper waves.  z needs h(t) and feeds h(t+1): two
-//                  hand-offs in series with a 5-MFMA chain = 630 cycles, longer than the ten MFMAs it removed from R.)
+//                  Here the chain stays on one wave (R: r of all units, candidate, blend); z -- needed only by the
+//                  blend, a whole timestep later -- and the input projections (16 of the 41 MFMAs of a timestep) are
+//                  taken off it by three helper waves; one s_barrier per timestep, which R reaches last.  The whole
+//                  feature ring of the tile (32 slots x 1 KB) is staged in LDS by all four waves in the SAME round trip
+//                  as the stream counters (which slot is which timestep is decided afterwards, per lane), so the chain
+//                  contains no global access.  The splits that were built and timed are listed at gru_tile_cw below
+//                  and in DESIGN.md 4.2b.
 #pragma once
 #include "gru_device.h"
 #include "gru_cw_pack.h"

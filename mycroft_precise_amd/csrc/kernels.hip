@@ -155,6 +155,9 @@ __global__ __launch_bounds__(64) void gru_bf16_kernel(const GruArgs a) {
 // that at large batches the two kinds are resident TOGETHER -- with the network first, its workgroups fill every
 // wave slot and the frame role only starts when they drain (the launch then costs the SUM of the two roles).
 // Returns the index in the canonical order [network | frames | bookkeeping].
+constexpr int kFramesFirst = 1, kBySimd = 2;       // launch flags of fused_update_kernel (its last argument)
+constexpr int kCwRoleSlot = 1984;                  // four ints of the GRU workgroup's LDS between the mailboxes and the staged ring
+static_assert(CwBox::END <= kCwRoleSlot && kCwRoleSlot + 4 <= CwLds::XR, "role slots overlap");
 __device__ __forceinline__ int role_block(const int b, const int n_gru, const int n_frames, const int frames_first) {
     if (!frames_first || b >= n_gru + n_frames) return b;
     return b < n_frames ? n_gru + b : b - n_frames;
@@ -230,7 +233,7 @@ template <class R, class SH, int RG, bool MW, bool PROJ, bool CW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
                                                            const int n_gru_blocks, const int n_frame_blocks, const int n_tiles, const int frames_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = role_block(blockIdx.x, n_gru_blocks, n_frame_blocks, frames_first);
+    const int b = role_block(blockIdx.x, n_gru_blocks, n_frame_blocks, frames_first & kFramesFirst);
     if (b < n_gru_blocks) {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #if defined(PE_PRIO_R)
@@ -241,7 +244,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
         if constexpr (CW) {                     // stock width, re-tiled (gru_cw_device.h)
             static_assert(RG == 5 && !PROJ, "the re-tiled shapes exist for the stock width, without projection rows");
             if (MW) {
-                gru_tile_cw<false>(g, b, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
+                // kBySimd: the four roles sit on SIMDs 0..3 in a fixed order (R on 0, Z1, Z2, P) so that the frame waves of
+                // this compute unit know what runs beside them (mfcc_frame_tasks<.., true>).  Roles follow the SIMDs only
+                // if the four waves sit on four different ones (they do: a workgroup's waves are spread round-robin;
+                // checked, not assumed).
+                int role = wave;
+                if (frames_first & kBySimd) {
+                    int* const slot = reinterpret_cast<int*>(smem) + kCwRoleSlot;
+                    const int simd = wave_simd_id();
+                    if ((threadIdx.x & 63) == 0) slot[wave] = simd;
+                    __syncthreads();
+                    if (((1 << slot[0]) | (1 << slot[1]) | (1 << slot[2]) | (1 << slot[3])) == 15) role = simd;
+                }
+                gru_tile_cw<false>(g, b, role, threadIdx.x & 63, reinterpret_cast<float*>(smem));
             } else {
                 const int tile = b * 4 + wave;
                 if (tile < n_tiles) gru_tile_v<kRing>(g, tile, threadIdx.x & 63);
@@ -253,7 +268,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
             if (tile < n_tiles) gru_tile<RG, kRing, PROJ>(g, tile, threadIdx.x & 63);
         }
     } else if (b < n_gru_blocks + n_frame_blocks) {
-        mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
+        if constexpr (CW && MW) {
+            if (frames_first & kBySimd) mfcc_frame_tasks<R, SH, true>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
+            else mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
+        } else {
+            mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
+        }
     } else {
         mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
     }
@@ -445,12 +465,15 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
     // 31.8 / 103.8 us against 35.5 / 109.0 us network-first; the float64 front end gains nothing either way -- its
     // FP64 multiply-adds and the MFMAs do not overlap on a SIMD)
     static const int ff_env = env_int("PE_FUSED_FRAMES_FIRST", -1);
-    const int frames_first = ff_env >= 0 ? ff_env : (g.waves_per_tile != 4 && tiles >= 4 * n_cus);
+    // one network tile per compute unit on the critical-wave kernel: roles by SIMD, frame slots split by SIMD load
+    static const int bs_env = env_int("PE_BY_SIMD", -1);
+    const bool by_simd = g.cw && g.waves_per_tile == 4 && cw_four_waves_ok(g) && tiles <= n_cus && bs_env != 0;
+    const int frames_first = (ff_env >= 0 ? ff_env : (g.waves_per_tile != 4 && tiles >= 4 * n_cus)) | (by_simd ? kBySimd : 0);
     // resident frame workgroups per compute unit: at one network tile per compute unit the launch lasts as long as the
     // network's dependent chain, and two frame workgroups (two streams per wave, the second one's samples prefetched)
     // disturb that chain less than four (measured, 4096 streams: 20.6 vs 20.9 us in phase, 21.1 vs 22.5 us with
     // desynchronised streams); larger batches want every wave slot
-    const int fb = stream_frame_blocks(m.geo.n_streams, n_cus, tiles <= n_cus ? 2 : frames_first ? 3 : 4);
+    const int fb = stream_frame_blocks(m.geo.n_streams, n_cus, tiles <= n_cus ? 2 : (frames_first & kFramesFirst) ? 3 : 4);
     int gru_blocks = g.waves_per_tile == 4 ? tiles : (tiles + 3) / 4;
     static const int skip = env_int("PE_FUSED_SKIP", 0);       // tuning aid (wrong results): 1 = launch without the MFCC roles, 2 = without the network role, 3 = without the bookkeeping role
     int fb_ = fb, book = tiles;

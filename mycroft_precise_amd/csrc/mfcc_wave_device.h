@@ -42,7 +42,7 @@ __device__ unsigned long long pe_dbg_wave_times[4 * 8192];      // start / end o
 #define PE_T_BLOCK 0            // which workgroup's first wave leaves the section stamps
 #endif
 #define PE_T(i) do { if (threadIdx.x == 0 && blockIdx.x == PE_T_BLOCK) pe_dbg_timers[i] = __builtin_readcyclecounter(); } while (0)
-#define PE_WAVE_T(slot, which) do { if ((threadIdx.x & 63) == 0 && (slot) < 8192) { pe_dbg_wave_times[4 * (slot) + (which)] = wall_clock64(); pe_dbg_wave_times[4 * (slot) + 2 + (which)] = __builtin_readcyclecounter(); } } while (0)
+#define PE_WAVE_T(slot, which) do { if ((threadIdx.x & 63) == 0 && (slot) < 8192) { pe_dbg_wave_times[4 * (slot) + (which)] = wall_clock64(); pe_dbg_wave_times[4 * (slot) + 2 + (which)] = (__builtin_readcyclecounter() & ~3ull) | (unsigned long long)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3); } } while (0)
 #else
 #define PE_T(i) do { } while (0)
 #define PE_WAVE_T(slot, which) do { } while (0)
@@ -403,7 +403,15 @@ __device__ __attribute__((noinline)) RawFrame fetch_frame_slow(const FrameTask<R
     return out;
 }
 
-template <class R, class SH>
+// SIMD of the compute unit this wave runs on (HW_ID.SIMD_ID: s_getreg_b32 hwreg(HW_REG_HW_ID, 4, 2))
+__device__ __forceinline__ int wave_simd_id() { return (int)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3); }
+
+// BY_SIMD (fused launch at one network tile per compute unit): the network workgroup of the compute unit has its four
+// roles on SIMDs 0..3 in a fixed order (fused_update_kernel), and a frame wave's float64 multiply-adds wait while the
+// matrix pipe of its SIMD runs the MFMAs of that role (R 37 % of the time, Z1 33 %, P 29 %, Z2 20 %: measured frame
+// waves run 1.1x to 2x longer depending on the SIMD).  So the four waves of a frame workgroup split the workgroup's
+// slots 3 : 4 : 5 : 4 by the SIMD they sit on instead of evenly.
+template <class R, class SH, bool BY_SIMD = false>
 __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, const WaveTables<R>& wt, unsigned char* smem,
                                                  const int first_task, const int task_stride) {
     using K = RealK<R>;
@@ -426,8 +434,31 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
     const int n_waves = task_stride;
     const long long n_slots = 2LL * geo.n_streams;
     const int per_wave = (int)((n_slots + n_waves - 1) / n_waves);
-    const long long sg_begin = (long long)(first_task + wave) * per_wave;
-    const long long sg_end = sg_begin + per_wave < n_slots ? sg_begin + per_wave : n_slots;
+    long long sg_begin = (long long)(first_task + wave) * per_wave;
+    long long sg_end = sg_begin + per_wave < n_slots ? sg_begin + per_wave : n_slots;
+    if constexpr (BY_SIMD) {
+        // one int per wave at the base of its (not yet used) scratch: which SIMD each wave of this workgroup sits on
+        int* const slot = reinterpret_cast<int*>(smem + (wt.L.total - wave_lds_skip(wt.L)));
+        constexpr int kStride = kWaveScratchReals * (int)sizeof(R) / 4;
+        const int simd = wave_simd_id();
+        if (lane == 0) slot[wave * kStride] = simd;
+        __syncthreads();
+        int seen = 0;
+#pragma unroll
+        for (int w = 0; w < kFrameWaves; ++w) seen |= 1 << slot[w * kStride];
+        __syncthreads();                    // (the slots are scratch again)
+        if (seen == 15) {                   // four waves on four SIMDs (always, as far as observed; else: the even split)
+            const long long wg_begin = (long long)first_task * per_wave;
+            long long wg_end = wg_begin + (long long)kFrameWaves * per_wave;
+            wg_end = wg_end < n_slots ? wg_end : n_slots;
+            const long long len = wg_end > wg_begin ? wg_end - wg_begin : 0;
+            // cumulative shares in sixteenths by SIMD: 3 | 4 | 5 | 4 (the wave on SIMD 0 sits beside the critical wave)
+            const int lo16 = simd == 0 ? 0 : simd == 1 ? 3 : simd == 2 ? 7 : 12;
+            const int hi16 = simd == 0 ? 3 : simd == 1 ? 7 : simd == 2 ? 12 : 16;
+            sg_begin = wg_begin + (len * lo16 + 8) / 16;
+            sg_end = wg_begin + (len * hi16 + 8) / 16;
+        }
+    }
     const int s_begin = (int)(sg_begin >> 1);
     const int s_end = sg_end > sg_begin ? (int)((sg_end + 1) >> 1) : s_begin;
     int base = s_begin, kb_next = -1;

@@ -40,6 +40,9 @@ for u in range(24):
         print('   %d frame waves (100 MHz clock, us after the first wave start): starts min 0 / median %.2f / max %.2f; ends min %.2f / median %.2f / max %.2f; durations median %.2f / max %.2f'
               % (ok.sum(), np.median(st_ - t00) / 100, (st_.max() - t00) / 100, (en.min() - t00) / 100, np.median(en - t00) / 100, (en.max() - t00) / 100,
                  np.median(en - st_) / 100, (en - st_).max() / 100))
+        simd = wt[ok, 2] & 3
+        dur = (wt[ok, 1] - wt[ok, 0]) / 100.0
+        print('   frame-wave duration by the SIMD it sits on (median / max us): ' + ', '.join('SIMD %d: %.2f / %.2f (%d waves)' % (k, np.median(dur[simd == k]), dur[simd == k].max(), (simd == k).sum()) for k in range(4)))
         q, kc, ke = eng.stream_state()
         order = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15]
         print('update %d (frames so far %d): ' % (u, kc[0]) + ', '.join('%s +%d' % (names[k], t[k] - t[0]) for k in order))
