@@ -302,7 +302,25 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
     f32x4 stage[kCwSlots / 4];
 #pragma unroll
     for (int i = 0; i < kCwSlots / 4; ++i) stage[i] = *reinterpret_cast<const f32x4*>(xbase + (size_t)(wave + 4 * i) * kTileStreams * kRowFloats);
-    const uint32_t first = cw_window_end(a, stream) - (uint32_t)T;
+    // (the counters are only REQUESTED here: the arithmetic on them -- first_slot() -- comes after a role has requested its
+    //  weights.  Loads return in order: consumed up here, the counters made every role wait for its share of the ring before
+    //  the weight loads even went out, a second round trip in the prologue: 4.1 k cycles instead of ~2.3 k)
+    const uint32_t ke0 = a.st_ke[stream];                 // counters exist for padded streams too
+    int q0 = 0;
+    uint32_t kc0 = 0;
+    if (a.predict_ke) { q0 = a.st_q[stream]; kc0 = a.st_kc[stream]; }
+    uint32_t first = 0;
+    auto first_slot = [&]() {                               // cw_window_end(a, stream) - T, from the values requested above
+        uint32_t ke = ke0;
+        if (a.predict_ke) {
+            const int avail = q0 + a.chunk;
+            const int nnew = avail >= a.frame_len ? 1 + (avail - a.frame_len) / a.hop : 0;
+            const int qn = avail - nnew * a.hop;
+            const int m = qn + a.hop * (int)(kc0 + (uint32_t)nnew - ke);
+            if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
+        }
+        first = ke - (uint32_t)T;
+    };
     float* const XR = S + CwLds::XR;
     float* const L4 = S + lane * 4;
     float* const L2 = S + lane * 2;
@@ -435,6 +453,7 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
         for (int rho = 0; rho < 5; ++rho) wrZ[rho] = cw[CwPack::WR + (0 * 5 + rho) * 64 + lane];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { wx[kk] = cw[CwPack::WX + (kTZ * 4 + kk) * 64 + lane]; bb[kk] = cw[CwPack::BIAS + (kTZ * 4 + kk) * 64 + lane]; }
+        first_slot();
         stage_out();
 #pragma unroll
         for (int rho = 0; rho < 5; ++rho) cw_pin(wrZ[rho]);
@@ -466,6 +485,7 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
         load_v(0, wfz, wvz);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { wx[kk] = cw[CwPack::WX + (kTV * 4 + kk) * 64 + lane]; bb[kk] = cw[CwPack::BIAS + (kTV * 4 + kk) * 64 + lane]; }
+        first_slot();
         stage_out();
         pin_v(wfz, wvz);
 #pragma unroll
@@ -501,6 +521,7 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
             c0[kk] = cw[CwPack::BIAS + (kTX * 4 + kk) * 64 + lane];
             c1[kk] = cw[CwPack::BIAS + (kTC * 4 + kk) * 64 + lane];
         }
+        first_slot();
         stage_out();
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { cw_pin(w0[kk]); cw_pin(w1[kk]); cw_pin(c0[kk]); cw_pin(c1[kk]); }

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
         const int tile = b * tpw + wave;
         if (wave < tpw && tile < n_tiles) gru_tile_bf16<kRing, DELTA, RB>(g, tile, threadIdx.x & 63);
     } else if (b < n_gru_blocks + n_frame_blocks) {
-        mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
+        mfcc_frame_tasks<R, SH, true>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
     } else {
         mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
     }
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         gru_tile_dpp(g, b, wave, threadIdx.x & 63);
     } else if (b < n_gru_blocks + n_frame_blocks) {
-        mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
+        mfcc_frame_tasks<R, SH, true>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
     } else {
         mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
     }
@@ -268,12 +268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
             if (tile < n_tiles) gru_tile<RG, kRing, PROJ>(g, tile, threadIdx.x & 63);
         }
     } else if (b < n_gru_blocks + n_frame_blocks) {
-        if constexpr (CW && MW) {
-            if (frames_first & kBySimd) mfcc_frame_tasks<R, SH, true>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
-            else mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
-        } else {
-            mfcc_frame_tasks<R, SH>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
-        }
+        mfcc_frame_tasks<R, SH, true, !PROJ>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves, CW && MW && (frames_first & kBySimd));
     } else {
         mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
     }

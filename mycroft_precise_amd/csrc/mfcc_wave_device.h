@@ -77,20 +77,27 @@ __host__ __device__ inline size_t wave_lds_bytes(int real_size, const pe_wave::L
 
 // workgroup-wide copy of the table image into LDS in two steps, so that the global loads can be issued at the very
 // top of a kernel and the LDS stores + barrier placed where the tables are first needed
-constexpr int kTabRegs = PE_TW_LDS == 2 ? 5 : 2;    // 16-byte pieces per thread held in flight (256 threads: 20 / 8 KB)
-struct TabRegs { uint4 v[kTabRegs]; };
+// 16-byte pieces per thread held in flight (256 threads: 20 / 12 / 8 KB; the stock float64 image is 16.6 KB, the float32 one 8.3 KB)
+template <class R> constexpr int kTabRegs = PE_TW_LDS == 2 ? (sizeof(R) == 8 ? 5 : 3) : 2;
+struct TabRegs { uint4 v0, v1, v2, v3, v4; };       // (named members, not an array: the array form ended up in scratch memory)
 
+// UNCONDITIONAL loads from clamped indices, unconditional stores to clamped indices: a load inside an exec-masked block
+// makes the compiler wait for every outstanding load (s_waitcnt vmcnt(0)) before the next such block -- the five pieces,
+// the stream counters and the first frame's samples were seven round trips in series at the top of every frame wave
+// (ISA, round 3).  The surplus threads hold piece 0 and store it where it belongs.
 template <class R>
 __device__ __forceinline__ TabRegs wave_tables_issue(const WaveTables<R>& g) {
     const int skip = wave_lds_skip(g.L);
     const int n16 = (g.L.total - skip) >> 4;
     const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(g.blob) + skip);
-    TabRegs t;
-#pragma unroll
-    for (int k = 0; k < kTabRegs; ++k) {
+    auto piece = [&](int k) -> uint4 {
         const int i = threadIdx.x + k * blockDim.x;
-        t.v[k] = i < n16 ? src[i] : uint4{0, 0, 0, 0};
-    }
+        return src[i < n16 ? i : 0];
+    };
+    TabRegs t;
+    t.v0 = piece(0); t.v1 = piece(1);
+    if constexpr (kTabRegs<R> > 2) t.v2 = piece(2);
+    if constexpr (kTabRegs<R> > 3) { t.v3 = piece(3); t.v4 = piece(4); }
     return t;
 }
 
@@ -100,12 +107,14 @@ __device__ __forceinline__ void wave_tables_commit(unsigned char* smem, const Wa
     const int n16 = (g.L.total - skip) >> 4;
     const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(g.blob) + skip);
     uint4* dst = reinterpret_cast<uint4*>(smem);
-#pragma unroll
-    for (int k = 0; k < kTabRegs; ++k) {
+    auto put = [&](int k, const uint4& v) {
         const int i = threadIdx.x + k * blockDim.x;
-        if (i < n16) dst[i] = t.v[k];
-    }
-    for (int i = threadIdx.x + kTabRegs * blockDim.x; i < n16; i += blockDim.x) dst[i] = src[i];     // (larger filterbanks)
+        dst[i < n16 ? i : 0] = v;
+    };
+    put(0, t.v0); put(1, t.v1);
+    if constexpr (kTabRegs<R> > 2) put(2, t.v2);
+    if constexpr (kTabRegs<R> > 3) { put(3, t.v3); put(4, t.v4); }
+    for (int i = threadIdx.x + kTabRegs<R> * blockDim.x; i < n16; i += blockDim.x) dst[i] = src[i];     // (larger filterbanks)
     __syncthreads();
 }
 
@@ -384,20 +393,21 @@ struct PcmRegs { int a0, a1, a2, a3, b0, b1, b2, b3; bool two; };
 // the rare PCM path (odd chunk lengths, unaligned buffers, chunks shorter than a frame): one sample at a time
 struct RawFrame { int v[4]; };
 
-template <class R>
-__device__ __attribute__((noinline)) RawFrame fetch_frame_slow(const FrameTask<R> f, int lane, int flen, int C, size_t update_stride) {
+// (plain arguments: a FrameTask passed by value reserved 48 bytes of private memory per lane in the calling kernels)
+__device__ __attribute__((noinline)) RawFrame fetch_frame_slow(const int16_t* car, const int16_t* row, int vb, int q, int off0,
+                                                               int lane, int flen, int C, size_t update_stride) {
     RawFrame out;
     auto vsample = [&](int vv) -> int {
-        if (vv < f.q) return (int)f.car[vv];
-        int w = f.off0 + (vv - f.vb);
-        const int16_t* r = f.row;
+        if (vv < q) return (int)car[vv];
+        int w = off0 + (vv - vb);
+        const int16_t* r = row;
         while (w >= C) { w -= C; r += update_stride; }
         return (int)r[w];
     };
     for (int a4 = 0; a4 < 4; ++a4) {
         const int n = 2 * (lane + 64 * a4);
-        const int lo = n < flen ? (vsample(f.vb + n) & 0xffff) : 0;
-        const int hi = n + 1 < flen ? vsample(f.vb + n + 1) : 0;
+        const int lo = n < flen ? (vsample(vb + n) & 0xffff) : 0;
+        const int hi = n + 1 < flen ? vsample(vb + n + 1) : 0;
         out.v[a4] = lo | (hi << 16);
     }
     return out;
@@ -411,14 +421,17 @@ __device__ __forceinline__ int wave_simd_id() { return (int)(__builtin_amdgcn_s_
 // matrix pipe of its SIMD runs the MFMAs of that role (R 37 % of the time, Z1 33 %, P 29 %, Z2 20 %: measured frame
 // waves run 1.1x to 2x longer depending on the SIMD).  So the four waves of a frame workgroup split the workgroup's
 // slots 3 : 4 : 5 : 4 by the SIMD they sit on instead of evenly.
-template <class R, class SH, bool BY_SIMD = false>
+// SINGLE: the call is one update (n_updates == 1: every fused launch) and, NOPROJ, stores no projection rows: both known at
+// compile time there, which removes the several-updates arithmetic (chunk index of a frame, a frame's tail in the next
+// update's row) and the projection block from the frame loop.
+template <class R, class SH, bool SINGLE = false, bool NOPROJ = false>
 __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, const WaveTables<R>& wt, unsigned char* smem,
-                                                 const int first_task, const int task_stride) {
+                                                 const int first_task, const int task_stride, const bool by_simd = false) {
     using K = RealK<R>;
     const StreamGeom& geo = a.geo;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_kb = a.n_frame_rows;
-    const int C = a.chunk, hop = geo.hop, flen = geo.frame_len, slots = geo.ring_slots, U = a.n_updates;
+    const int C = a.chunk, hop = geo.hop, flen = geo.frame_len, slots = geo.ring_slots, U = SINGLE ? 1 : a.n_updates;
     const size_t update_stride = (size_t)geo.n_streams * C;
     // dword loads of (even, odd) sample pairs need every quantity that shifts a pair boundary to be even; a frame
     // may cross at most one chunk boundary (always true for a single update: its samples are carry ++ one chunk)
@@ -436,7 +449,7 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
     const int per_wave = (int)((n_slots + n_waves - 1) / n_waves);
     long long sg_begin = (long long)(first_task + wave) * per_wave;
     long long sg_end = sg_begin + per_wave < n_slots ? sg_begin + per_wave : n_slots;
-    if constexpr (BY_SIMD) {
+    if (by_simd) {
         // one int per wave at the base of its (not yet used) scratch: which SIMD each wave of this workgroup sits on
         int* const slot = reinterpret_cast<int*>(smem + (wt.L.total - wave_lds_skip(wt.L)));
         constexpr int kStride = kWaveScratchReals * (int)sizeof(R) / 4;
@@ -466,8 +479,9 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
     unsigned long long due = 0;
     auto load_counters = [&]() {
         const int s = base + lane;
-        vq = 0; vkc = 0;
-        if (s < s_end) { vq = a.st_q[s]; vkc = (int)a.st_kc[s]; }
+        const int sc = s < s_end ? s : 0;                       // (unconditional loads: see wave_tables_issue)
+        vq = a.st_q[sc]; vkc = (int)a.st_kc[sc];
+        vq = s < s_end ? vq : 0; vkc = s < s_end ? vkc : 0;
     };
     auto lane_frames = [&]() {                                // (after the counters arrived)
         const int avail = vq + U * C;
@@ -502,7 +516,7 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
         f.ring_row = a.ring_bf16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(a.ring) + cell * kRowFloats)
                                  : a.ring + cell * kRowFloats;
         // projection rows: [tile][slot] blocks of 4 KB laid out [output tile][stream][g][q] (gru_device.h: proj_base)
-        f.proj_row = a.proj_ring ? a.proj_ring + ((size_t)tile * slots + slot) * kTileStreams * kProjRow + (size_t)j * 16 : nullptr;
+        f.proj_row = (!NOPROJ && a.proj_ring) ? a.proj_ring + ((size_t)tile * slots + slot) * kTileStreams * kProjRow + (size_t)j * 16 : nullptr;
         return true;
     };
     // The frame's samples as int16 pairs: point n = lane + 64 a4 <-> samples 2n, 2n+1 (zero beyond the frame length).
@@ -528,7 +542,7 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
         r.two = false;
         if (pairs && (f.q & 1) == 0) {
             const int qa = f.q - f.vb;
-            const int over = f.off0 + flen - C;
+            const int over = SINGLE ? 0 : f.off0 + flen - C;      // (a single update's frames end inside its chunk)
             const int in_row = f.off0 + flen < C ? f.off0 + flen : C;
             const __amdgpu_buffer_rsrc_t rb = wave_rsrc(f.row, 2 * (in_row > 0 ? in_row : 0));
             const int shift = 2 * f.off0;
@@ -549,7 +563,7 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
             }
             return r;
         }
-        const RawFrame sl = fetch_frame_slow<R>(f, lane, flen, C, update_stride);
+        const RawFrame sl = fetch_frame_slow(f.car, f.row, f.vb, f.q, f.off0, lane, flen, C, update_stride);
         r.a0 = sl.v[0]; r.a1 = sl.v[1]; r.a2 = sl.v[2]; r.a3 = sl.v[3];
         return r;
     };
@@ -567,8 +581,10 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
     PE_T(0);
     PE_WAVE_T(first_task + wave, 0);
     // ---- kernel top: everything whose address is known without a dependent load goes out first ------------------
+    // the table image for LDS goes out first: loads return in order, and these (L2 hits after a compute unit's first
+    // workgroup) must not queue behind the stream counters and samples, which come from farther away
+    const TabRegs tab_regs = wave_tables_issue<R>(wt);
     load_counters();
-    const TabRegs tab_regs = wave_tables_issue<R>(wt);                 // table image for LDS
     // this lane's twiddles, straight from the global image (once per wave)
 #if PE_TW_LDS == 2
     const pe_wave::LaneConsts<R> lc{};
@@ -577,14 +593,15 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
 #endif
     const pe_wave::Tab<R> tab = pe_wave::bind<R>(smem, wt.L, wave_lds_skip(wt.L));
     R* const S = reinterpret_cast<R*>(smem + (wt.L.total - wave_lds_skip(wt.L))) + (size_t)wave * kWaveScratchReals;
-    // the wave's first frame is requested BEFORE the table image is waited for: the HBM round trip of its samples and
-    // the L2 round trip of the tables overlap (a 4096-stream update is one or two frames per wave: this is its latency)
+    // tables -> LDS first, then the counters (both on their way since the top; measured 16.40 vs 16.48 us per fused update
+    // against requesting the first frame before the image is stored: the workgroup barrier in the commit is passed
+    // earlier by every wave), then the first frame's samples
+    wave_tables_commit<R>(smem, wt, tab_regs);
     lane_frames();
     FrameTask<R> cur;
     bool have = next_frame(cur);
     PcmRegs pcm;
     if (have) pcm = request_pcm(cur);
-    wave_tables_commit<R>(smem, wt, tab_regs);
     const LaneRuns lr = lane_runs(tab, lane, geo.n_filt);
     wave_scratch_init(S, lane);
     PE_T(1);
@@ -616,7 +633,7 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
             const float xf = __shfl(mine, (lane & 15) * 4, 64);
             xf_prev = xf; row_prev = cur.ring_row;
             PE_T(10);
-            if (cur.proj_row) {
+            if (!NOPROJ && cur.proj_row) {
                 // input projection of this frame, once, for every window it will appear in: row[o] = b[o] + sum_c x[c] W[c][o]
                 // (o in MFMA slot order); the rounded float32 features are what the network would have read
                 float* XF = reinterpret_cast<float*>(S);

@@ -9,7 +9,7 @@ from mycroft_precise_amd import _lib, synth
 from mycroft_precise_amd.params import pr
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-dbg = os.path.join(REPO, 'mycroft_precise_amd', 'csrc', 'build', 'libprecise_engine_dbg.so')
+dbg = os.environ.get('PE_DBG_LIB') or os.path.join(REPO, 'mycroft_precise_amd', 'csrc', 'build', 'libprecise_engine_dbg.so')
 _lib._lib = None
 _lib.LIB_PATH = dbg
 lib = _lib.load()
