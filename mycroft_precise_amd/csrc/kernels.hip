@@ -308,11 +308,17 @@ static int stream_frame_blocks(int n_streams, int n_cus, int per_cu_default = 4)
 
 template <class R>
 static size_t frame_lds(const WaveTables<R>& t) { return wave_lds_bytes(sizeof(R), t.L, kFrameWaves); }
+// the kernels address the table image with the compile-time section offsets of their shape (mfcc_wave_device.h: wave_bind)
+template <class R>
+static bool blob_matches_shape(const WaveTables<R>& t) {
+    return t.L.mel_pad == ShapeStock::MEL ? shape_layout_matches<R, ShapeStock>(t.L) : shape_layout_matches<R, ShapeAny>(t.L);
+}
 
 template <class R>
 static hipError_t launch_mfcc(const MfccStreamArgs<R>& a, const WaveTables<R>& t, int n_cus, hipStream_t s) {
     const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
     const int fb = stream_frame_blocks(a.geo.n_streams, n_cus);
+    if (!blob_matches_shape(t)) return hipErrorInvalidValue;
     static const int skip = env_int("PE_MFCC_SKIP", 0);        // tuning aid (wrong results): 1 = frame role only, 2 = bookkeeping role only
     if (skip == 1) { hipLaunchKernelGGL((mfcc_kernel<R, ShapeStock>), dim3(fb), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb); return hipGetLastError(); }
     if (skip == 2) { hipLaunchKernelGGL((mfcc_kernel<R, ShapeStock>), dim3(tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, 0); return hipGetLastError(); }
@@ -326,6 +332,7 @@ hipError_t launch_mfcc_f32(const MfccStreamArgs<float>& a, const WaveTables<floa
 template <class R>
 static hipError_t launch_offline(const MfccOfflineArgs<R>& a, const WaveTables<R>& t, int n_cus, hipStream_t s) {
     if (a.n_frames <= 0) return hipSuccess;
+    if (!blob_matches_shape(t)) return hipErrorInvalidValue;
     if (t.L.mel_pad == ShapeStock::MEL) hipLaunchKernelGGL((mfcc_offline_kernel<R, ShapeStock>), dim3(frame_blocks(a.n_frames, n_cus)), dim3(64 * kFrameWaves), frame_lds(t), s, a, t);
     else hipLaunchKernelGGL((mfcc_offline_kernel<R, ShapeAny>), dim3(frame_blocks(a.n_frames, n_cus)), dim3(64 * kFrameWaves), frame_lds(t), s, a, t);
     return hipGetLastError();
@@ -507,7 +514,7 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
 // (the fused kernels are built for the stock table shape only: engine.hip falls back to two launches otherwise)
 template <class R>
 static hipError_t launch_fused(const MfccStreamArgs<R>& m, const WaveTables<R>& t, const GruArgs& g, int n_cus, hipStream_t s) {
-    if (t.L.mel_pad != ShapeStock::MEL) return hipErrorInvalidValue;
+    if (t.L.mel_pad != ShapeStock::MEL || !blob_matches_shape(t)) return hipErrorInvalidValue;
     if (g.bf16) {
         const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
         static const int tpw_env = env_int("PE_BF16_TPW", 0);

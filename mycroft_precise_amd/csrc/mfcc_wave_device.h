@@ -74,6 +74,26 @@ __host__ __device__ inline int wave_lds_skip(const pe_wave::Layout& L) { return 
 __host__ __device__ inline size_t wave_lds_bytes(int real_size, const pe_wave::Layout& L, int waves) {
     return (size_t)(L.total - wave_lds_skip(L)) + (size_t)waves * kWaveScratchReals * real_size;
 }
+// LDS of a frame workgroup: [scratch of wave 0 .. 3][table image].  The scratch comes first so that neither base depends
+// on the image size, and the section offsets of the image are compile-time constants of the table shape SH (the host builds
+// the blob with the same constexpr pe_wave::layout; launch_* refuse a blob that disagrees): every table address in the frame
+// loop is an instruction offset -- with runtime offsets the twelve section pointers lived in SGPRs, spilled to VGPR lanes
+// and were fetched back by v_readlane in every frame (round 3: 60 of the 223 instructions between two transforms).
+template <class R> constexpr int kWaveImageBase = kFrameWaves * kWaveScratchReals * (int)sizeof(R);
+template <class R, class SH> constexpr pe_wave::Layout shape_layout() { return pe_wave::layout((int)sizeof(R), SH::MEL, SH::DCT, 0, 0); }
+template <class R, class SH>
+__host__ __device__ inline bool shape_layout_matches(const pe_wave::Layout& L) {
+    constexpr pe_wave::Layout K = shape_layout<R, SH>();
+    return L.tw1 == K.tw1 && L.tw2 == K.tw2 && L.tw3 == K.tw3 && L.w512 == K.w512 && L.logtab == K.logtab && L.mel_w == K.mel_w &&
+           L.dct_w == K.dct_w && L.mel_start == K.mel_start && L.pstart == K.pstart && L.partner == K.partner && L.proj_w == K.proj_w;
+}
+template <class R, class SH>
+__device__ __forceinline__ pe_wave::Tab<R> wave_bind(const unsigned char* image, const pe_wave::Layout& L) {
+    pe_wave::Layout K = shape_layout<R, SH>();
+    K.proj_b = L.proj_b; K.proj_rows = L.proj_rows; K.total = L.total;
+    K.mel_pad = L.mel_pad; K.dct_pad = L.dct_pad; K.np_pad = L.np_pad; K.mel_len = L.mel_len; K.dct_len = L.dct_len; K.np_max = L.np_max;
+    return pe_wave::bind<R>(image, K, wave_lds_skip(K));
+}
 
 // workgroup-wide copy of the table image into LDS in two steps, so that the global loads can be issued at the very
 // top of a kernel and the LDS stores + barrier placed where the tables are first needed
@@ -106,7 +126,7 @@ __device__ __forceinline__ void wave_tables_commit(unsigned char* smem, const Wa
     const int skip = wave_lds_skip(g.L);
     const int n16 = (g.L.total - skip) >> 4;
     const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(g.blob) + skip);
-    uint4* dst = reinterpret_cast<uint4*>(smem);
+    uint4* dst = reinterpret_cast<uint4*>(smem + kWaveImageBase<R>);
     auto put = [&](int k, const uint4& v) {
         const int i = threadIdx.x + k * blockDim.x;
         dst[i < n16 ? i : 0] = v;
@@ -451,7 +471,7 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
     long long sg_end = sg_begin + per_wave < n_slots ? sg_begin + per_wave : n_slots;
     if (by_simd) {
         // one int per wave at the base of its (not yet used) scratch: which SIMD each wave of this workgroup sits on
-        int* const slot = reinterpret_cast<int*>(smem + (wt.L.total - wave_lds_skip(wt.L)));
+        int* const slot = reinterpret_cast<int*>(smem);
         constexpr int kStride = kWaveScratchReals * (int)sizeof(R) / 4;
         const int simd = wave_simd_id();
         if (lane == 0) slot[wave * kStride] = simd;
@@ -591,8 +611,8 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
 #else
     const pe_wave::LaneConsts<R> lc = pe_wave::lane_consts(pe_wave::bind<R>(static_cast<const unsigned char*>(wt.blob), wt.L), lane);
 #endif
-    const pe_wave::Tab<R> tab = pe_wave::bind<R>(smem, wt.L, wave_lds_skip(wt.L));
-    R* const S = reinterpret_cast<R*>(smem + (wt.L.total - wave_lds_skip(wt.L))) + (size_t)wave * kWaveScratchReals;
+    const pe_wave::Tab<R> tab = wave_bind<R, SH>(smem + kWaveImageBase<R>, wt.L);
+    R* const S = reinterpret_cast<R*>(smem) + (size_t)wave * kWaveScratchReals;
     // tables -> LDS first, then the counters (both on their way since the top; measured 16.40 vs 16.48 us per fused update
     // against requesting the first frame before the image is stored: the workgroup barrier in the commit is passed
     // earlier by every wave), then the first frame's samples
@@ -668,8 +688,8 @@ __device__ __forceinline__ void mfcc_offline_frames(const MfccOfflineArgs<R>& a,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const TabRegs tab_regs = wave_tables_issue<R>(wt);
     wave_tables_commit<R>(smem, wt, tab_regs);
-    const pe_wave::Tab<R> tab = pe_wave::bind<R>(smem, wt.L, wave_lds_skip(wt.L));
-    R* S = reinterpret_cast<R*>(smem + (wt.L.total - wave_lds_skip(wt.L))) + (size_t)wave * kWaveScratchReals;
+    const pe_wave::Tab<R> tab = wave_bind<R, SH>(smem + kWaveImageBase<R>, wt.L);
+    R* S = reinterpret_cast<R*>(smem) + (size_t)wave * kWaveScratchReals;
 #if PE_TW_LDS == 2
     const pe_wave::LaneConsts<R> lc{};
 #else

@@ -64,11 +64,13 @@ struct Layout {          // byte offsets into the blob (16-byte aligned sections
     int mel_len, dct_len, np_max;
 };
 
-inline int align16(int v) { return (v + 15) & ~15; }
+constexpr int align16(int v) { return (v + 15) & ~15; }
 
 constexpr int kProjRow = 64;        // floats per input-projection row (4 MFMA output tiles x 16 rows)
 
-inline Layout layout(int real_size, int mel_len, int dct_len, int np_max, int proj_rows = 0) {
+// (constexpr: for a table SHAPE -- mel_len, dct_len as compiled into a kernel -- every section offset but `total` is a
+//  compile-time constant there, and the kernel's LDS addresses fold into instruction offsets)
+constexpr Layout layout(int real_size, int mel_len, int dct_len, int np_max, int proj_rows = 0) {
     Layout L{};
     int off = 0;
     L.tw1 = off; off += 3 * 64 * 2 * real_size;
