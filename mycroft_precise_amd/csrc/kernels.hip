@@ -19,8 +19,23 @@ namespace pe {
 #endif
 // workgroups [0, n_frame_blocks): frame tasks; the rest: one bookkeeping workgroup per tile (they read what the
 // frame tasks read and write elsewhere, so the two roles share a launch)
+// Every 64-byte line of a kernel's argument segment, requested by the first instructions of the kernel.  The role
+// selection reads the trailing integers, waits, branches, and only then do the role's own pointers get loaded -- from
+// other cache lines, after a second miss of the scalar cache (two memory round trips in series before the first vector
+// load can go out; ISA, round 3).  With every line on its way behind ONE wait the later scalar loads hit.
+template <int BYTES>
+__device__ __forceinline__ void touch_kernel_arguments() {
+    const int* ka = (const int*)__builtin_amdgcn_kernarg_segment_ptr();
+    static_assert(BYTES <= 12 * 64, "more lines than this helper requests");
+    auto line = [&](int i) -> int { return i * 64 < BYTES ? ka[i * 16] : 0; };
+    const int v0 = line(0), v1 = line(1), v2 = line(2), v3 = line(3), v4 = line(4), v5 = line(5), v6 = line(6), v7 = line(7),
+              v8 = line(8), v9 = line(9), v10 = line(10), v11 = line(11);
+    asm volatile("" :: "s"(v0), "s"(v1), "s"(v2), "s"(v3), "s"(v4), "s"(v5), "s"(v6), "s"(v7), "s"(v8), "s"(v9), "s"(v10), "s"(v11));
+}
+
 template <class R, class SH>
 __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(SH::WPE))) void mfcc_kernel(const MfccStreamArgs<R> a, const WaveTables<R> t, const int n_frame_blocks) {
+    touch_kernel_arguments<(int)(sizeof(MfccStreamArgs<R>) + sizeof(WaveTables<R>) + 4)>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x < n_frame_blocks) mfcc_frame_tasks<R, SH>(a, t, smem, (int)blockIdx.x * kFrameWaves, n_frame_blocks * kFrameWaves);
     else mfcc_book_tile<R>(a, (int)blockIdx.x - n_frame_blocks);
@@ -89,15 +104,18 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
 // ---- GRU: one wave per 16-stream tile ----------------------------------------------------------
 template <int R, int MODE, bool PROJ = false, int KX = 1>
 __global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
+    touch_kernel_arguments<(int)sizeof(GruArgs)>();
     gru_tile<R, MODE, PROJ, KX>(a, blockIdx.x, threadIdx.x);
 }
 
 // ---- GRU, stock width re-tiled (gru_cw_device.h): one wave per tile / four waves per tile ------------------------
 template <int MODE>
 __global__ __launch_bounds__(64) void gru_v_kernel(const GruArgs a) {
+    touch_kernel_arguments<(int)sizeof(GruArgs)>();
     gru_tile_v<MODE>(a, blockIdx.x, threadIdx.x);
 }
 __global__ __launch_bounds__(256) void gru_cw_kernel(const GruArgs a) {
+    touch_kernel_arguments<(int)sizeof(GruArgs)>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     gru_tile_cw<false>(a, blockIdx.x, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
@@ -147,6 +165,7 @@ hipError_t launch_gru_wide(const WideArgs& a, int mode, hipStream_t s) {
 // ---- GRU, bf16 operands: one wave per 16-stream tile --------------------------------------------------
 template <int MODE, bool DELTA, bool RB = false>
 __global__ __launch_bounds__(64) void gru_bf16_kernel(const GruArgs a) {
+    touch_kernel_arguments<(int)sizeof(GruArgs)>();
     gru_tile_bf16<MODE, DELTA, RB>(a, blockIdx.x, threadIdx.x);
 }
 
@@ -167,6 +186,7 @@ __device__ __forceinline__ int role_block(const int b, const int n_gru, const in
 template <class R, class SH, bool DELTA, bool RB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_bf16_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
                                                                 const int n_gru_blocks, const int n_frame_blocks, const int n_tiles, const int frames_first) {
+    touch_kernel_arguments<(int)(sizeof(MfccStreamArgs<R>) + sizeof(WaveTables<R>) + sizeof(GruArgs) + 16)>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // frames_first: bit 0 = frame workgroups dispatched first; bits 8.. = network tiles per workgroup (1, 2 or 4: with few
     // tiles, one or two network waves on EVERY compute unit disturb the frame waves less than four on every second one)
@@ -233,6 +253,7 @@ template <class R, class SH, int RG, bool MW, bool PROJ, bool CW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WPE))) void fused_update_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
                                                            const int n_gru_blocks, const int n_frame_blocks, const int n_tiles, const int frames_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    touch_kernel_arguments<(int)(sizeof(MfccStreamArgs<R>) + sizeof(WaveTables<R>) + sizeof(GruArgs) + 16)>();
     const int b = role_block(blockIdx.x, n_gru_blocks, n_frame_blocks, frames_first & kFramesFirst);
     if (b < n_gru_blocks) {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

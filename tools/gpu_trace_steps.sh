@@ -19,7 +19,8 @@ t0 = int(rows[0]['Start_Timestamp'])
 prev_end = None
 import os
 n_show = int(os.environ.get('TRACE_SHOW', '45'))
-for i, r in enumerate(rows[:n_show]):
+n_from = int(os.environ.get('TRACE_FROM', '0'))
+for i, r in enumerate(rows[n_from:n_from + n_show]):
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     print('%3d start %9.2f us  dur %6.2f  gap %6.2f' % (i, (s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3 if prev_end else 0))
     prev_end = e
