@@ -478,7 +478,7 @@ def main():
         mfcc_name = 'double' if args.mfcc_precision == 'f64' else 'float'
         mfma_peak = MFMA_F32_PEAK_TFLOPS if args.gru_precision == 'f32' else MFMA_BF16_PEAK_TFLOPS
         four_waves = (B + 15) // 16 <= torch.cuda.get_device_properties(device).multi_processor_count   # engine.hip: gru_args
-        mfcc_kernel = 'mfcc_kernel<%s, ShapeStock>' % mfcc_name
+        mfcc_kernel = 'mfcc_kernel<%s, ShapeStock, true>' % mfcc_name
         retiled = four_waves if args.gru_tiling < 0 else bool(args.gru_tiling)       # engine.hip: gru_args (stock width only)
         fused_name = ('fused_update_kernel<%s, ShapeStock, 5, %s, false, %s>' % (mfcc_name, 'true' if four_waves else 'false', 'true' if retiled else 'false')
                       if args.gru_precision == 'f32' else 'fused_update_bf16_kernel<%s, ShapeStock>' % mfcc_name)

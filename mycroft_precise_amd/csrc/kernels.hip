@@ -33,11 +33,12 @@ __device__ __forceinline__ void touch_kernel_arguments() {
     asm volatile("" :: "s"(v0), "s"(v1), "s"(v2), "s"(v3), "s"(v4), "s"(v5), "s"(v6), "s"(v7), "s"(v8), "s"(v9), "s"(v10), "s"(v11));
 }
 
-template <class R, class SH>
+// SINGLE: one update, no projection rows (the launcher knows): the frame loop without the several-updates arithmetic
+template <class R, class SH, bool SINGLE = false>
 __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(SH::WPE))) void mfcc_kernel(const MfccStreamArgs<R> a, const WaveTables<R> t, const int n_frame_blocks) {
     touch_kernel_arguments<(int)(sizeof(MfccStreamArgs<R>) + sizeof(WaveTables<R>) + 4)>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if ((int)blockIdx.x < n_frame_blocks) mfcc_frame_tasks<R, SH>(a, t, smem, (int)blockIdx.x * kFrameWaves, n_frame_blocks * kFrameWaves);
+    if ((int)blockIdx.x < n_frame_blocks) mfcc_frame_tasks<R, SH, SINGLE, SINGLE>(a, t, smem, (int)blockIdx.x * kFrameWaves, n_frame_blocks * kFrameWaves);
     else mfcc_book_tile<R>(a, (int)blockIdx.x - n_frame_blocks);
 }
 
@@ -343,8 +344,14 @@ static hipError_t launch_mfcc(const MfccStreamArgs<R>& a, const WaveTables<R>& t
     static const int skip = env_int("PE_MFCC_SKIP", 0);        // tuning aid (wrong results): 1 = frame role only, 2 = bookkeeping role only
     if (skip == 1) { hipLaunchKernelGGL((mfcc_kernel<R, ShapeStock>), dim3(fb), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb); return hipGetLastError(); }
     if (skip == 2) { hipLaunchKernelGGL((mfcc_kernel<R, ShapeStock>), dim3(tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, 0); return hipGetLastError(); }
-    if (t.L.mel_pad == ShapeStock::MEL) hipLaunchKernelGGL((mfcc_kernel<R, ShapeStock>), dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
-    else hipLaunchKernelGGL((mfcc_kernel<R, ShapeAny>), dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
+    const bool single = a.n_updates == 1 && !a.proj_ring;
+    if (t.L.mel_pad == ShapeStock::MEL) {
+        if (single) hipLaunchKernelGGL((mfcc_kernel<R, ShapeStock, true>), dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
+        else hipLaunchKernelGGL((mfcc_kernel<R, ShapeStock>), dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
+    } else {
+        if (single) hipLaunchKernelGGL((mfcc_kernel<R, ShapeAny, true>), dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
+        else hipLaunchKernelGGL((mfcc_kernel<R, ShapeAny>), dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
+    }
     return hipGetLastError();
 }
 hipError_t launch_mfcc_f64(const MfccStreamArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s) { return launch_mfcc<double>(a, t, n_cus, s); }
