@@ -13,6 +13,8 @@ echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/${tag}_smoke.log
 echo "== bench"
 timeout 900 python bench.py "$@" > $OUT/${tag}_bench.json 2> $OUT/${tag}_bench.err; tail -2 $OUT/${tag}_bench.err; cut -c1-400 $OUT/${tag}_bench.json
+echo "== bench, the driver's command"
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${tag}_bench_driver.json 2> $OUT/${tag}_bench_driver.err; tail -2 $OUT/${tag}_bench_driver.err; cut -c1-300 $OUT/${tag}_bench_driver.json
 echo "== rocprofv3 kernel trace"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/${tag}_prof
