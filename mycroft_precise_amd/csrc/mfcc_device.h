@@ -67,28 +67,34 @@ __device__ __forceinline__ void mfcc_book_tile(const MfccStreamArgs<R>& a, const
     const int q = a.st_q[s];
     const uint32_t kc = a.st_kc[s];
     const int avail = q + U * C;
-    const int nnew = avail >= flen ? 1 + (avail - flen) / hop : 0;
+    // (divisions by the hop and the chunk length through the host-made reciprocals: a runtime integer division is ~40
+    //  instructions, and this role had six of them per stream)
+    auto by_hop = [&](int x) -> int { return (int)a.div_hop.div((uint32_t)x); };
+    auto by_chunk = [&](int x) -> int { return (int)a.div_chunk.div((uint32_t)x); };
+    const int nnew = avail >= flen ? 1 + by_hop(avail - flen) : 0;
     const int16_t* car = a.carry + (size_t)s * kCarryCap;
     const int16_t* base = a.pcm + (size_t)s * C;
     // virtual sample v (0 <= v < avail): carry below q, chunk (v - q) / C above
     auto vsample = [&](int v) -> int {
         if (v < q) return (int)car[v];
-        const int w = v - q, u = w / C;
+        const int w = v - q, u = by_chunk(w);
         return (int)base[(size_t)u * update_stride + (w - u * C)];
     };
     // dword loads of (even, odd) pairs: every quantity that shifts a pair boundary must be even, and the span
     // may cross at most one chunk boundary
     const bool fast = a.pcm_pairs_ok && ((q | hop | C) & 1) == 0 && (C >= flen || U == 1);
-    auto fetch = [&](int vb, int limit, int (&dst)[16]) {
+    // dwords c = C0 .. C0 + 7 of the lane (sample pairs 32 c + 2 r): unconditional loads from clamped positions -- a load
+    // inside an exec-masked block is waited for before the next such block starts
+    auto fetch = [&](int vb, int limit, const int c0, int (&dst)[8]) {
         if (fast && ((vb | limit) & 1) == 0) {
             const int w0 = vb - q;                              // < 0: the span starts inside the carry
             int u0 = 0, off0 = w0;
-            if (w0 >= 0) { u0 = w0 / C; off0 = w0 - u0 * C; }
+            if (w0 >= 0) { u0 = by_chunk(w0); off0 = w0 - u0 * C; }
             const int16_t* rowu = base + (size_t)u0 * update_stride;
             const ptrdiff_t wrap = (ptrdiff_t)update_stride - C;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const int n = 32 * c + 2 * r;
+            for (int c = 0; c < 8; ++c) {
+                const int n = 32 * (c0 + c) + 2 * r;
                 const int nn = n < limit ? n : 0;
                 const int v = vb + nn, off = off0 + nn;
                 const int16_t* p = (v < q) ? (car + v) : (rowu + off + (off >= C ? wrap : 0));
@@ -97,8 +103,8 @@ __device__ __forceinline__ void mfcc_book_tile(const MfccStreamArgs<R>& a, const
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const int n = 32 * c + 2 * r;
+            for (int c = 0; c < 8; ++c) {
+                const int n = 32 * (c0 + c) + 2 * r;
                 const int lo = n < limit ? (vsample(vb + n) & 0xffff) : 0;
                 const int hi = n + 1 < limit ? vsample(vb + n + 1) : 0;
                 dst[c] = lo | (hi << 16);
@@ -106,15 +112,25 @@ __device__ __forceinline__ void mfcc_book_tile(const MfccStreamArgs<R>& a, const
         }
     };
     const int qn = avail - nnew * hop;
-    if (qn > 0) {
-        int left[16];
-        fetch(nnew * hop, qn, left);
-        int16_t* carw = a.carry_next + (size_t)s * kCarryCap;
+    int16_t* const carw = a.carry_next + (size_t)s * kCarryCap;
+    auto put = [&](const int c0, const int (&left)[8]) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int n = 32 * c + 2 * r;
+        for (int c = 0; c < 8; ++c) {
+            const int n = 32 * (c0 + c) + 2 * r;
             if (n + 1 < qn) *reinterpret_cast<int*>(carw + n) = left[c];
             else if (n < qn) carw[n] = (int16_t)(left[c] & 0xffff);
+        }
+    };
+    // the leftover of a stream is up to 511 samples = 16 dwords per lane of its group, but in most updates it is shorter than
+    // 256 samples or empty (q < 0: the next frame starts inside the next chunk): the two halves are wave-uniform branches
+    if (__any(qn > 0)) {
+        int left[8];
+        const int vb = qn > 0 ? nnew * hop : q;                 // (streams with nothing to move read their chunk's first samples and store nothing)
+        fetch(vb, qn > 0 ? qn : 0, 0, left);
+        put(0, left);
+        if (__any(qn > 256)) {
+            fetch(vb, qn > 0 ? qn : 0, 8, left);
+            put(8, left);
         }
     }
     if (r == 0) {
@@ -122,11 +138,11 @@ __device__ __forceinline__ void mfcc_book_tile(const MfccStreamArgs<R>& a, const
         uint32_t kcu = kc, ke = a.st_ke[s];
         for (int u = 0; u < U; ++u) {                          // the counters update by update, as pe_update moves them
             const int av = qu + C;
-            const int nn = av >= flen ? 1 + (av - flen) / hop : 0;
+            const int nn = av >= flen ? 1 + by_hop(av - flen) : 0;
             qu = av - nn * hop;
             kcu += (uint32_t)nn;
             const int m = qu + hop * (int)(kcu - ke);
-            if (m >= geo.window) ke += 1u + (uint32_t)((m - geo.window) / hop);
+            if (m >= geo.window) ke += 1u + (uint32_t)by_hop(m - geo.window);
             if (a.ke_hist) a.ke_hist[(size_t)u * a.n_padded + s] = ke;
         }
         a.st_q_next[s] = qu;
