@@ -283,8 +283,8 @@ int pack_gru_weights(pe_engine* e, const pe_gru_layer& L, const float* dense_ker
     if ((rc = dev_upload(e, &e->wr2, wr2))) return rc;
     if ((rc = dev_upload(e, &e->bias, bias))) return rc;
     if ((rc = dev_upload(e, &e->wd, wd))) return rc;
-    if (R == 5 && !delta && KX == 1) {          // the stock width also in its re-tiled form (gru_cw_device.h)
-        const std::vector<float> blob = pack_gru_cw(L.kernel, L.recurrent_kernel, L.bias, F, H);
+    if (R == 5 && KX == 1) {                    // the stock width also in its re-tiled form (gru_cw_device.h)
+        const std::vector<float> blob = pack_gru_cw(L.kernel, L.recurrent_kernel, L.bias, F, H, delta);
         if ((rc = dev_upload(e, &e->cw_blob, blob))) return rc;
     }
     return PE_OK;
@@ -523,13 +523,12 @@ GruArgs gru_args(const pe_engine* e) {
     // regime (two-pass MFMAs + reductions: 81.0 vs 77.3 us at 65 536 streams), so an engine takes ONE tiling for all
     // of its launches -- every shape of a tiling agrees bit for bit -- by its size.  The critical-wave kernel still
     // wins with two tiles per compute unit (8192 streams, fused: 272 vs 254 M windows/s against one wave per tile).
-    const bool cw_ok = e->cw_blob && e->row_floats == kRowFloats && !a.proj_ring && !a.bf16 && !e->wide && !e->prm.use_delta &&
-                       e->gru_waves != 16;
+    const bool cw_ok = e->cw_blob && e->row_floats == kRowFloats && !a.proj_ring && !a.bf16 && !e->wide && e->gru_waves != 16;
     const bool retile = cw_ok && (e->gru_tiling == 1 || (e->gru_tiling < 0 && e->n_tiles <= 2 * e->n_cus));
     const int auto_waves = retile ? (e->n_tiles <= 2 * e->n_cus ? 4 : 1) : (e->n_tiles <= e->n_cus ? 4 : 1);
     a.waves_per_tile = e->gru_waves ? e->gru_waves : auto_waves;      // (16 = DPP kernel: opt-in)
     if (a.waves_per_tile == 16 && !dpp_ok) a.waves_per_tile = 4;
-    if (e->prm.use_delta) a.waves_per_tile = 1;          // only the one-wave kernel carries the delta inputs
+    if (e->prm.use_delta && !retile) a.waves_per_tile = 1;       // (classic tiling: only the one-wave kernel carries the delta inputs)
     if (e->row_floats != kRowFloats) a.waves_per_tile = 1;       // ... and the 32-float feature rows
     a.cw = retile ? e->cw_blob : nullptr;
     return a;
@@ -581,6 +580,10 @@ bool can_fuse(const pe_engine* e, int chunk) {
     //  frame role's 128-register budget -- fused, that shape spilled 96-240 bytes per lane into the time loop)
     if (!(e->fused && !e->general && !e->wide && e->table_layout.mel_pad == 10 && chunk <= emit_window(e->prm) - frame_len_of(e->prm))) return false;
     if (e->prm.gru_precision == 0 && gru_small_regs(e->units) >= 6 && gru_args(e).waves_per_tile != 4) return false;
+    if (e->prm.use_delta && e->prm.gru_precision == 0) {        // re-tiled one-wave shape with delta inputs: no fused instantiation
+        const GruArgs g = gru_args(e);
+        if (g.cw && g.waves_per_tile != 4) return false;
+    }
     return true;
 }
 

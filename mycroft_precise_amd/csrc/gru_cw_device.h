@@ -113,6 +113,14 @@ __device__ __forceinline__ f32x4 cw_xproj(const float (&w)[4], const f32x4& b, c
     return acc;
 }
 
+// use_delta (vectorization.py:53-59): + (x_t - x_(t-1)) . W[F .. 2F-1] on top of an input projection, k-steps in order
+// (gru_tile does the same: bias, features, differences, then the recurrent chain)
+__device__ __forceinline__ f32x4 cw_dproj(const float (&w)[4], f32x4 acc, const f32x4& d) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = mfma(w[kk], d[kk], acc);
+    return acc;
+}
+
 // One timestep of the recurrence on one wave, given the four accumulator inits (x.W + b of TZ, TX, TC and of the quarter
 // tile TV = {z, r, candidate of units 16..19 in registers 0, 1, 2}).  VF: the partial sums as VALU fma chains (weights
 // wf) instead of 4x4x1 MFMAs (weights wv).  h[rho] <-> unit 4 rho + g.
@@ -197,7 +205,8 @@ __device__ __forceinline__ void cw_head(const GruArgs& a, const float (&h)[5], c
 }
 
 // ---- one wave per tile ----------------------------------------------------------------------------------------
-template <int MODE>
+// DELTA: use_delta models (compile-time here: sixteen more resident weights)
+template <int MODE, bool DELTA = false>
 __device__ __forceinline__ void gru_tile_v(const GruArgs& a, const int tile, const int lane) {
     const int g = lane >> 4, j = lane & 15;
     const long long stream = (long long)tile * kTileStreams + j;
@@ -206,13 +215,15 @@ __device__ __forceinline__ void gru_tile_v(const GruArgs& a, const int tile, con
     const float* cw = a.cw;
     CwStep<false> S;
     S.load(cw, lane);
-    float wx[4][4], wd[5];
+    float wx[4][4], wxd[DELTA ? 4 : 1][4], wd[5];
     f32x4 bias[4];
+    constexpr bool delta = DELTA;
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             wx[tl][kk] = cw[CwPack::WX + (tl * 4 + kk) * 64 + lane];
+            if constexpr (DELTA) wxd[tl][kk] = cw[CwPack::WXD + (tl * 4 + kk) * 64 + lane];
             bias[tl][kk] = cw[CwPack::BIAS + (tl * 4 + kk) * 64 + lane];
         }
 #pragma unroll
@@ -228,8 +239,17 @@ __device__ __forceinline__ void gru_tile_v(const GruArgs& a, const int tile, con
         const long long w = valid ? stream : 0;               // padded lanes shadow window 0
         xbase = a.feats + ((size_t)w * a.row_stride) * kRowFloats + 4 * g;
     } else {
-        xbase = a.feats + (size_t)stream * T * a.n_in;        // explicit [n][T][F] batch (Runner.predict)
+        xbase = a.feats + (size_t)stream * T * (delta ? 2 * a.n_in : a.n_in);        // explicit [n][T][F] batch (Runner.predict)
     }
+    const int frow = delta ? 2 * a.n_in : a.n_in;             // floats per timestep of an explicit batch (it carries its delta columns)
+    auto load_d = [&](int t) -> f32x4 {                       // kFeats: the batch's own delta columns
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!valid || t >= T) return v;
+        const float* p = xbase + (size_t)t * frow + a.n_in + 4 * g;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) v[kk] = (4 * g + kk < a.n_in) ? p[kk] : 0.f;
+        return v;
+    };
     auto load_x = [&](int t) -> f32x4 {
         const int tc = t < T ? t : T - 1;
         if (MODE == kRing) {
@@ -239,7 +259,7 @@ __device__ __forceinline__ void gru_tile_v(const GruArgs& a, const int tile, con
         if (MODE == kRows) return *reinterpret_cast<const f32x4*>(xbase + (size_t)tc * kRowFloats);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (!valid || t >= T) return v;
-        const float* p = xbase + (size_t)t * a.n_in + 4 * g;
+        const float* p = xbase + (size_t)t * frow + 4 * g;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) v[kk] = (4 * g + kk < a.n_in) ? p[kk] : 0.f;
         return v;
@@ -247,11 +267,19 @@ __device__ __forceinline__ void gru_tile_v(const GruArgs& a, const int tile, con
     float h[5];
 #pragma unroll
     for (int rho = 0; rho < 5; ++rho) h[rho] = 0.f;
-    f32x4 x = load_x(0);
+    f32x4 x = load_x(0), xprev = x;
     for (int t = 0; t < T; ++t) {
         const f32x4 xn = load_x(t + 1);
-        const f32x4 aZ = cw_xproj(wx[kTZ], bias[kTZ], x), aX = cw_xproj(wx[kTX], bias[kTX], x);
-        const f32x4 aC = cw_xproj(wx[kTC], bias[kTC], x), aV = cw_xproj(wx[kTV], bias[kTV], x);
+        f32x4 aZ = cw_xproj(wx[kTZ], bias[kTZ], x), aX = cw_xproj(wx[kTX], bias[kTX], x);
+        f32x4 aC = cw_xproj(wx[kTC], bias[kTC], x), aV = cw_xproj(wx[kTV], bias[kTV], x);
+        if constexpr (DELTA) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == kFeats) d = load_d(t);
+            else if (t > 0) d = x - xprev;
+            aZ = cw_dproj(wxd[kTZ], aZ, d); aX = cw_dproj(wxd[kTX], aX, d);
+            aC = cw_dproj(wxd[kTC], aC, d); aV = cw_dproj(wxd[kTV], aV, d);
+            xprev = x;
+        }
         S.step(h, aZ, aX, aC, aV);
         x = xn;
     }
@@ -379,6 +407,14 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
         }
     };
 
+    // use_delta: the helpers add (x_t - x_(t-1)) . W[F .. 2F-1] to the inits they compute (nothing at t = 0); a wave-uniform
+    // runtime flag -- the helpers have the registers and the issue slots (P goes from 8 to 16 eight-pass MFMAs per timestep)
+    const bool delta = a.use_delta != 0;
+    auto load_wxd = [&](const int tl, float (&w)[4]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) w[kk] = delta ? cw[CwPack::WXD + (tl * 4 + kk) * 64 + lane] : 0.f;
+    };
+
     if (wave == 0) {
         // ================= R ===============================================================================
         float wrX[5], wrC[5], wfr[4][5], wfc[4][5], wvr[5], wvc[5], wd[5];
@@ -453,19 +489,23 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
         for (int rho = 0; rho < 5; ++rho) wrZ[rho] = cw[CwPack::WR + (0 * 5 + rho) * 64 + lane];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { wx[kk] = cw[CwPack::WX + (kTZ * 4 + kk) * 64 + lane]; bb[kk] = cw[CwPack::BIAS + (kTZ * 4 + kk) * 64 + lane]; }
+        float wxd[4];
+        load_wxd(kTZ, wxd);
         first_slot();
         stage_out();
 #pragma unroll
         for (int rho = 0; rho < 5; ++rho) cw_pin(wrZ[rho]);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) { cw_pin(wx[kk]); cw_pin(bb[kk]); }
+        for (int kk = 0; kk < 4; ++kk) { cw_pin(wx[kk]); cw_pin(bb[kk]); cw_pin(wxd[kk]); }
         const f32x4 bias = {bb[0], bb[1], bb[2], bb[3]};
         cw_barrier();
-        f32x4 accZ = cw_xproj(wx, bias, x_row(0));
+        f32x4 xc = x_row(0);
+        f32x4 accZ = cw_xproj(wx, bias, xc);
         f32x4 xn = x_row(1);
         cw_barrier();
         for (int t = 0; t < T; ++t) {
             f32x4 nZ = cw_xproj(wx, bias, xn);              // next step's init, while h(t) is on its way
+            if (delta) { nZ = cw_dproj(wxd, nZ, xn - xc); xc = xn; }
             xn = x_row(t + 2);
             cw_pin(nZ);
             float h[5];
@@ -485,14 +525,17 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
         load_v(0, wfz, wvz);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { wx[kk] = cw[CwPack::WX + (kTV * 4 + kk) * 64 + lane]; bb[kk] = cw[CwPack::BIAS + (kTV * 4 + kk) * 64 + lane]; }
+        float wxd[4];
+        load_wxd(kTV, wxd);
         first_slot();
         stage_out();
         pin_v(wfz, wvz);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) { cw_pin(wx[kk]); cw_pin(bb[kk]); }
+        for (int kk = 0; kk < 4; ++kk) { cw_pin(wx[kk]); cw_pin(bb[kk]); cw_pin(wxd[kk]); }
         const f32x4 bias = {bb[0], bb[1], bb[2], bb[3]};
         cw_barrier();
-        f32x4 v = cw_xproj(wx, bias, x_row(0));
+        f32x4 xc = x_row(0);
+        f32x4 v = cw_xproj(wx, bias, xc);
         float zi = v[0];
         L2[CwBox::PV] = v[1];
         L2[CwBox::PV + 1] = v[2];
@@ -501,6 +544,7 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
         for (int t = 0; t < T; ++t) {
             const int nb = (t + 1) & 1;
             v = cw_xproj(wx, bias, xn);                      // inits of step t + 1, while h(t) is on its way
+            if (delta) { v = cw_dproj(wxd, v, xn - xc); xc = xn; }
             xn = x_row(t + 2);
             cw_pin(v);
             L2[CwBox::PV + nb * 128] = v[1];
@@ -521,22 +565,24 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
             c0[kk] = cw[CwPack::BIAS + (kTX * 4 + kk) * 64 + lane];
             c1[kk] = cw[CwPack::BIAS + (kTC * 4 + kk) * 64 + lane];
         }
+        float d0[4], d1[4];
+        load_wxd(kTX, d0);
+        load_wxd(kTC, d1);
         first_slot();
         stage_out();
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) { cw_pin(w0[kk]); cw_pin(w1[kk]); cw_pin(c0[kk]); cw_pin(c1[kk]); }
+        for (int kk = 0; kk < 4; ++kk) { cw_pin(w0[kk]); cw_pin(w1[kk]); cw_pin(c0[kk]); cw_pin(c1[kk]); cw_pin(d0[kk]); cw_pin(d1[kk]); }
         const f32x4 b0 = {c0[0], c0[1], c0[2], c0[3]}, b1 = {c1[0], c1[1], c1[2], c1[3]};
         cw_barrier();                       // ring staged
-        {
-            const f32x4 x = x_row(0);
-            *reinterpret_cast<f32x4*>(L4 + CwBox::PX) = cw_xproj(w0, b0, x);
-            *reinterpret_cast<f32x4*>(L4 + CwBox::PC) = cw_xproj(w1, b1, x);
-        }
+        f32x4 xc = x_row(0);
+        *reinterpret_cast<f32x4*>(L4 + CwBox::PX) = cw_xproj(w0, b0, xc);
+        *reinterpret_cast<f32x4*>(L4 + CwBox::PC) = cw_xproj(w1, b1, xc);
         f32x4 xn = x_row(1);
         cw_barrier();
         for (int t = 0; t < T; ++t) {
             const int nb = (t + 1) & 1;
-            const f32x4 p0 = cw_xproj(w0, b0, xn), p1 = cw_xproj(w1, b1, xn);     // inits of step t + 1
+            f32x4 p0 = cw_xproj(w0, b0, xn), p1 = cw_xproj(w1, b1, xn);     // inits of step t + 1
+            if (delta) { const f32x4 d = xn - xc; p0 = cw_dproj(d0, p0, d); p1 = cw_dproj(d1, p1, d); xc = xn; }
             *reinterpret_cast<f32x4*>(L4 + CwBox::PX + nb * 256) = p0;
             *reinterpret_cast<f32x4*>(L4 + CwBox::PC + nb * 256) = p1;
             xn = x_row(t + 2);

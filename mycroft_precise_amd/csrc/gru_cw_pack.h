@@ -13,7 +13,8 @@ struct CwPack {
     static constexpr int WR = BIAS + 4 * 4 * 64;        // [TZ, TX, TC][5 rho][64]     recurrent kernel, A operands
     static constexpr int WV = WR + 3 * 5 * 64;          // [z, r, c][5 rho][64]        4x4x1 A operands of units 16..19
     static constexpr int WF = WV + 3 * 5 * 64;          // [z, r, c][4 a][5 rho][64]   the same weights per target a (VALU form)
-    static constexpr int SIZE = WF + 3 * 4 * 5 * 64;
+    static constexpr int WXD = WF + 3 * 4 * 5 * 64;     // [TZ, TX, TC, TV][4 kk][64]  input kernel rows F .. 2F-1 (use_delta), else 0
+    static constexpr int SIZE = WXD + 4 * 4 * 64;
 };
 enum { kTZ = 0, kTX = 1, kTC = 2, kTV = 3 };
 
@@ -24,7 +25,8 @@ inline void cw_slot(int tile, int q, int& gate, int& rho) {
     else { gate = tile; rho = q; }
 }
 
-inline std::vector<float> pack_gru_cw(const float* kernel, const float* recurrent, const float* bias, int F, int H) {
+// delta: the kernel has 2 F rows, rows F .. 2F-1 multiply x_t - x_(t-1) (vectorization.py:53-59)
+inline std::vector<float> pack_gru_cw(const float* kernel, const float* recurrent, const float* bias, int F, int H, bool delta = false) {
     std::vector<float> blob(CwPack::SIZE, 0.f);
     for (int tile = 0; tile < 4; ++tile)
         for (int lane = 0; lane < 64; ++lane) {
@@ -39,6 +41,7 @@ inline std::vector<float> pack_gru_cw(const float* kernel, const float* recurren
                     for (int kk = 0; kk < 4; ++kk) {
                         const int phi = 4 * g + kk;
                         if (phi < F) blob[CwPack::WX + (tile * 4 + kk) * 64 + lane] = kernel[(size_t)phi * 3 * H + col];
+                        if (phi < F && delta) blob[CwPack::WXD + (tile * 4 + kk) * 64 + lane] = kernel[(size_t)(F + phi) * 3 * H + col];
                     }
                     if (tile != kTV)
                         for (int rs = 0; rs < 5; ++rs) {

@@ -67,13 +67,14 @@ __global__ __launch_bounds__(256) void gru_many_mw_kernel(const GruArgs a, const
 }
 
 // the same two for the re-tiled stock width (gru_cw_device.h)
+template <bool DELTA>
 __global__ __launch_bounds__(64) void gru_many_v_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
     const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
     GruArgs b = a;
     b.st_ke = a.st_ke + (size_t)u * n_padded;
     b.out = a.out + (size_t)u * a.n_streams;
     b.predict_ke = 0;
-    gru_tile_v<kRing>(b, tile, threadIdx.x);
+    gru_tile_v<kRing, DELTA>(b, tile, threadIdx.x);
 }
 __global__ __launch_bounds__(256) void gru_many_cw_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -110,10 +111,10 @@ __global__ __launch_bounds__(64) void gru_small_kernel(const GruArgs a) {
 }
 
 // ---- GRU, stock width re-tiled (gru_cw_device.h): one wave per tile / four waves per tile ------------------------
-template <int MODE>
+template <int MODE, bool DELTA>
 __global__ __launch_bounds__(64) void gru_v_kernel(const GruArgs a) {
     touch_kernel_arguments<(int)sizeof(GruArgs)>();
-    gru_tile_v<MODE>(a, blockIdx.x, threadIdx.x);
+    gru_tile_v<MODE, DELTA>(a, blockIdx.x, threadIdx.x);
 }
 __global__ __launch_bounds__(256) void gru_cw_kernel(const GruArgs a) {
     touch_kernel_arguments<(int)sizeof(GruArgs)>();
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
                 gru_tile_cw<false>(g, b, role, threadIdx.x & 63, reinterpret_cast<float*>(smem));
             } else {
                 const int tile = b * 4 + wave;
-                if (tile < n_tiles) gru_tile_v<kRing>(g, tile, threadIdx.x & 63);
+                if (tile < n_tiles) gru_tile_v<kRing, false>(g, tile, threadIdx.x & 63);       // (use_delta on this shape: two launches, engine.hip can_fuse)
             }
         } else if (MW) {
             gru_tile_mw_any<RG, PROJ>(g, b, wave, threadIdx.x & 63, reinterpret_cast<float*>(smem));
@@ -384,9 +385,14 @@ static hipError_t launch_r(const GruArgs& a, int mode, hipStream_t s) {
     if constexpr (R == 5) {
         if (a.cw) {
             if (mode == kRing && a.waves_per_tile == 4 && cw_four_waves_ok(a)) hipLaunchKernelGGL(gru_cw_kernel, dim3(tiles), dim3(256), kCwLdsBytes, s, a);
-            else if (mode == kRing) hipLaunchKernelGGL(gru_v_kernel<kRing>, dim3(tiles), dim3(64), 0, s, a);
-            else if (mode == kRows) hipLaunchKernelGGL(gru_v_kernel<kRows>, dim3(tiles), dim3(64), 0, s, a);
-            else hipLaunchKernelGGL(gru_v_kernel<kFeats>, dim3(tiles), dim3(64), 0, s, a);
+            else if (a.use_delta) {
+                if (mode == kRing) hipLaunchKernelGGL((gru_v_kernel<kRing, true>), dim3(tiles), dim3(64), 0, s, a);
+                else if (mode == kRows) hipLaunchKernelGGL((gru_v_kernel<kRows, true>), dim3(tiles), dim3(64), 0, s, a);
+                else hipLaunchKernelGGL((gru_v_kernel<kFeats, true>), dim3(tiles), dim3(64), 0, s, a);
+            }
+            else if (mode == kRing) hipLaunchKernelGGL((gru_v_kernel<kRing, false>), dim3(tiles), dim3(64), 0, s, a);
+            else if (mode == kRows) hipLaunchKernelGGL((gru_v_kernel<kRows, false>), dim3(tiles), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((gru_v_kernel<kFeats, false>), dim3(tiles), dim3(64), 0, s, a);
             return hipGetLastError();
         }
         if (mode == kRing && a.proj_ring && a.waves_per_tile == 16) {
@@ -441,11 +447,13 @@ static hipError_t launch_many_r(const GruArgs& a, int n_updates, int n_padded, h
     const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
     // up to ~1.5 windows per SIMD the four-wave kernel wins (4096 streams x 4 updates: 18.1 vs 20.1 us per
     // update), from 2 per SIMD on the one-wave kernel does (x 16: 12.5 vs 14.0)
-    const bool mw = (long long)tiles * n_updates <= 1536 && !a.use_delta;      // (the delta inputs: one-wave kernel only)
+    const bool few = (long long)tiles * n_updates <= 1536;
+    const bool mw = few && !a.use_delta;       // (classic tiling: the delta inputs are on the one-wave kernel only)
     if constexpr (R == 5) {
         if (a.cw) {
-            if (mw && cw_four_waves_ok(a)) hipLaunchKernelGGL(gru_many_cw_kernel, dim3(tiles * n_updates), dim3(256), kCwLdsBytes, s, a, tiles, n_padded);
-            else hipLaunchKernelGGL(gru_many_v_kernel, dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
+            if (few && cw_four_waves_ok(a)) hipLaunchKernelGGL(gru_many_cw_kernel, dim3(tiles * n_updates), dim3(256), kCwLdsBytes, s, a, tiles, n_padded);
+            else if (a.use_delta) hipLaunchKernelGGL(gru_many_v_kernel<true>, dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
+            else hipLaunchKernelGGL(gru_many_v_kernel<false>, dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
             return hipGetLastError();
         }
         if (a.proj_ring && a.waves_per_tile == 16) {       // the engine's single updates use the DPP kernel: so does the batch

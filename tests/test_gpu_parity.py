@@ -683,6 +683,25 @@ def test_use_delta_matches_reference_semantics(tmp_path):
         want_many = np.stack([ref2.update(pcm[u + i]) for i in range(4)])
         assert np.array_equal(many.update_many(pcm[u:u + 4]), want_many), u
     many.close(); ref2.close()
+    # every kernel shape that carries the delta inputs: classic tiling (one wave per tile only) and the re-tiled stock width
+    # (critical-wave kernel with four waves, one wave per tile); the shapes of a tiling agree bit for bit
+    shapes = {}
+    for tiling, waves in ((0, 1), (1, 4), (1, 1)):
+        eng = HipEngine(hpr, w, n_streams=n)
+        eng.set_gru_tiling(tiling)
+        eng.set_gru_waves(waves)
+        refs2 = [ol.OracleListener(w, opr) for _ in range(n)]
+        outs = []
+        for u in range(12):
+            want = np.array([r.update_raw(pcm[u, j].tobytes()) for j, r in enumerate(refs2)])
+            got = eng.update(pcm[u])
+            assert np.abs(got - want).max() <= GUARD_RAW, (tiling, waves, u)
+            outs.append(got)
+        assert np.abs(eng.predict(np.stack([ol.add_deltas(r.mfccs) for r in refs2]).astype(np.float32)) -
+                      keras_gru.predict(np.stack([ol.add_deltas(r.mfccs) for r in refs2]).astype(np.float32), w)).max() <= GUARD_RAW
+        shapes[(tiling, waves)] = np.stack(outs)
+        eng.close()
+    assert np.array_equal(shapes[(1, 4)], shapes[(1, 1)])
     # explicit batch with its delta columns
     x = np.stack([ol.add_deltas(r.mfccs) for r in refs]).astype(np.float32)
     assert x.shape == (n, 29, 26)

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_cw(const GruArgs a) {
     gru_tile_cw<VF>(a, blockIdx.x, wave, threadIdx.x & 63, Sd);
 }
 __global__ __launch_bounds__(64) void k_one(const GruArgs a) { gru_tile<5, kRing, false>(a, blockIdx.x, threadIdx.x); }
-__global__ __launch_bounds__(64) void k_v(const GruArgs a) { gru_tile_v<kRing>(a, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64) void k_v(const GruArgs a) { gru_tile_v<kRing, false>(a, blockIdx.x, threadIdx.x); }
 
 template <class Tv> static Tv* upload(const std::vector<Tv>& v) {
     Tv* d; hipMalloc(&d, v.size() * sizeof(Tv)); hipMemcpy(d, v.data(), v.size() * sizeof(Tv), hipMemcpyHostToDevice); return d;
