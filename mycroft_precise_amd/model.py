@@ -11,8 +11,9 @@ so this module defines the weights as plain arrays in Keras layout:
      'dense_kernel': [H,1], 'dense_bias': [1]}
 
 stored as ``<model>.npz`` next to the usual ``<model>.npz.params`` JSON, read straight from the
-reference's frozen-graph ``<model>.pb`` (``pb_model.py``: a protobuf wire reader, no TensorFlow), or -- for a
-Keras ``<model>.net`` -- from the side-car ``<model>.net.npz`` that ``tools/export_net_to_npz.py`` writes.
+reference's frozen-graph ``<model>.pb`` (``pb_model.py``: a protobuf wire reader, no TensorFlow), or from a
+Keras ``<model>.net`` (``h5_model.py``: an HDF5 reader for what h5py / Keras write, no h5py; files outside that
+subset fall back to the side-car ``<model>.net.npz`` that ``tools/export_net_to_npz.py`` writes).
 """
 import numpy as np
 
@@ -71,13 +72,21 @@ def load_weights(model_name: str) -> dict:
         from .pb_model import weights_from_pb
         return weights_from_pb(model_name)
     if model_name.endswith('.net'):
-        # Keras HDF5: the engine has no HDF5 reader and the GPU box no h5py; the weights travel as the side-car
-        # that tools/export_net_to_npz.py writes next to the file (run where h5py exists)
+        # Keras HDF5: read directly (h5_model.py: the subset of the format that h5py / Keras write); a file that uses
+        # something else, or is not there at all, falls back to the side-car that tools/export_net_to_npz.py writes
+        # next to it where h5py exists
         from os.path import isfile
+        from .h5_model import H5FormatError, H5Unsupported, weights_from_net
+        why = 'the file does not exist'
+        if isfile(model_name):
+            try:
+                return weights_from_net(model_name)
+            except (H5Unsupported, H5FormatError) as ex:
+                why = str(ex)
         if not isfile(model_name + '.npz'):
             raise NotImplementedError(
-                'importing %s needs its exported weights %s.npz: run `python tools/export_net_to_npz.py %s` on a '
-                'machine with h5py, or freeze the model with precise-convert to .pb' % (model_name, model_name, model_name))
+                'cannot read %s (%s) and its exported weights %s.npz do not exist: run `python tools/export_net_to_npz.py '
+                '%s` on a machine with h5py, or freeze the model with precise-convert to .pb' % (model_name, why, model_name, model_name))
         net_file, model_name = model_name, model_name + '.npz'
         _check_sidecar(net_file, model_name)
     with np.load(model_name, allow_pickle=False) as z:

@@ -945,6 +945,23 @@ def test_legacy_params_file_selects_speechpy_and_matches_reference(tmp_path, sto
         P.pr.__dict__.clear(); P.pr.__dict__.update(saved)
 
 
+def test_listener_on_a_keras_net_file(tmp_path, stock_weights):
+    """The reference's own model container: ``Listener('<name>.net')`` (network_runner.py:77-95 loads it through Keras) with
+    the HDF5 file parsed by mycroft_precise_amd.h5_model -- no side-car, no h5py.  File written by tests/h5_writer.py."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import h5_writer
+    from test_host import _keras_net_tree
+    from mycroft_precise_amd.network_runner import Listener
+    path = str(tmp_path / 'hey-synthetic.net')
+    h5_writer.write_h5(path, _keras_net_tree(stock_weights), split_headers=True)
+    lis = Listener(path, 2048)
+    ref = ol.OracleListener(stock_weights, ol.Params())
+    pcm = synth.stream_pcm(23, 34 * 1024)
+    for u in range(34):
+        chunk = pcm[u * 1024:(u + 1) * 1024].tobytes()
+        assert abs(lis.update_raw(chunk) - ref.update_raw(chunk)) <= GUARD_RAW, u
+
+
 def test_listener_on_a_params_file_with_other_front_end_sizes(tmp_path):
     """The drop-in Listener on a model whose .params asks for n_fft = 1024, 40 filters, 20 coefficients
     (params.py:150-165 -> network_runner.py:98-153): the general front end behind the unchanged Python surface,

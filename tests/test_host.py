@@ -314,7 +314,8 @@ def test_pb_roundtrip_and_load_weights(tmp_path, stock_weights):
     save_weights(npz, stock_weights)
     w2 = load_weights(npz)
     assert np.array_equal(w2['gru'][0][1], stock_weights['gru'][0][1])
-    # Keras .net: refused (no HDF5 reader) unless the exporter's side-car sits next to it
+    # Keras .net that cannot be read directly (missing, or not what h5py writes): refused unless the exporter's side-car
+    # sits next to it
     with pytest.raises(NotImplementedError) as ei:
         load_weights(str(tmp_path / 'model.net'))
     assert 'export_net_to_npz.py' in str(ei.value)
@@ -425,3 +426,94 @@ def test_pb_reader_handles_tf_encodings(tmp_path):
     open(path, 'wb').write(pm._node('x', 'Placeholder'))
     with pytest.raises(ValueError):
         pm.weights_from_pb(path)
+
+
+def _keras_net_tree(w, extra_root_attrs=None):
+    """The HDF5 tree Keras 2.2.4 writes for model.py:76-82 (keras/engine/saving.py: save_model / save_weights_to_hdf5_group)."""
+    import json
+    from h5_writer import group, dataset
+    k, rk, b = w['gru'][0]
+    cfg = json.dumps({'class_name': 'Sequential', 'config': {'name': 'sequential_1', 'layers': [
+        {'class_name': 'GRU', 'config': {'name': 'net', 'units': int(rk.shape[0]), 'activation': 'linear', 'recurrent_activation': 'hard_sigmoid',
+                                         'batch_input_shape': [None, 29, int(k.shape[0])], 'reset_after': False}},
+        {'class_name': 'Dense', 'config': {'name': 'dense_1', 'units': 1, 'activation': 'sigmoid'}}]}}).encode('utf8')
+    attrs = {'keras_version': b'2.2.4', 'backend': b'tensorflow', 'model_config': cfg}
+    attrs.update(extra_root_attrs or {})
+    return group({
+        'model_weights': group({
+            'net': group({'net': group({'kernel:0': dataset(k), 'recurrent_kernel:0': dataset(rk), 'bias:0': dataset(b)})},
+                         attrs={'weight_names': [b'net/kernel:0', b'net/recurrent_kernel:0', b'net/bias:0']}),
+            'dense_1': group({'dense_1': group({'kernel:0': dataset(w['dense_kernel']), 'bias:0': dataset(w['dense_bias'])})},
+                             attrs={'weight_names': [b'dense_1/kernel:0', b'dense_1/bias:0']})},
+            attrs={'layer_names': [b'net', b'dense_1'], 'backend': b'tensorflow', 'keras_version': b'2.2.4'}),
+        'optimizer_weights': group({'training': group({'Adam': group({'iterations:0': dataset(np.int64(1234))})})},
+                                   attrs={'weight_names': [b'training/Adam/iterations:0']})}, attrs=attrs)
+
+
+@pytest.mark.parametrize('split_headers,user_block', [(False, 0), (True, 0), (False, 512), (True, 512)])
+def test_keras_net_file_is_read_without_h5py(tmp_path, stock_weights, split_headers, user_block):
+    """network_runner.py:77-95 / model.py:48-54 load ``<model>.net`` through Keras; here the HDF5 container is parsed
+    directly.  No HDF5 library exists offline: the file comes from tests/h5_writer.py, an independent byte-level writer of
+    the same dialect (superblock 0, version-1 object headers with and without continuation blocks, symbol-table groups,
+    optional user block)."""
+    import h5_writer
+    from mycroft_precise_amd import h5_model
+    from mycroft_precise_amd.model import load_weights
+    path = str(tmp_path / 'hey.net')
+    h5_writer.write_h5(path, _keras_net_tree(stock_weights), split_headers=split_headers, superblock_at=user_block)
+    w = load_weights(path)
+    for a, b in zip(w['gru'][0], stock_weights['gru'][0]):
+        assert a.dtype == np.float32 and np.array_equal(a, b)
+    assert np.array_equal(w['dense_kernel'], stock_weights['dense_kernel'])
+    assert np.array_equal(w['dense_bias'], stock_weights['dense_bias'])
+    cfg = h5_model.model_config(path)
+    assert [l['class_name'] for l in cfg['config']['layers']] == ['GRU', 'Dense']
+    f = h5_model.H5File(path)
+    assert sorted(f.keys()) == ['model_weights', 'optimizer_weights'] and f.attrs['keras_version'] == b'2.2.4'
+    assert int(f['optimizer_weights/training/Adam/iterations:0'].read()) == 1234
+
+
+def test_h5_reader_layouts_types_and_refusals(tmp_path):
+    """Dataset layouts and element types beyond what Keras uses by default (h5py users do turn compression on):
+    chunked with deflate + shuffle and partial edge chunks, compact, big-endian, float64, integers; string attributes of
+    both kinds; groups with more entries than one symbol-table node holds; and clear refusals for what is outside the
+    subset."""
+    import h5_writer
+    from h5_writer import group, dataset
+    from mycroft_precise_amd import h5_model
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((37, 23)).astype(np.float32)
+    many = {'d%02d' % i: dataset(np.full((3,), i, np.int32)) for i in range(21)}         # 3 symbol-table nodes
+    tree = group({'chunked': dataset(a, layout='chunked', chunks=(16, 8), gzip=True, shuffle=True),
+                  'plain_chunks': dataset(a.astype(np.float64), layout='chunked', chunks=(37, 23)),
+                  'compact': dataset(a[:2], layout='compact', attrs={'scale': np.float64(0.5), 'ids': np.arange(4, dtype=np.uint16)}),
+                  'big': dataset(a.astype('>f4')), 'empty': dataset(np.zeros((0, 4), np.float32)),
+                  'many': group(many)},
+                 attrs={'title': 'variable-length string', 'fixed': b'fixed-length', 'names': [b'a', b'bcd']})
+    path = str(tmp_path / 'layouts.h5')
+    h5_writer.write_h5(path, tree)
+    f = h5_model.H5File(path)
+    assert np.array_equal(f['chunked'].read(), a) and np.array_equal(f['plain_chunks'].read(), a.astype(np.float64))
+    assert np.array_equal(f['compact'].read(), a[:2]) and np.array_equal(f['big'].read(), a)
+    assert f['big'].read().dtype == np.float32 and f['empty'].read().shape == (0, 4)
+    assert f['compact'].attrs['scale'] == 0.5 and list(f['compact'].attrs['ids']) == [0, 1, 2, 3]
+    assert f.attrs['title'] == 'variable-length string' and f.attrs['fixed'] == b'fixed-length' and list(f.attrs['names']) == [b'a', b'bcd']
+    assert sorted(f['many'].keys()) == sorted(many) and int(f['many/d17'].read()[0]) == 17
+    with pytest.raises(KeyError):
+        f['many/nope']
+    # not HDF5 at all / truncated in the middle of the tree
+    bad = tmp_path / 'bad.net'
+    bad.write_bytes(b'not an HDF5 file')
+    with pytest.raises(h5_model.H5FormatError):
+        h5_model.H5File(str(bad))
+    whole = open(path, 'rb').read()
+    (tmp_path / 'cut.h5').write_bytes(whole[:len(whole) // 3])
+    with pytest.raises(h5_model.H5FormatError):
+        g = h5_model.H5File(str(tmp_path / 'cut.h5'))
+        [g[k].read() for k in ('chunked', 'big', 'compact')]
+    # a newer superblock than this reader knows
+    newer = bytearray(whole)
+    newer[8] = 4
+    (tmp_path / 'newer.h5').write_bytes(bytes(newer))
+    with pytest.raises(h5_model.H5Unsupported):
+        h5_model.H5File(str(tmp_path / 'newer.h5'))

@@ -10,8 +10,8 @@ Run it wherever h5py is installed (the training machine); neither Keras nor Tens
 
 ``mycroft_precise_amd.model.load_weights('hey-mycroft.net')`` then picks the side-car up by itself, so
 ``Listener('hey-mycroft.net')`` keeps working with the reference's own file name (the ``.params`` file stays
-``hey-mycroft.net.params``).  The GPU box has no h5py and the engine has no HDF5 reader: without the side-car
-``.net`` models are refused with a pointer to this script.
+``hey-mycroft.net.params``).  Since round 3 the package reads ``.net`` files itself (``mycroft_precise_amd/h5_model.py``,
+no h5py); this exporter is the fallback for files that use HDF5 features outside that reader's subset.
 
 Keras 2.x layout of a saved Sequential model: group ``model_weights`` (or the file root for weights-only
 files) -> attribute ``layer_names`` -> one group per layer -> attribute ``weight_names`` -> datasets
