@@ -34,9 +34,10 @@ def _pad8(b):
 
 
 class _Writer:
-    def __init__(self, split_headers=False):
+    def __init__(self, split_headers=False, latest=False):
         self.buf = bytearray(96)                 # the superblock goes here at the end
         self.split = split_headers               # put the attributes of every object into a continuation block
+        self.latest = latest                     # libver='latest' structures: version-2 object headers, link messages
         self.gheap = []                          # variable-length strings: objects of one global heap collection
         self.gheap_addr = None
 
@@ -86,6 +87,8 @@ class _Writer:
             else:
                 arr = np.asarray(value)
             dt, ds, data = self.datatype(arr.dtype), self.dataspace(arr.shape), arr.tobytes()
+        if self.latest:                                           # version 3: no padding, a character-set byte
+            return struct.pack('<BBHHHB', 3, 0, len(nm), len(dt), len(ds), 0) + nm + dt + ds + data
         return struct.pack('<BBHHH', 1, 0, len(nm), len(dt), len(ds)) + _pad8(nm) + _pad8(dt) + _pad8(ds) + data
 
     def global_heap(self, tree):
@@ -118,6 +121,18 @@ class _Writer:
             return out
         amsgs = [(0x0C, self.attribute(name, value)) for name, value in attrs.items()]
         messages = list(messages)
+        if self.latest:
+            # "OHDR", version 2, flags 0x02 (4-byte chunk size), messages with 4-byte prefixes and no padding, checksum
+            # (written as 0: the reader under test does not verify checksums); continuation blocks carry "OCHK"
+            def pack2(msgs):
+                return b''.join(struct.pack('<BHB', kind, len(data), 0) + data for kind, data in msgs)
+            if self.split and amsgs:
+                block = b'OCHK' + pack2(amsgs) + b'\0' * 4
+                cont = self.alloc(block)
+                body = pack2(messages + [(0x10, struct.pack('<QQ', cont, len(block)))])
+            else:
+                body = pack2(messages + amsgs)
+            return self.alloc(b'OHDR' + struct.pack('<BBI', 2, 0x02, len(body)) + body + b'\0' * 4)
         if self.split and amsgs:
             block = pack(amsgs)
             cont = self.alloc(block)
@@ -172,6 +187,15 @@ class _Writer:
 
     def write_group(self, node):
         """Returns (object header address, B-tree address, local heap address)."""
+        if self.latest:
+            # compact new-style group: link info (no dense storage), group info, one link message per child
+            msgs = [(0x02, struct.pack('<BBQQ', 0, 0, UNDEF, UNDEF)), (0x0A, struct.pack('<BB', 0, 0))]
+            for name in sorted(node['children']):
+                child = node['children'][name]
+                addr = self.write_group(child)[0] if child['kind'] == 'group' else self.write_dataset(child)
+                nm = name.encode('utf-8')
+                msgs.append((0x06, struct.pack('<BBBB', 1, 0x10, 1, len(nm)) + nm + struct.pack('<Q', addr)))      # flags: character set present (UTF-8)
+            return self.header(msgs, node['attrs']), UNDEF, UNDEF
         entries = []
         for name in sorted(node['children']):
             child = node['children'][name]
@@ -205,13 +229,20 @@ class _Writer:
         return header, btree, heap_addr
 
 
-def write_h5(path, tree, split_headers=False, superblock_at=0):
+def write_h5(path, tree, split_headers=False, superblock_at=0, latest=False):
     """``split_headers``: attributes go into object-header continuation blocks.  ``superblock_at``: 0 or 512 (a user
-    block in front of the file; addresses are relative to the superblock's base address then)."""
-    w = _Writer(split_headers)
+    block in front of the file; addresses are relative to the superblock's base address then).  ``latest``: the structures
+    of libver='latest' files (superblock 2, version-2 object headers, link messages, version-3 attributes)."""
+    w = _Writer(split_headers, latest)
     w.global_heap(tree)
     root, btree, heap = w.write_group(tree)
     eof = len(w.buf)
+    if latest:
+        sb = b'\x89HDF\r\n\x1a\n' + struct.pack('<BBBB', 2, 8, 8, 0) + struct.pack('<QQQQ', superblock_at, UNDEF, eof, root) + b'\0' * 4
+        w.buf[0:len(sb)] = sb
+        with open(path, 'wb') as f:
+            f.write(b'\0' * superblock_at + bytes(w.buf))
+        return
     sb = b'\x89HDF\r\n\x1a\n' + struct.pack('<BBBBBBBB', 0, 0, 0, 0, 0, 8, 8, 0) + struct.pack('<HHI', LEAF_K, INTERNAL_K, 0)
     sb += struct.pack('<QQQQ', superblock_at, UNDEF, eof, UNDEF)
     sb += struct.pack('<QQII', 0, root, 1, 0) + struct.pack('<QQ', btree, heap)

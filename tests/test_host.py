@@ -450,17 +450,18 @@ def _keras_net_tree(w, extra_root_attrs=None):
                                    attrs={'weight_names': [b'training/Adam/iterations:0']})}, attrs=attrs)
 
 
-@pytest.mark.parametrize('split_headers,user_block', [(False, 0), (True, 0), (False, 512), (True, 512)])
-def test_keras_net_file_is_read_without_h5py(tmp_path, stock_weights, split_headers, user_block):
+@pytest.mark.parametrize('split_headers,user_block,latest', [(False, 0, False), (True, 0, False), (False, 512, False), (True, 512, False),
+                                                             (False, 0, True), (True, 512, True)])
+def test_keras_net_file_is_read_without_h5py(tmp_path, stock_weights, split_headers, user_block, latest):
     """network_runner.py:77-95 / model.py:48-54 load ``<model>.net`` through Keras; here the HDF5 container is parsed
     directly.  No HDF5 library exists offline: the file comes from tests/h5_writer.py, an independent byte-level writer of
     the same dialect (superblock 0, version-1 object headers with and without continuation blocks, symbol-table groups,
-    optional user block)."""
+    optional user block) and of the libver='latest' one (superblock 2, version-2 object headers, link messages)."""
     import h5_writer
     from mycroft_precise_amd import h5_model
     from mycroft_precise_amd.model import load_weights
     path = str(tmp_path / 'hey.net')
-    h5_writer.write_h5(path, _keras_net_tree(stock_weights), split_headers=split_headers, superblock_at=user_block)
+    h5_writer.write_h5(path, _keras_net_tree(stock_weights), split_headers=split_headers, superblock_at=user_block, latest=latest)
     w = load_weights(path)
     for a, b in zip(w['gru'][0], stock_weights['gru'][0]):
         assert a.dtype == np.float32 and np.array_equal(a, b)
