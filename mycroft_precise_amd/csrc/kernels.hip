@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
             static_assert(RG == 5 && !PROJ, "the re-tiled shapes exist for the stock width, without projection rows");
             if (MW) {
                 // kBySimd: the four roles sit on SIMDs 0..3 in a fixed order (R on 0, Z1, Z2, P) so that the frame waves of
-                // this compute unit know what runs beside them (mfcc_frame_tasks<.., true>).  Roles follow the SIMDs only
+                // this compute unit know what runs beside them (mfcc_frame_tasks(..., by_simd)).  Roles follow the SIMDs only
                 // if the four waves sit on four different ones (they do: a workgroup's waves are spread round-robin;
                 // checked, not assumed).
                 int role = wave;

@@ -436,7 +436,7 @@ __device__ __attribute__((noinline)) RawFrame fetch_frame_slow(const int16_t* ca
 // SIMD of the compute unit this wave runs on (HW_ID.SIMD_ID: s_getreg_b32 hwreg(HW_REG_HW_ID, 4, 2))
 __device__ __forceinline__ int wave_simd_id() { return (int)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3); }
 
-// BY_SIMD (fused launch at one network tile per compute unit): the network workgroup of the compute unit has its four
+// by_simd (fused launch at one network tile per compute unit): the network workgroup of the compute unit has its four
 // roles on SIMDs 0..3 in a fixed order (fused_update_kernel), and a frame wave's float64 multiply-adds wait while the
 // matrix pipe of its SIMD runs the MFMAs of that role (R 37 % of the time, Z1 33 %, P 29 %, Z2 20 %: measured frame
 // waves run 1.1x to 2x longer depending on the SIMD).  So the four waves of a frame workgroup split the workgroup's
