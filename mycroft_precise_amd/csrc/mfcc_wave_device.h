@@ -348,11 +348,16 @@ __device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, const pe_
         if (has_filter) {
             const int p0 = lr.p0, np = lr.np;
             R pv[SH::NP];
+            // (past a filter's last run the read goes to a slot that holds 0 -- the exchange padding of lane 63, which
+            //  nothing overwrites after wave_scratch_init -- instead of selecting on the 8-byte value afterwards: one
+            //  32-bit select per term instead of two)
+            constexpr int kZero = 2 * (63 * pe_wave::kXchgStride + pe_wave::kXchgStride - 1);
+            static_assert(kZero >= pe_wave::kLogMelOff + pe_wave::kMaxFilt + 1 && kZero + 1 < kWaveScratchReals, "the zero slot lies behind the log-mel area");
 #pragma unroll
-            for (int i = 0; i < SH::NP; ++i) pv[i] = lds_read(&PART[p0 + i]);         // (past the last run: log-mel slots, not added)
+            for (int i = 0; i < SH::NP; ++i) pv[i] = lds_read(i < np ? &PART[p0 + i] : &S[kZero]);
             x = R(0);
 #pragma unroll
-            for (int i = 0; i < SH::NP; ++i) x += i < np ? pv[i] : R(0);
+            for (int i = 0; i < SH::NP; ++i) x += pv[i];
         }
         if (takes_total) x = psum;
         if (has_filter || takes_total) {
