@@ -518,3 +518,66 @@ def test_h5_reader_layouts_types_and_refusals(tmp_path):
     (tmp_path / 'newer.h5').write_bytes(bytes(newer))
     with pytest.raises(h5_model.H5Unsupported):
         h5_model.H5File(str(tmp_path / 'newer.h5'))
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_h5_reader_on_random_trees(tmp_path, seed):
+    """Seeded random files: nested groups of random fan-out (up to three symbol-table nodes), datasets of random rank,
+    shape, type and layout, attributes of every supported kind -- written in both dialects, with and without continuation
+    blocks, read back element for element."""
+    import h5_writer
+    from h5_writer import group, dataset
+    from mycroft_precise_amd import h5_model
+    rng = np.random.default_rng(100 + seed)
+    dtypes = ['<f4', '<f8', '>f4', '<i4', '<u2', '<i8']
+
+    def rand_array():
+        shape = tuple(int(x) for x in rng.integers(1, 9, size=int(rng.integers(0, 4))))
+        dt = np.dtype(dtypes[int(rng.integers(len(dtypes)))])
+        a = rng.standard_normal(shape) * 100
+        return a.astype(dt)
+
+    def rand_attrs():
+        out = {}
+        for i in range(int(rng.integers(0, 4))):
+            kind = int(rng.integers(4))
+            out['a%d' % i] = [b'bytes-%d' % i, 'text %d \u00e9' % i, [b'x', b'yz%d' % i], rand_array()][kind]
+        return out
+
+    def rand_dataset():
+        a = rand_array()
+        layout = ['contiguous', 'compact', 'chunked'][int(rng.integers(3))] if a.ndim else 'contiguous'
+        chunks = tuple(int(rng.integers(1, s + 1)) for s in a.shape) if layout == 'chunked' else None
+        return dataset(a, attrs=rand_attrs(), layout=layout, chunks=chunks, gzip=bool(rng.integers(2)) and layout == 'chunked',
+                       shuffle=bool(rng.integers(2)) and layout == 'chunked')
+
+    def rand_group(depth):
+        children = {}
+        for i in range(int(rng.integers(0, 20 if depth == 0 else 5))):
+            children['n%d_%d' % (depth, i)] = rand_group(depth + 1) if depth < 2 and rng.integers(3) == 0 else rand_dataset()
+        return group(children, attrs=rand_attrs())
+
+    tree = rand_group(0)
+
+    def check(node, obj):
+        for k, v in node['attrs'].items():
+            got = obj.attrs[k]
+            if isinstance(v, (bytes, str)):
+                assert got == v, k
+            elif isinstance(v, list):
+                assert list(got) == v, k
+            else:
+                assert np.array_equal(np.asarray(got), v) and np.asarray(got).dtype.kind == v.dtype.kind, k
+        if node['kind'] == 'dataset':
+            got = obj.read()
+            assert got.shape == node['array'].shape and np.array_equal(got, node['array'])
+        else:
+            assert sorted(obj.keys()) == sorted(node['children'])
+            for name, child in node['children'].items():
+                check(child, obj[name])
+
+    path = str(tmp_path / 'random.h5')
+    for latest in (False, True):
+        for split in (False, True):
+            h5_writer.write_h5(path, tree, split_headers=split, latest=latest, superblock_at=512 if split else 0)
+            check(tree, h5_model.H5File(path))
