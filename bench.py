@@ -74,12 +74,45 @@ def _affinity_cores():
         return os.cpu_count() or 1
 
 
+def _physical_cores():
+    """One logical CPU per PHYSICAL core of this process's affinity set (the first hardware thread of every
+    /sys/devices/system/cpu/cpuN/topology/thread_siblings_list group); falls back to the affinity set itself."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return list(range(os.cpu_count() or 1))
+    seen, picked = set(), []
+    for c in allowed:
+        try:
+            with open('/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list' % c) as f:
+                txt = f.read().strip()
+            sib = set()
+            for part in txt.split(','):
+                if '-' in part:
+                    lo, hi = part.split('-')
+                    sib.update(range(int(lo), int(hi) + 1))
+                else:
+                    sib.add(int(part))
+            key = min(sib)
+        except (OSError, ValueError):
+            key = c
+        if key not in seen:
+            seen.add(key)
+            picked.append(c)
+    return picked or allowed
+
+
 def _cpu_worker(args):
     """One host core's share of the cpu_baseline: the numpy oracle ("port") on its own slice of streams.
     Import, weights and PCM synthesis happen BEFORE the start barrier; only the arithmetic is timed.  The loop
     runs until `seconds` have passed (so the sample is bounded whatever the loaded per-core rate turns out to
     be); returns (updates done, own compute time)."""
-    first, n_streams, seconds, n_distinct, seed, barrier = args
+    first, n_streams, seconds, n_distinct, seed, barrier, cpu = args
+    if cpu is not None:
+        try:
+            os.sched_setaffinity(0, {cpu})                  # one worker per physical core, pinned
+        except (AttributeError, OSError):
+            pass
     from oracle import listener as oracle_listener          # checker / baseline only
     try:
         from threadpoolctl import threadpool_limits
@@ -103,9 +136,10 @@ def _cpu_worker(args):
             return n, dt
 
 
-def _cpu_round(cores, streams_per_core, seconds):
+def _cpu_round(cpus, streams_per_core, seconds):
     import multiprocessing as mp
     ctx = mp.get_context('fork')
+    cores = len(cpus)
     barrier = ctx.Barrier(cores)
     procs, results = [], ctx.Queue()
 
@@ -113,8 +147,8 @@ def _cpu_round(cores, streams_per_core, seconds):
         results.put(_cpu_worker(job))
 
     t0 = time.perf_counter()
-    for c in range(cores):
-        pr_ = ctx.Process(target=run, args=((c * streams_per_core, streams_per_core, seconds, 8, 42, barrier),))
+    for i, c in enumerate(cpus):
+        pr_ = ctx.Process(target=run, args=((i * streams_per_core, streams_per_core, seconds, 8, 42, barrier, c),))
         pr_.start()
         procs.append(pr_)
     done = [results.get() for _ in procs]
@@ -128,24 +162,40 @@ def _cpu_round(cores, streams_per_core, seconds):
 
 
 def cpu_baseline(seconds=4.0, streams_per_core=128):
-    """Oracle ("port" of the reference's sonopy + Keras arithmetic, vectorised over streams) on every host core,
-    on a bounded sample of the same workload: ONE round at the batch shape that measured fastest on this pool's
-    256-core hosts (128 streams per core: cache-resident; 1024 per core -- the GPU's own regime -- runs at half that
-    rate because the float64 temporaries fall out of cache and the cores queue on memory; 48 per core is 15 % slower).
-    All workers start their timed loops together (barrier after fork / synthesis) and run for `seconds`;
-    rate = windows of all workers / the longest worker's compute time.  One core alone is timed first."""
-    cores = _affinity_cores()
+    """Oracle ("port" of the reference's sonopy + Keras arithmetic, vectorised over streams) on the host cores, on a
+    bounded sample of the same workload: ONE process per PHYSICAL core, pinned to it (sched_setaffinity; the second
+    hardware thread of a core adds nothing to a float64 numpy loop and un-pinned workers migrate), ONE round at the
+    batch shape that measured fastest on this pool's hosts (128 streams per core: cache-resident; 1024 per core -- the
+    GPU's own regime -- runs at half that rate because the float64 temporaries fall out of cache).  All workers start
+    their timed loops together (barrier after fork / synthesis) and run for `seconds`; rate = windows of all workers /
+    the longest worker's compute time.  One core alone is timed first; `linear_scaling_reference` = that rate x the
+    physical cores (what the box would do if the cores did not share memory bandwidth / clocks)."""
+    logical = _affinity_cores()
+    cpus = _physical_cores()
+    cores = len(cpus)
     from oracle import listener as _warm_import      # noqa: F401  (imported once here: the forked workers inherit it)
-    n_alone, t_alone = _cpu_worker((0, 1024, 1.0, 8, 42, None))                 # one core, nothing else running
-    r = _cpu_round(cores, streams_per_core, seconds)
-    return {'value': r['value'], 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
-            'compute_s': r['compute_s'], 'wall_s': r['wall_s'] + t_alone,
-            'per_core': r['value'] / cores, 'single_core_alone': 1024 * n_alone / t_alone,
+    try:
+        prev = os.sched_getaffinity(0)
+    except AttributeError:
+        prev = None
+    n_alone, t_alone = _cpu_worker((0, 1024, 1.0, 8, 42, None, cpus[0]))        # one core, nothing else running
+    n_a128, t_a128 = _cpu_worker((0, streams_per_core, 1.0, 8, 42, None, cpus[0]))
+    if prev is not None:
+        os.sched_setaffinity(0, prev)
+    r = _cpu_round(cpus, streams_per_core, seconds)
+    alone = max(1024 * n_alone / t_alone, streams_per_core * n_a128 / t_a128)
+    return {'value': r['value'], 'unit': 'windows/s', 'cores': cores, 'physical_cores': cores, 'logical_cpus': logical,
+            'pinned': True, 'kind': 'port',
+            'compute_s': r['compute_s'], 'wall_s': r['wall_s'] + t_alone + t_a128,
+            'per_core': r['value'] / cores, 'single_core_alone': alone,
+            'single_core_alone_1024_streams': 1024 * n_alone / t_alone,
+            'single_core_alone_%d_streams' % streams_per_core: streams_per_core * n_a128 / t_a128,
+            'linear_scaling_reference': alone * cores,
             'rounds': [r],
-            'sample': 'numpy oracle (float64 MFCC + float32 GRU), one process per core on %d cores, %d streams per core, timed '
-                      'loops start together after fork/synthesis and run %.0f s: %d windows in %.1f s = %.0f windows/s; '
-                      'one core alone at 1024 streams: %.0f windows/s'
-                      % (cores, streams_per_core, seconds, r['windows'], r['compute_s'], r['value'], 1024 * n_alone / t_alone)}
+            'sample': 'numpy oracle (float64 MFCC + float32 GRU), one pinned process per physical core on %d cores (%d logical '
+                      'CPUs), %d streams per core, timed loops start together after fork/synthesis and run %.0f s: %d windows in '
+                      '%.1f s = %.0f windows/s; one core alone: %.0f windows/s (x %d cores = %.0f if the cores scaled linearly)'
+                      % (cores, logical, streams_per_core, seconds, r['windows'], r['compute_s'], r['value'], alone, cores, alone * cores)}
 
 
 def cpu_baseline_single_stream(seconds=3.0):
@@ -197,16 +247,29 @@ def wait_for_gpu():
     torch.cuda.synchronize()
 
 
-def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_precision, ring_precision, steps, warmup, n_res, tol):
-    """One non-headline BASELINE.json configuration on this GPU (N = 1 only, after the headline's timed region): the same
-    step definition, its own roofline object, and a parity spot-check of the timed region's last probabilities against
-    the oracle (the checker: never inside a timed region) on the first 8 streams."""
+def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_precision, ring_precision, steps, warmup, n_res, tol,
+                 params_kw=None, roofline_kind=None):
+    """One non-headline configuration on this GPU (N = 1 only, after the headline's timed region): the same step
+    definition, its own roofline object, and a parity spot-check of the timed region's last probabilities against
+    the oracle (the checker: never inside a timed region) on the first 8 streams.
+    params_kw: ListenerParams overrides (n_fft / n_filt / n_mfcc ...: the general front end, params.py:28-118).
+    roofline_kind: 'hbm' (fused launch vs HBM), 'mfma' (network launch vs fp32 MFMA), 'mfma_fused' (fused launch vs fp32
+    MFMA: the capacity point, where the update IS the network + MFCC roles of one launch), 'hbm_mfcc' (MFCC launch vs HBM)."""
+    import warnings
     from oracle import listener as oracle_listener
-    weights = synth.make_weights(units=units)
+    hpr, opr = pr, None
+    if params_kw:
+        hpr = pr.copy()
+        hpr.__dict__.update(params_kw)
+        opr = oracle_listener.Params(**params_kw)
+    n_mfcc = int(hpr.n_mfcc)
+    weights = synth.make_weights(n_in=n_mfcc, units=units)
     stock = units == (20,)
-    flop_per_window = 2 * sum(29 * 3 * h * (f + h) for f, h in zip((13,) + units[:-1], units)) + 2 * units[-1]
-    engine = HipEngine(pr, weights, n_streams=streams, device=dev_index, mfcc_precision=mfcc_precision,
-                       gru_precision=gru_precision, ring_precision=ring_precision)
+    flop_per_window = 2 * sum(29 * 3 * h * (f + h) for f, h in zip((n_mfcc,) + units[:-1], units)) + 2 * units[-1]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        engine = HipEngine(hpr, weights, n_streams=streams, device=dev_index, mfcc_precision=mfcc_precision,
+                           gru_precision=gru_precision, ring_precision=ring_precision)
     pcm = synth_pcm_device(n_res, streams, 0, device)
     out = torch.zeros((streams,), dtype=torch.float32, device=device)
     st = torch.cuda.current_stream().cuda_stream
@@ -233,39 +296,56 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
     update_ms = ev0.elapsed_time(ev1) / n_b
     engine.set_fused(False)
     engine.set_timing(True)
-    g_ms = []
+    g_ms, m_ms = [], []
     for i in range(min(steps, 40)):
         run(warmup + steps + n_b + i, 1)
-        g_ms.append(engine.last_timing()[1])
+        tm = engine.last_timing()
+        m_ms.append(tm[0])
+        g_ms.append(tm[1])
     engine.set_timing(False)
     engine.close()
-    gru_ms = float(np.mean(g_ms))
+    gru_ms, mfcc_ms = float(np.mean(g_ms)), float(np.mean(m_ms))
     # parity spot-check: the oracle replays the same chunks for streams 0..7
     host = pcm[:, :8].cpu().numpy()
-    oracle = oracle_listener.BatchedOracle(weights, 8)
+    oracle = oracle_listener.BatchedOracle(weights, 8, opr) if opr is not None else oracle_listener.BatchedOracle(weights, 8)
     want = None
     for i in range(warmup + steps):
         want = oracle.update_raw(host[i % n_res])
     err = float(np.abs(np.asarray(want, dtype=np.float64) - got).max())
-    hbm_bound = gru_precision == 'bf16'
-    bytes_per_window = 2048 + 1.28 * 13 * (2 if ring_precision == 'bf16' else 4)
-    if hbm_bound:
-        ach = bytes_per_window * streams / (update_ms * 1e-3) / 1e9
-        roof = {'kernel': 'fused_update_bf16_kernel<%s, ShapeStock>' % ('double' if mfcc_precision == 'f64' else 'float'), 'bound': 'hbm',
+    if roofline_kind is None:
+        roofline_kind = 'hbm' if gru_precision == 'bf16' else 'mfma'
+    mfcc_name = 'double' if mfcc_precision == 'f64' else 'float'
+    bytes_per_window = 2048 + 1.28 * n_mfcc * (2 if ring_precision == 'bf16' else 4)
+    if roofline_kind in ('hbm', 'hbm_mfcc'):
+        ms = update_ms if roofline_kind == 'hbm' else mfcc_ms
+        ach = bytes_per_window * streams / (ms * 1e-3) / 1e9
+        kern = ('fused_update_bf16_kernel<%s, ShapeStock>' % mfcc_name if roofline_kind == 'hbm'
+                else 'mfcc_general_stream_kernel<%s> (one HIP event pair per launch)' % mfcc_name)
+        roof = {'kernel': kern, 'bound': 'hbm',
                 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
-                'avg_launch_ms': update_ms, 'algorithmic': '%.1f B/window x %d windows/launch' % (bytes_per_window, streams)}
+                'avg_launch_ms': ms, 'algorithmic': '%.1f B/window x %d windows/launch' % (bytes_per_window, streams)}
     else:
-        ach = flop_per_window * streams / (gru_ms * 1e-3) / 1e12
-        roof = {'kernel': 'gru_wide_kernel<%d, 1, 4>' % ((units[0] + 63) // 64) if not stock else 'network launch', 'bound': 'mfma',
+        fused = roofline_kind == 'mfma_fused'
+        ms = update_ms if fused else gru_ms
+        ach = flop_per_window * streams / (ms * 1e-3) / 1e12
+        kern = ('fused_update_kernel<%s, ShapeStock, 5, false, false, false> (network || MFCC || bookkeeping roles)' % mfcc_name if fused
+                else ('gru_wide_kernel<%d, 1, 4>' % ((units[0] + 63) // 64) if not stock else 'network launch'))
+        roof = {'kernel': kern, 'bound': 'mfma',
                 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
-                'avg_launch_ms': gru_ms, 'algorithmic': '%d flop/window x %d windows/launch' % (flop_per_window, streams)}
-    return {'name': name, 'value': streams * steps / elapsed, 'unit': 'windows/s', 'ms_per_step': 1e3 * elapsed / steps,
-            'steps': steps, 'warmup': warmup, 'dtype': gru_precision,
-            'config': {'workload': name, 'streams_per_gpu': streams, 'gru': 'H=%s' % ','.join(map(str, units)),
-                       'mfcc_dtype': mfcc_precision, 'feature_rows': ring_precision},
-            'roofline': roof,
-            'parity': {'max_abs_err': err, 'tol': tol, 'streams_checked': 8, 'ok': bool(err <= tol),
-                       'against': 'oracle.listener.BatchedOracle on the same chunks (checker, outside the timed region)'}}
+                'avg_launch_ms': ms, 'algorithmic': '%d flop/window x %d windows/launch' % (flop_per_window, streams)}
+    res = {'name': name, 'value': streams * steps / elapsed, 'unit': 'windows/s', 'ms_per_step': 1e3 * elapsed / steps,
+           'realtime_streams': streams * steps / elapsed / REALTIME_WINDOWS_PER_S,
+           'steps': steps, 'warmup': warmup, 'dtype': gru_precision,
+           'config': {'workload': name, 'streams_per_gpu': streams, 'gru': 'H=%s' % ','.join(map(str, units)),
+                      'mfcc_dtype': mfcc_precision, 'feature_rows': ring_precision,
+                      'resident_pcm_mb': n_res * chunk_bytes / 1e6},
+           'stage_ms': {'update_back_to_back': update_ms, 'mfcc_launch_alone': mfcc_ms, 'network_launch_alone': gru_ms},
+           'roofline': roof,
+           'parity': {'max_abs_err': err, 'tol': tol, 'streams_checked': 8, 'ok': bool(err <= tol),
+                      'against': 'oracle.listener.BatchedOracle on the same chunks (checker, outside the timed region)'}}
+    if params_kw:
+        res['config']['listener_params'] = dict(params_kw)
+    return res
 
 
 def main():
@@ -284,6 +364,7 @@ def main():
     ap.add_argument('--gru-waves', type=int, default=0, help='pe_set_gru_waves: 0 automatic (default), 1 or 4 waves per tile')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-configs', action='store_true', help='skip the non-headline BASELINE configurations (wide 256x2, bf16) after the headline')
+    ap.add_argument('--only-extra', default='', help='run only the extra configurations whose name contains this text')
     ap.add_argument('--no-batched', action='store_true', help='skip the pe_update_many extra (profiling runs: keeps per-kernel means clean)')
     ap.add_argument('--roofline-launches', type=int, default=2000,
                     help='back-to-back launches of the roofline pass that precedes the warm-up (HIP events around the run)')
@@ -318,7 +399,7 @@ def main():
     B = args.streams
     n_global = B * world
     steps, warmup = args.steps, args.warmup
-    n_res = min(args.resident_updates, warmup + steps)
+    n_res = max(2, args.resident_updates)          # independent of --steps: the input working set (n_res x B x 2 KB) is the same for every command line
 
     units = tuple(int(u) for u in args.units.split(','))
     weights = synth.make_weights(units=units)
@@ -445,14 +526,29 @@ def main():
 
     # ---- the other BASELINE.json configurations that fit one GPU (N = 1 only; each a few seconds) -------------------
     extras = []
+    only = args.only_extra
     if world == 1 and rank == 0 and not args.no_extra_configs and stock and args.gru_precision == 'f32' and B == 4096:
-        for cfg in (('configs[3]: wide GRU 256x2 fp32, batch=4096 synthetic 16 kHz streams on 1 MI355X', (256, 256), 4096, 'f64', 'f32', 'f32', 100, 40, 64, 1e-4),
-                    ('configs[4] shard: bf16 MFCC rows + bf16 GRU (f32 front end), batch=8192 streams per MI355X (65536 / 8)', (20,), 8192, 'f32', 'bf16', 'bf16', 200, 40, 64, 1e-2),
-                    ('configs[4] on one GPU: bf16 MFCC rows + bf16 GRU (f32 front end), batch=65536 streams', (20,), 65536, 'f32', 'bf16', 'bf16', 100, 40, 32, 1e-2)):
+        for cfg in (dict(name='configs[3]: wide GRU 256x2 fp32, batch=4096 synthetic 16 kHz streams on 1 MI355X', units=(256, 256), streams=4096,
+                         mfcc_precision='f64', gru_precision='f32', ring_precision='f32', steps=100, warmup=40, n_res=64, tol=1e-4),
+                    dict(name='configs[4] shard: bf16 MFCC rows + bf16 GRU (f32 front end), batch=8192 streams per MI355X (65536 / 8)', units=(20,), streams=8192,
+                         mfcc_precision='f32', gru_precision='bf16', ring_precision='bf16', steps=200, warmup=40, n_res=64, tol=1e-2),
+                    dict(name='configs[4] on one GPU: bf16 MFCC rows + bf16 GRU (f32 front end), batch=65536 streams', units=(20,), streams=65536,
+                         mfcc_precision='f32', gru_precision='bf16', ring_precision='bf16', steps=100, warmup=40, n_res=32, tol=1e-2),
+                    # the metric's second half ("max concurrent real-time streams") is a large-batch figure: the stock
+                    # configuration (float64 MFCC as the reference computes it, float32 GRU) with the machine full
+                    dict(name='capacity: stock GRU fp32 + f64 MFCC, batch=65536 streams on 1 MI355X (max concurrent real-time streams)', units=(20,), streams=65536,
+                         mfcc_precision='f64', gru_precision='f32', ring_precision='f32', steps=100, warmup=40, n_res=32, tol=1e-4,
+                         roofline_kind='mfma_fused'),
+                    # a non-stock .params file (params.py:28-118): the general front end (mfcc_general_device.h)
+                    dict(name='general front end: n_fft=1024, n_filt=40, n_mfcc=20 (non-stock ListenerParams), stock-width GRU fp32, batch=4096 streams', units=(20,), streams=4096,
+                         mfcc_precision='f64', gru_precision='f32', ring_precision='f32', steps=100, warmup=40, n_res=64, tol=1e-4,
+                         params_kw=dict(n_fft=1024, n_filt=40, n_mfcc=20), roofline_kind='hbm_mfcc')):
+            if only and only not in cfg['name']:
+                continue
             try:
-                extras.append(extra_config(cfg[0], device, dev_index, *cfg[1:]))
+                extras.append(extra_config(device=device, dev_index=dev_index, **cfg))
             except Exception as ex:                                  # noqa: BLE001  (an extra must not cost the headline line)
-                extras.append({'name': cfg[0], 'error': repr(ex)})
+                extras.append({'name': cfg['name'], 'error': repr(ex)})
 
     def pmc_traffic(kernel):
         """HBM bytes per launch from the committed rocprofv3 PMC summary (bench.py cannot collect PMC
@@ -477,9 +573,13 @@ def main():
 
         mfcc_name = 'double' if args.mfcc_precision == 'f64' else 'float'
         mfma_peak = MFMA_F32_PEAK_TFLOPS if args.gru_precision == 'f32' else MFMA_BF16_PEAK_TFLOPS
-        four_waves = (B + 15) // 16 <= torch.cuda.get_device_properties(device).multi_processor_count   # engine.hip: gru_args
+        # the engine's own rule (engine.hip: gru_args): stock width re-tiled while tiles <= 2 x CUs (or forced), four waves per
+        # tile while tiles <= 2 x CUs on the re-tiled shapes / <= CUs on the classic tiling (or forced)
+        n_cus = torch.cuda.get_device_properties(device).multi_processor_count
+        tiles = (B + 15) // 16
+        retiled = (tiles <= 2 * n_cus) if args.gru_tiling < 0 else bool(args.gru_tiling)
+        four_waves = (tiles <= (2 * n_cus if retiled else n_cus)) if not args.gru_waves else args.gru_waves == 4
         mfcc_kernel = 'mfcc_kernel<%s, ShapeStock, true>' % mfcc_name
-        retiled = four_waves if args.gru_tiling < 0 else bool(args.gru_tiling)       # engine.hip: gru_args (stock width only)
         fused_name = ('fused_update_kernel<%s, ShapeStock, 5, %s, false, %s>' % (mfcc_name, 'true' if four_waves else 'false', 'true' if retiled else 'false')
                       if args.gru_precision == 'f32' else 'fused_update_bf16_kernel<%s, ShapeStock>' % mfcc_name)
         gru_name = ((('gru_cw_kernel' if retiled else 'gru_mw_kernel<5, false>') if four_waves else
@@ -502,9 +602,12 @@ def main():
             'ms_per_step': 1e3 * elapsed / steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.gru_precision, 'data': 'synthetic',
-            'config': {'workload': '%s GRU (default ListenerParams) %s, batch=%d synthetic 16 kHz '
-                                   'streams per MI355X, one 1024-sample chunk per stream per step'
-                                   % ('stock' if stock else 'wide %s' % 'x'.join(map(str, units)), args.gru_precision, B),
+            'config': {'workload': '%s%s GRU (default ListenerParams) %s, batch=%d synthetic 16 kHz '
+                                   'streams per MI355X%s, one 1024-sample chunk per stream per step'
+                                   % ('BASELINE configs[1]: ' if (stock and world == 1 and B == 4096 and args.gru_precision == 'f32') else
+                                      'BASELINE configs[2]: ' if (stock and world == 8 and B == 4096 and args.gru_precision == 'f32') else '',
+                                      'stock' if stock else 'wide %s' % 'x'.join(map(str, units)), args.gru_precision, B,
+                                      ' (batch=%d streams sharded across %d x MI355X, RCCL gather over xGMI)' % (n_global, world) if world > 1 else ''),
                        'streams_per_gpu': B, 'global_streams': n_global, 'chunk_samples': CHUNK,
                        'gru': 'H=%s, T=29, F=13, ' % args.units + ('f32 MFMA 16x16x4' if args.gru_precision == 'f32' else 'bf16 MFMA 16x16x32, f32 accumulate'),
                        'mfcc_dtype': args.mfcc_precision, 'feature_rows': args.ring_precision,
@@ -514,6 +617,9 @@ def main():
             # what the communicator reported and every rank's own clock around the timed region (value uses the max)
             'sequence': 'roofline pass (%d back-to-back launches, HIP events) -> %d warm-up steps -> %d timed steps; a region entered '
                         'from an idle GPU measures ~8 %% slower (DESIGN 5)' % (roofline_launches, warmup, steps),
+            'untimed_launches_before_timed_region': roofline_launches + warmup,
+            'resident_pcm': {'slabs': n_res, 'mb': n_res * chunk_bytes / 1e6,
+                             'note': 'distinct [B][1024] int16 slabs cycled by every pass; independent of --steps'},
             'ranks_seen': ranks_seen, 'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms)},
             # dominant kernel of the timed region: the fused launch (GRU role is its long pole)
             'roofline': ({'kernel': fused_name, 'bound': 'hbm', 'achieved': gbs_w(fused_ms), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

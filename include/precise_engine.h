@@ -44,9 +44,16 @@ typedef struct pe_params {
     int32_t sample_rate;     /* 16000                                        params.py:142 */
     int32_t window_samples;  /* 1600   int(sample_rate*window_t+0.5)         params.py:84  */
     int32_t hop_samples;     /* 800    int(sample_rate*hop_t+0.5)            params.py:89  */
-    int32_t n_fft;           /* 512    (only 512 has a kernel)               params.py:142 */
-    int32_t n_filt;          /* 20     mel filters, <= 64                    params.py:142 */
-    int32_t n_mfcc;          /* 13     coefficients kept, <= 16              params.py:142 */
+    int32_t n_fft;           /* 512    any power of two in 64..2048          params.py:142 */
+    int32_t n_filt;          /* 20     mel filters, 1..128                   params.py:142 */
+    int32_t n_mfcc;          /* 13     coefficients kept, 1..32, <= n_filt   params.py:142
+                                Front-end kernels: the stock shape (n_fft = 512, <= 64 filters whose runs fit the 64
+                                lanes of a wave, <= 16 coefficients) runs on the one-frame-per-wave kernel and the fused
+                                launch; EVERY OTHER shape in the ranges above runs on the general front end (same
+                                results contract, two launches per update, pe_update_many = the same updates one after
+                                the other).  17..32 coefficients feed the float32 network of <= 32 units without
+                                use_delta only; the bf16 configuration exists for the stock shape only.  Outside the
+                                ranges (n_fft not a power of two, > 2048, ...): PE_ERR_UNSUPPORTED.                  */
     int32_t n_features;      /* 29     T, timesteps per network input        params.py:79  */
     int32_t use_delta;       /* 0      1: network inputs are [x_t, x_t - x_(t-1)]
                                        (vectorization.py:53-59), layer n_in = 2 n_mfcc   params.py:143 */
@@ -158,8 +165,9 @@ int pe_vectorize_raw(pe_engine* e, const double* audio_host, int64_t n_samples,
                      double* feats_out_host, int64_t max_frames, int64_t* n_frames_out);
 
 /* The same buffer through the Vectorizer.mels entry (vectorization.py:32-35 -> sonopy.mel_spec): log of the
- * mel filterbank energies, no DCT.  mels_out[max_frames][n_filt] float64.  Offline form only: a streaming
- * engine whose network consumes mel features (feature_size = n_filt > 16) has no kernel. */
+ * mel filterbank energies, no DCT.  mels_out[max_frames][n_filt] float64.  Offline form only, as in the reference:
+ * its Listener allocates the feature window n_mfcc wide (network_runner.py:104,123), so mel rows of n_filt columns
+ * cannot stream through it either; pe_create refuses vectorizer = 1. */
 int pe_vectorize_mels(pe_engine* e, const double* audio_host, int64_t n_samples,
                       double* mels_out_host, int64_t max_frames, int64_t* n_frames_out);
 
@@ -212,19 +220,20 @@ int pe_set_fused(pe_engine* e, int32_t enabled);
  * order), each is deterministic; changing the setting restarts all streams. */
 int pe_set_input_projection(pe_engine* e, int32_t enabled);
 
-/* Network kernel shape: 0 (default) = automatic (four waves share each 16-stream tile while the
- * engine has no more tiles than the device has compute units -- 256 on MI355X, i.e. 4096 streams -- one wave
- * per tile beyond; use_delta networks always take the one-wave kernel), 1 / 4 = forced: results are bit-identical.
+/* Network kernel shape: 0 (default) = automatic -- four waves share each 16-stream tile while the engine has few
+ * tiles (stock width 17..20 units, re-tiled: up to 2 tiles per compute unit = 8192 streams on MI355X, the
+ * critical-wave kernel, use_delta included; other widths: up to 1 tile per compute unit, and use_delta on the
+ * one-wave kernel), one wave per tile beyond -- 1 / 4 = forced: results are bit-identical.
  * 16 = sixteen lanes per stream without matrix cores (needs pe_set_input_projection(e, 1); its own summation order:
  * agrees to ~5e-6; slower, kept for measurement). */
 int pe_set_gru_waves(pe_engine* e, int32_t waves_per_tile);
 
 /* Tiling of the stock-width float32 network (17..20 units, model.py:76-82): 1 = three full MFMA tiles + partial sums
  * for units 16..19 (csrc/gru_cw_device.h: shortens the four-wave kernel's timestep), 0 = the classic four tiles,
- * -1 (default) = automatic (re-tiled while the engine has no more tiles than the device has compute units).  Every
+ * -1 (default) = automatic (re-tiled while the engine has no more than two tiles per compute unit).  Every
  * kernel shape of ONE tiling agrees bit for bit (pe_update / pe_update_many / pe_predict / pe_evaluate, one or four
  * waves, fused or not); the two tilings agree to float32 summation order (<= 1e-6 on the probability).  Ignored by
- * the other networks (other widths, use_delta, bf16, wide, projection rows). */
+ * the other networks (other widths, bf16, wide, projection rows); use_delta models of the stock width follow it. */
 int pe_set_gru_tiling(pe_engine* e, int32_t tiling);
 
 /* HIP-event timing of the kernels launched by the last *_device/host update on this engine

@@ -581,8 +581,11 @@ bool can_fuse(const pe_engine* e, int chunk) {
     if (!(e->fused && !e->general && !e->wide && e->table_layout.mel_pad == 10 && chunk <= emit_window(e->prm) - frame_len_of(e->prm))) return false;
     if (e->prm.gru_precision == 0 && gru_small_regs(e->units) >= 6 && gru_args(e).waves_per_tile != 4) return false;
     if (e->prm.use_delta && e->prm.gru_precision == 0) {        // re-tiled one-wave shape with delta inputs: no fused instantiation
+        // (waves_per_tile == 4 is not enough: the four-wave shape needs the 32-slot ring it stages in LDS -- after
+        //  pe_reserve_updates, or with a longer feature window, the launcher falls back to the one-wave shape, whose
+        //  fused instantiation has no delta inputs)
         const GruArgs g = gru_args(e);
-        if (g.cw && g.waves_per_tile != 4) return false;
+        if (g.cw && (g.waves_per_tile != 4 || e->ring_slots != kCwSlots || e->prm.n_features > kCwSlots)) return false;
     }
     return true;
 }

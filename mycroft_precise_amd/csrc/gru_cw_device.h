@@ -34,7 +34,6 @@
 
 namespace pe {
 
-constexpr int kCwSlots = 32;            // ring slots the four-wave shape stages in LDS (the engine's ring for T <= 29 + pending)
 
 // LDS of one tile (floats): the mailboxes (CwBox), then the staged ring
 struct CwLds {

@@ -14,6 +14,7 @@ constexpr int kCarryCap = 512;      // int16 samples of leftover PCM kept per st
 constexpr int kNfft = 512;          // the only FFT size with a kernel
 constexpr int kBins = kNfft / 2 + 1;
 constexpr int kMaxFilt = 64;
+constexpr int kCwSlots = 32;        // ring slots the four-wave critical-wave GRU kernel stages in LDS (gru_cw_device.h): the engine's ring for T <= 29 + pending
 
 template <class R> struct cplx { R x, y; };
 

@@ -28,6 +28,11 @@ import numpy as np
 
 SIGNATURE = b'\x89HDF\r\n\x1a\n'
 UNDEF = 0xFFFFFFFFFFFFFFFF
+# Bounds for damaged / hostile files: every structure is visited once (cyclic B-trees and continuation chains end in
+# H5FormatError, not in a hang), and no dataset or attribute may claim more memory than a wake-word model could need
+MAX_DATASET_BYTES = 1 << 28         # 256 MiB per dataset (the stock network is 8 KB, the widest kernel holds 2.4 MB)
+MAX_HEADER_BLOCKS = 4096            # object-header continuation blocks per object
+MAX_TREE_DEPTH = 64
 
 
 class H5Unsupported(NotImplementedError):
@@ -59,6 +64,8 @@ class _Buf:
         return v
 
     def skip(self, n):
+        if n < 0:
+            raise H5FormatError('negative skip of %d bytes at %d' % (n, self.p))
         self.p += n
 
 
@@ -78,8 +85,10 @@ class _Datatype:
         raise H5Unsupported('datatype class %d as an array element' % self.cls)
 
 
-def _parse_datatype(b):
+def _parse_datatype(b, depth=0):
     """Datatype message (0x0003) at the cursor; leaves the cursor behind its properties."""
+    if depth > 4:
+        raise H5FormatError('datatype nested deeper than 4 levels')
     word = b.u(4)
     cls, version, bits = word & 0xF, (word >> 4) & 0xF, word >> 8
     size = b.u(4)
@@ -88,6 +97,8 @@ def _parse_datatype(b):
     order = '>' if bits & 1 else '<'
     if cls == 0:                                     # fixed point: bit offset, precision
         b.skip(4)
+        if size not in (1, 2, 4, 8):
+            raise H5Unsupported('%d-byte integers' % size)
         return _Datatype(0, size, order, signed=bool(bits & 8))
     if cls == 1:                                     # floating point: 12 bytes of layout (IEEE assumed, checked by size)
         if bits & 0x40:
@@ -95,9 +106,11 @@ def _parse_datatype(b):
         b.skip(12)
         return _Datatype(1, size, order)
     if cls == 3:                                     # fixed-length string: padding type in bits 0-3
+        if size < 1 or size > MAX_DATASET_BYTES:
+            raise H5FormatError('fixed-length string of %d bytes' % size)
         return _Datatype(3, size, strpad=bits & 0xF)
     if cls == 9:                                     # variable length: base type follows
-        base = _parse_datatype(b)
+        base = _parse_datatype(b, depth + 1)
         return _Datatype(9, size, base=base, vlen_string=(bits & 0xF) == 1)
     raise H5Unsupported('datatype class %d (compound / reference / enum / array / opaque / time / bitfield)' % cls)
 
@@ -112,10 +125,23 @@ def _parse_dataspace(b, L):
             return None                              # null dataspace
     else:
         raise H5Unsupported('dataspace message version %d' % version)
+    if rank > 32:
+        raise H5FormatError('dataspace of rank %d' % rank)
     dims = tuple(b.u(L) for _ in range(rank))
     if flags & 1:
         b.skip(rank * L)                             # maximum dimensions
     return dims
+
+
+def _count(shape, itemsize):
+    """Elements of a dataspace, refused when they could not be a model's (a flipped bit in a dimension must not
+    turn into a multi-gigabyte allocation)."""
+    count = 1
+    for dim in shape or ():
+        count *= int(dim)
+        if count * itemsize > MAX_DATASET_BYTES:
+            raise H5FormatError('dataspace %r x %d bytes exceeds the %d-byte bound of this reader' % (tuple(shape), itemsize, MAX_DATASET_BYTES))
+    return count
 
 
 class _Object:
@@ -200,9 +226,15 @@ class _Object:
             raise H5FormatError('object at %d has no dataspace' % self.addr)
         return _parse_dataspace(_Buf(self.f.data, m[2]), self.f.L)
 
+    def _datatype(self):
+        m = self._first(0x03)
+        if m is None:
+            raise H5FormatError('object at %d has no datatype' % self.addr)
+        return _parse_datatype(_Buf(self.f.data, m[2]))
+
     @property
     def dtype(self):
-        return _parse_datatype(_Buf(self.f.data, self._first(0x03)[2])).numpy()
+        return self._datatype().numpy()
 
     def read(self):
         """The dataset as a numpy array in native byte order."""
@@ -210,9 +242,9 @@ class _Object:
         shape = self.shape
         if shape is None:
             return None
-        dt = _parse_datatype(_Buf(f.data, self._first(0x03)[2]))
+        dt = self._datatype()
         nd = dt.numpy()
-        count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        count = _count(shape, nd.itemsize)
         lay = self._first(0x08)
         if lay is None:
             raise H5FormatError('dataset at %d has no layout message' % self.addr)
@@ -236,6 +268,9 @@ class _Object:
             rank = b.u(1)
             btree = b.u(f.O)
             chunk = tuple(b.u(4) for _ in range(rank))         # last entry: the element size
+            if rank != len(shape) + 1 or any(c < 1 for c in chunk):
+                raise H5FormatError('dataset at %d: chunk dimensions %r for shape %r' % (self.addr, chunk, shape))
+            _count(chunk[:-1], nd.itemsize)
             raw = f._read_chunked(btree, shape, chunk[:-1], nd.itemsize, self._filters())
         else:
             raise H5Unsupported('data layout class %d (virtual)' % cls)
@@ -321,8 +356,12 @@ class H5File(_Object):
                 b.skip(4)
             size = b.u(1 << (flags & 3))
             blocks = [(b.p, size)]
+            seen = set()
             while blocks:
                 start, n = blocks.pop(0)
+                if start in seen or len(seen) >= MAX_HEADER_BLOCKS:
+                    raise H5FormatError('object header at %d: cyclic or endless continuation chain' % addr)
+                seen.add(start)
                 b = _Buf(d, start)
                 end = start + n
                 while b.p + 4 <= end:
@@ -334,6 +373,8 @@ class H5File(_Object):
                         caddr, clen = c.u(self.O), c.u(self.L)
                         if d[self.base + caddr:self.base + caddr + 4] != b'OCHK':
                             raise H5FormatError('continuation block without signature at %d' % caddr)
+                        if clen < 8:
+                            raise H5FormatError('continuation block of %d bytes at %d' % (clen, caddr))
                         blocks.append((self.base + caddr + 4, clen - 8))
                     elif kind != 0:
                         msgs.append((kind, mflags, b.p, msize))
@@ -347,8 +388,12 @@ class H5File(_Object):
         size = b.u(4)
         b.skip(4)                                    # header is padded to 8 bytes
         blocks = [(b.p, size)]
+        seen = set()
         while blocks:
             start, n = blocks.pop(0)
+            if start in seen or len(seen) >= MAX_HEADER_BLOCKS:
+                raise H5FormatError('object header at %d: cyclic or endless continuation chain' % addr)
+            seen.add(start)
             b = _Buf(d, start)
             while b.p + 8 <= start + n:
                 kind, msize, mflags = b.u(2), b.u(2), b.u(1)
@@ -366,8 +411,13 @@ class H5File(_Object):
 
     # ---- old-style groups -----------------------------------------------------------------------
     def _heap_string(self, heap_data, off):
-        end = self.data.index(b'\0', heap_data + off)
-        return self.data[heap_data + off:end].decode('utf-8')
+        start = heap_data + off
+        if start < 0 or start >= len(self.data):
+            raise H5FormatError('link name at %d lies outside the file' % start)
+        end = self.data.find(b'\0', start, start + 4096)
+        if end < 0:
+            raise H5FormatError('unterminated link name at %d' % start)
+        return self.data[start:end].decode('utf-8')
 
     def _group_entries(self, btree, heap):
         d = self.data
@@ -377,8 +427,12 @@ class H5File(_Object):
         h.skip(4 + 2 * self.L)
         heap_data = self.base + h.u(self.O)
         out = {}
+        seen = set()
 
-        def node(addr):
+        def node(addr, depth=0):
+            if addr in seen or depth > MAX_TREE_DEPTH:
+                raise H5FormatError('group B-tree at %d: cyclic or too deep' % btree)
+            seen.add(addr)
             b = _Buf(d, self.base + addr)
             sig = b.raw(4)
             if sig == b'TREE':
@@ -388,7 +442,7 @@ class H5File(_Object):
                 b.skip(2 * self.O)
                 for _ in range(used):
                     b.skip(self.L)                   # key
-                    node(b.u(self.O))
+                    node(b.u(self.O), depth + 1)
             elif sig == b'SNOD':
                 b.skip(2)
                 for _ in range(b.u(2)):
@@ -438,7 +492,7 @@ class H5File(_Object):
         p += pad(n_ds)
         if shape is None:
             return name, None
-        count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        count = _count(shape, max(1, dt.size))
         if dt.cls == 9:
             if not dt.vlen_string:
                 raise H5Unsupported('variable-length sequence attribute %r' % name)
@@ -451,6 +505,8 @@ class H5File(_Object):
             value = vals[0] if shape == () else np.array(vals, dtype=object).reshape(shape)
             return name, value
         nd = dt.numpy()
+        if p + count * nd.itemsize > len(self.data):
+            raise H5FormatError('attribute %r: %d elements of %d bytes run past the end of the file' % (name, count, nd.itemsize))
         arr = np.frombuffer(self.data[p:p + count * nd.itemsize], dtype=nd, count=count).reshape(shape)
         if dt.cls == 3:
             arr = np.array([v.split(b'\0')[0] if dt.strpad != 2 else v.rstrip(b' ') for v in arr.ravel()], dtype=object).reshape(shape)
@@ -482,8 +538,13 @@ class H5File(_Object):
             return bytes(int(np.prod(shape, dtype=np.int64)) * itemsize)
         out = np.zeros(shape, dtype='V%d' % itemsize)
         d = self.data
+        seen = set()
+        chunk_bytes = int(np.prod(chunk, dtype=np.int64)) * itemsize
 
-        def node(addr):
+        def node(addr, depth=0):
+            if addr in seen or depth > MAX_TREE_DEPTH:
+                raise H5FormatError('chunk B-tree at %d: cyclic or too deep' % btree)
+            seen.add(addr)
             b = _Buf(d, self.base + addr)
             if b.raw(4) != b'TREE':
                 raise H5FormatError('no chunk B-tree node at %d' % addr)
@@ -496,14 +557,17 @@ class H5File(_Object):
                 offs = [b.u(8) for _ in range(rank + 1)][:rank]
                 child = b.u(self.O)
                 if level > 0:
-                    node(child)
+                    node(child, depth + 1)
                     continue
                 raw = d[self.base + child:self.base + child + nbytes]
                 for i, (fid, vals) in reversed(list(enumerate(filters))):
                     if mask & (1 << i):
                         continue
                     if fid == 1:
-                        raw = zlib.decompress(raw)
+                        z = zlib.decompressobj()
+                        raw = z.decompress(raw, chunk_bytes + 64)        # (a chunk inflates to chunk_bytes, + fletcher32)
+                        if z.unconsumed_tail:
+                            raise H5FormatError('chunk at %d inflates beyond its %d bytes' % (child, chunk_bytes))
                     elif fid == 2:                   # shuffle: byte planes -> elements
                         n = len(raw) // itemsize
                         raw = np.frombuffer(raw[:n * itemsize], np.uint8).reshape(itemsize, n).T.tobytes() + raw[n * itemsize:]
@@ -511,6 +575,10 @@ class H5File(_Object):
                         raw = raw[:-4]
                     else:
                         raise H5Unsupported('filter %d (only deflate, shuffle, fletcher32)' % fid)
+                if len(raw) < chunk_bytes:
+                    raise H5FormatError('chunk at %d holds %d of %d bytes' % (child, len(raw), chunk_bytes))
+                if any(o >= s_ for o, s_ in zip(offs, shape)):
+                    raise H5FormatError('chunk at %d lies outside the dataset (offset %r, shape %r)' % (child, offs, shape))
                 block = np.frombuffer(raw, dtype='V%d' % itemsize, count=int(np.prod(chunk, dtype=np.int64))).reshape(chunk)
                 sel = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, chunk, shape))
                 out[sel] = block[tuple(slice(0, s.stop - s.start) for s in sel)]
@@ -522,9 +590,24 @@ def _names(value):
     return [v.decode('utf-8') if isinstance(v, (bytes, np.bytes_)) else str(v) for v in np.atleast_1d(value)]
 
 
-def weights_from_net(path) -> dict:
-    """The GRU + Dense weights of a Keras ``.net`` (the layout tools/export_net_to_npz.py documents), as
-    ``model.load_weights`` returns them.  model.py:76-82: GRU layer(s) named 'net', then Dense(1)."""
+class NotAPreciseModel(ValueError):
+    """The file parsed, but it does not hold GRU layer(s) + Dense(1) the way model.py:76-82 builds them."""
+
+
+def _guard(fn, path):
+    """Run the parser; whatever a damaged file makes it trip over (an index past the end, a missing message, a bad
+    deflate stream, undecodable text, runaway recursion) surfaces as H5FormatError -- the two documented
+    exception types (H5FormatError / H5Unsupported) are the whole error surface of this module."""
+    try:
+        return fn()
+    except (H5Unsupported, H5FormatError, NotAPreciseModel):
+        raise
+    except (KeyError, IndexError, TypeError, AttributeError, ValueError, OverflowError, zlib.error, UnicodeDecodeError,
+            RecursionError, MemoryError) as ex:
+        raise H5FormatError('%s: damaged or not a Keras HDF5 file (%s: %s)' % (path, type(ex).__name__, ex)) from ex
+
+
+def _weights_from_net(path) -> dict:
     f = H5File(path)
     root = f['model_weights'] if 'model_weights' in f else f
     if 'layer_names' not in root.attrs:
@@ -536,20 +619,37 @@ def weights_from_net(path) -> dict:
         for wname in _names(g.attrs.get('weight_names', [])):
             arrays[wname.split('/')[-1].split(':')[0]] = np.asarray(g[wname].read(), dtype=np.float32)
         if 'recurrent_kernel' in arrays:
+            if 'bias' not in arrays or 'kernel' not in arrays:
+                raise NotAPreciseModel('%s: GRU layer %s lacks a kernel / bias' % (path, name))
             if arrays['bias'].ndim != 1:
-                raise ValueError('%s: layer %s is a reset_after GRU (bias %r): not a precise model' % (path, name, arrays['bias'].shape))
-            gru.append((arrays['kernel'], arrays['recurrent_kernel'], arrays['bias']))
+                raise NotAPreciseModel('%s: layer %s is a reset_after GRU (bias %r): not a precise model' % (path, name, arrays['bias'].shape))
+            k, rk, bias = arrays['kernel'], arrays['recurrent_kernel'], arrays['bias']
+            if k.ndim != 2 or rk.ndim != 2 or rk.shape[1] != 3 * rk.shape[0] or k.shape[1] != rk.shape[1] or bias.shape[0] != rk.shape[1]:
+                raise NotAPreciseModel('%s: GRU layer %s has inconsistent shapes %r %r %r' % (path, name, k.shape, rk.shape, bias.shape))
+            gru.append((k, rk, bias))
         elif 'kernel' in arrays:
+            if arrays['kernel'].ndim != 2:
+                raise NotAPreciseModel('%s: Dense layer %s has a kernel of shape %r' % (path, name, arrays['kernel'].shape))
             dense = (arrays['kernel'], arrays.get('bias', np.zeros(arrays['kernel'].shape[1], np.float32)))
     if not gru or dense is None:
-        raise ValueError('%s: expected GRU layer(s) followed by a Dense(1) layer' % path)
+        raise NotAPreciseModel('%s: expected GRU layer(s) followed by a Dense(1) layer' % path)
     return {'gru': gru, 'dense_kernel': dense[0], 'dense_bias': dense[1]}
+
+
+def weights_from_net(path) -> dict:
+    """The GRU + Dense weights of a Keras ``.net`` (the layout tools/export_net_to_npz.py documents), as
+    ``model.load_weights`` returns them.  model.py:76-82: GRU layer(s) named 'net', then Dense(1).
+    Raises H5FormatError (damaged file), H5Unsupported (HDF5 feature outside the subset) or NotAPreciseModel."""
+    return _guard(lambda: _weights_from_net(path), path)
 
 
 def model_config(path):
     """The ``model_config`` JSON of a Keras ``.net`` as a dict, or None (weights-only file)."""
     import json
-    cfg = H5File(path).attrs.get('model_config')
-    if cfg is None:
-        return None
-    return json.loads(cfg.decode('utf-8') if isinstance(cfg, (bytes, np.bytes_)) else cfg)
+
+    def read():
+        cfg = H5File(path).attrs.get('model_config')
+        if cfg is None:
+            return None
+        return json.loads(cfg.decode('utf-8') if isinstance(cfg, (bytes, np.bytes_)) else cfg)
+    return _guard(read, path)

@@ -28,12 +28,15 @@ import struct
 import numpy as np
 
 DT_FLOAT = 1
+MAX_TENSOR_ELEMENTS = 1 << 26          # 64 M floats: no layer of a wake-word model comes near (damaged dims must not allocate)
 
 
 # ---- protobuf wire format ---------------------------------------------------------------------
 def _varint(buf, pos):
     result = shift = 0
     while True:
+        if pos >= len(buf):
+            raise ValueError('truncated protobuf message (varint runs past the end)')
         b = buf[pos]
         pos += 1
         result |= (b & 0x7F) << shift
@@ -110,7 +113,11 @@ def _decode_tensor(buf):
                 floats.append(struct.unpack('<f', val)[0])
     if dtype != DT_FLOAT:
         return None
-    count = int(np.prod(dims)) if dims else 1
+    count = 1
+    for dim in dims:
+        count *= int(dim)
+        if dim < 0 or count > MAX_TENSOR_ELEMENTS:
+            raise ValueError('float tensor of shape %r' % (dims,))
     if content is not None and len(content) == 4 * count:
         arr = np.frombuffer(content, dtype='<f4').copy()
     elif len(floats) == count:
@@ -123,7 +130,17 @@ def _decode_tensor(buf):
 
 
 def read_const_tensors(path):
-    """{node name: float32 ndarray} for every float ``Const`` node of a GraphDef file."""
+    """{node name: float32 ndarray} for every float ``Const`` node of a GraphDef file.  A damaged file raises
+    ValueError, whatever the parser tripped over."""
+    try:
+        return _read_const_tensors(path)
+    except ValueError:
+        raise
+    except (IndexError, TypeError, struct.error, UnicodeDecodeError, OverflowError, MemoryError) as ex:
+        raise ValueError('%s: damaged or not a GraphDef (%s: %s)' % (path, type(ex).__name__, ex)) from ex
+
+
+def _read_const_tensors(path):
     with open(path, 'rb') as f:
         data = memoryview(f.read())
     out = {}
@@ -171,8 +188,8 @@ def weights_from_pb(path):
             k, rk, b = strip[base + '/kernel'], strip[rk_name], strip[base + '/bias']
         except KeyError as e:
             raise ValueError('%s: GRU layer %r lacks %s' % (path, base, e))
-        units = rk.shape[0]
-        if rk.shape != (units, 3 * units) or k.shape[1] != 3 * units or b.shape != (3 * units,):
+        units = rk.shape[0] if rk.ndim == 2 else -1
+        if rk.ndim != 2 or k.ndim != 2 or rk.shape != (units, 3 * units) or k.shape[1] != 3 * units or b.shape != (3 * units,):
             raise ValueError('%s: layer %r has shapes %r %r %r (reset_after GRUs are not supported)'
                              % (path, base, k.shape, rk.shape, b.shape))
         layers.append((k, rk, b))

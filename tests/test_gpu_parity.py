@@ -683,6 +683,17 @@ def test_use_delta_matches_reference_semantics(tmp_path):
         want_many = np.stack([ref2.update(pcm[u + i]) for i in range(4)])
         assert np.array_equal(many.update_many(pcm[u:u + 4]), want_many), u
     many.close(); ref2.close()
+    # SINGLE updates on an engine whose ring was re-laid out by pe_reserve_updates (ring_slots != 32: the four-wave
+    # critical-wave shape is unavailable, and the fused one-wave shape has no delta inputs -> two launches; round-3 advisor
+    # finding: this combination silently dropped the W[F..2F-1] rows)
+    resv = HipEngine(hpr, w, n_streams=n)
+    resv.reserve_updates(4, 1024)
+    assert resv.info().ring_slots != 32
+    refs3 = [ol.OracleListener(w, opr) for _ in range(n)]
+    for u in range(36):
+        want = np.array([r.update_raw(pcm[u, j].tobytes()) for j, r in enumerate(refs3)])
+        assert np.abs(resv.update(pcm[u]) - want).max() <= GUARD_RAW, u
+    resv.close()
     # every kernel shape that carries the delta inputs: classic tiling (one wave per tile only) and the re-tiled stock width
     # (critical-wave kernel with four waves, one wave per tile); the shapes of a tiling agree bit for bit
     shapes = {}
