@@ -1223,7 +1223,12 @@ int pe_set_input_projection(pe_engine* e, int32_t enabled) {
 
 int pe_set_gru_waves(pe_engine* e, int32_t waves) {
     if (!e) return PE_ERR_INVALID;
-    if (waves != 0 && waves != 1 && waves != 4 && waves != 16) return fail(e, PE_ERR_INVALID, "gru kernel shape must be 0 (auto), 1, 4 (waves per tile) or 16 (lanes per stream)");
+    if (waves != 0 && waves != 1 && waves != 4 && waves != 16) return fail(e, PE_ERR_INVALID, "gru kernel shape must be 0 (auto), 1 or 4 (waves per tile)");
+#ifndef PE_TUNING
+    // 16 = sixteen lanes per stream without matrix cores (tools/micro/gru_dpp_device.h): measured, rejected,
+    // compiled into tuning builds only
+    if (waves == 16) return fail(e, PE_ERR_UNSUPPORTED, "the sixteen-lanes-per-stream kernel exists in -DPE_TUNING builds only (tools/build_variants.sh)");
+#endif
     e->gru_waves = waves;
     return PE_OK;
 }

@@ -6,7 +6,9 @@
 #include "mfcc_wave_device.h"
 #include "gru_device.h"
 #include "gru_cw_device.h"
-#include "gru_dpp_device.h"
+#ifdef PE_TUNING
+#include "../../tools/micro/gru_dpp_device.h"      // measured and rejected: tuning builds only (tools/build_variants.sh)
+#endif
 #include "gru_bf16_device.h"
 #include "gru_wide_device.h"
 #include "mfcc_general_device.h"
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(256) void gru_mw_kernel(const GruArgs a) {
     gru_tile_mw_any<R, PROJ>(a, blockIdx.x, wave, threadIdx.x & 63, S);
 }
 
+#ifdef PE_TUNING
 // ---- GRU: sixteen lanes per stream, no hand-offs (few tiles: the window's dependent chain is what counts) ----------
 __global__ __launch_bounds__(256) void gru_dpp_kernel(const GruArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -245,6 +248,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
     }
 }
+
+#endif      // PE_TUNING
 
 // ---- fused update: GRU role || MFCC frame role || bookkeeping role in ONE launch -------------------------------
 // Workgroups [0, n_gru_blocks) run the network on the feature windows as they will stand after this update (they
@@ -395,10 +400,12 @@ static hipError_t launch_r(const GruArgs& a, int mode, hipStream_t s) {
             else hipLaunchKernelGGL((gru_v_kernel<kFeats, false>), dim3(tiles), dim3(64), 0, s, a);
             return hipGetLastError();
         }
+#ifdef PE_TUNING
         if (mode == kRing && a.proj_ring && a.waves_per_tile == 16) {
             hipLaunchKernelGGL(gru_dpp_kernel, dim3(tiles), dim3(256), 0, s, a);
             return hipGetLastError();
         }
+#endif
         if (mode == kRing && a.proj_ring) {
             if (a.waves_per_tile == 4) hipLaunchKernelGGL((gru_mw_kernel<R, true>), dim3(tiles), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((gru_small_kernel<R, kRing, true>), dim3(tiles), dim3(64), 0, s, a);
@@ -456,10 +463,12 @@ static hipError_t launch_many_r(const GruArgs& a, int n_updates, int n_padded, h
             else hipLaunchKernelGGL(gru_many_v_kernel<false>, dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
             return hipGetLastError();
         }
+#ifdef PE_TUNING
         if (a.proj_ring && a.waves_per_tile == 16) {       // the engine's single updates use the DPP kernel: so does the batch
             hipLaunchKernelGGL(gru_many_dpp_kernel, dim3(tiles * n_updates), dim3(256), 0, s, a, tiles, n_padded);
             return hipGetLastError();
         }
+#endif
         if (a.proj_ring) {
             if (mw) hipLaunchKernelGGL((gru_many_mw_kernel<R, true>), dim3(tiles * n_updates), dim3(256), 0, s, a, tiles, n_padded);
             else hipLaunchKernelGGL((gru_many_kernel<R, true>), dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
@@ -531,10 +540,12 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
         }
     }
     if constexpr (RG == 5) {                 // (projection rows exist for the stock width only)
+#ifdef PE_TUNING
         if (g.proj_ring && g.waves_per_tile == 16) {
             hipLaunchKernelGGL((fused_update_dpp_kernel<R, ShapeStock>), dim3(tiles + fb_ + book), dim3(256), lds, s, m, t, g, tiles, fb_, tiles);
             return hipGetLastError();
         }
+#endif
         if (g.proj_ring) {
             if (g.waves_per_tile == 4) hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb_, tiles, frames_first);
             else hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, false, true>), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb_, tiles, frames_first);

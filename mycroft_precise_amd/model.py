@@ -67,6 +67,19 @@ def _check_sidecar(net_file: str, sidecar: str):
         warnings.warn('%s is newer than its exported weights %s: re-run tools/export_net_to_npz.py' % (net_file, sidecar))
 
 
+def _sidecar_matches(net_file: str, sidecar: str) -> bool:
+    import hashlib
+    try:
+        with np.load(sidecar, allow_pickle=False) as z:
+            if 'source_sha256' not in z.files:
+                return False
+            want = str(z['source_sha256'])
+        with open(net_file, 'rb') as f:
+            return hashlib.sha256(f.read()).hexdigest() == want
+    except (OSError, ValueError):
+        return False
+
+
 def load_weights(model_name: str) -> dict:
     if model_name.endswith('.pb'):
         from .pb_model import weights_from_pb
@@ -78,17 +91,23 @@ def load_weights(model_name: str) -> dict:
         from os.path import isfile
         from .h5_model import H5FormatError, H5Unsupported, weights_from_net
         why = 'the file does not exist'
-        if isfile(model_name):
-            try:
-                return weights_from_net(model_name)
-            except (H5Unsupported, H5FormatError) as ex:
-                why = str(ex)
-        if not isfile(model_name + '.npz'):
-            raise NotImplementedError(
-                'cannot read %s (%s) and its exported weights %s.npz do not exist: run `python tools/export_net_to_npz.py '
-                '%s` on a machine with h5py, or freeze the model with precise-convert to .pb' % (model_name, why, model_name, model_name))
-        net_file, model_name = model_name, model_name + '.npz'
-        _check_sidecar(net_file, model_name)
+        sidecar = model_name + '.npz'
+        if isfile(model_name) and isfile(sidecar) and _sidecar_matches(model_name, sidecar):
+            # a side-car that h5py exported from exactly this file (sha256 recorded inside) outranks the spec-written
+            # reader, which no libhdf5-written file has pinned yet (h5_model.py header)
+            pass
+        else:
+            if isfile(model_name):
+                try:
+                    return weights_from_net(model_name)
+                except (H5Unsupported, H5FormatError) as ex:
+                    why = str(ex)
+            if not isfile(sidecar):
+                raise NotImplementedError(
+                    'cannot read %s (%s) and its exported weights %s do not exist: run `python tools/export_net_to_npz.py '
+                    '%s` on a machine with h5py, or freeze the model with precise-convert to .pb' % (model_name, why, sidecar, model_name))
+            _check_sidecar(model_name, sidecar)
+        model_name = sidecar
     with np.load(model_name, allow_pickle=False) as z:
         n = int(z['n_layers'])
         layers = [(z['kernel_%d' % i], z['recurrent_kernel_%d' % i], z['bias_%d' % i]) for i in range(n)]

@@ -300,14 +300,11 @@ def test_gru_kernel_shapes_agree_bitwise(stock_weights):
             assert np.array_equal(o, outs[0]), u
     with pytest.raises(ValueError):
         engines[0].engine.set_gru_waves(3)
-    # 16 = sixteen LANES per stream (gru_dpp_device.h, the default up to 4096 streams): float32 multiply-adds in
-    # another order than the matrix cores' -- agrees to rounding, not bit for bit
+    # 16 = sixteen LANES per stream without matrix cores: measured, rejected, moved out of the product
+    # library (tools/micro/gru_dpp_device.h, -DPE_TUNING builds only): the product refuses it loudly
     d = BatchedListener(stock_weights, n)
-    d.engine.set_gru_waves(16)
-    ref = BatchedListener(stock_weights, n)
-    ref.engine.set_gru_waves(4)
-    for u in range(n_up):
-        assert np.abs(d.update_raw(pcm[u]) - ref.update_raw(pcm[u])).max() <= 5e-6, u
+    with pytest.raises(NotImplementedError):
+        d.engine.set_gru_waves(16)
 
 
 def test_input_projection_rows_agree_with_recomputed_projection(stock_weights):
@@ -327,11 +324,7 @@ def test_input_projection_rows_agree_with_recomputed_projection(stock_weights):
             e.set_input_projection(proj)
             e.set_fused(fused); e.set_gru_waves(waves)
             variants.append(e)
-        dpp = []
-        for fused in ((True, False) if proj else ()):
-            e = HipEngine(P.pr, stock_weights, n_streams=n)
-            e.set_fused(fused); e.set_gru_waves(16)
-            dpp.append(e)
+        dpp = []          # (the sixteen-lanes-per-stream kernel left the product library: tools/micro/gru_dpp_device.h)
         res = []
         for u in range(n_up):
             if u == 20:
@@ -342,10 +335,6 @@ def test_input_projection_rows_agree_with_recomputed_projection(stock_weights):
             for g in got[1:]:
                 assert np.array_equal(g, got[0]), (proj, u)
             res.append(got[0])
-            if proj:        # the sixteen-lanes-per-stream kernel: its own summation order, fused == two launches
-                gd = [e.update(pcm[u]) for e in dpp]
-                assert np.array_equal(gd[0], gd[1]), u
-                assert np.abs(gd[0] - got[0]).max() <= 5e-6, u
         outs[proj] = np.stack(res)
         for e in variants + dpp:
             e.close()
