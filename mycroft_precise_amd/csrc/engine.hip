@@ -531,6 +531,10 @@ GruArgs gru_args(const pe_engine* e) {
     if (e->prm.use_delta && !retile) a.waves_per_tile = 1;       // (classic tiling: only the one-wave kernel carries the delta inputs)
     if (e->row_floats != kRowFloats) a.waves_per_tile = 1;       // ... and the 32-float feature rows
     a.cw = retile ? e->cw_blob : nullptr;
+    // (tuning builds: PE_PAIR=1 = two tiles per network wave + mixed fused workgroups, tools/micro/gru_pair_device.h --
+    //  measured and rejected: an MFMA blocks the VALU of its SIMD for its whole duration)
+    a.pair = tuning_env_int("PE_PAIR", 0) != 0 && e->units >= 17 && e->units <= 20 && !a.cw && !a.proj_ring && !a.bf16 && !e->wide &&
+             !e->prm.use_delta && e->row_floats == kRowFloats && a.waves_per_tile == 1;
     return a;
 }
 

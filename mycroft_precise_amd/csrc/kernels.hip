@@ -6,8 +6,9 @@
 #include "mfcc_wave_device.h"
 #include "gru_device.h"
 #include "gru_cw_device.h"
-#ifdef PE_TUNING
-#include "../../tools/micro/gru_dpp_device.h"      // measured and rejected: tuning builds only (tools/build_variants.sh)
+#ifdef PE_TUNING      // measured and rejected: tuning builds only (tools/build_variants.sh)
+#include "../../tools/micro/gru_dpp_device.h"
+#include "../../tools/micro/gru_pair_device.h"
 #endif
 #include "gru_bf16_device.h"
 #include "gru_wide_device.h"
@@ -302,6 +303,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
     }
 }
 
+#ifdef PE_TUNING
+// ---- GRU, stock width, classic tiling: two tiles per wave (gru_pair_device.h) -------------------------------------
+// four waves per workgroup = eight tiles; the accumulator inits (biases) come from 256 bytes of LDS (no register cap
+// here: the input kernel stays in registers, three waves = six tile chains per SIMD)
+__global__ __launch_bounds__(256) void gru_pair_kernel(const GruArgs a, const int n_tiles) {
+    touch_kernel_arguments<(int)sizeof(GruArgs) + 4>();
+    __shared__ __attribute__((aligned(16))) float B[kPairBiasFloats];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wave == 0) pair_bias_to_lds(a, B, lane);
+    __syncthreads();
+    const int t0 = (blockIdx.x * 4 + wave) * 2;
+    if (t0 < n_tiles) gru_tile_pair<true>(a, t0, t0 + 1, n_tiles, lane, B);
+}
+
+// ---- fused update, throughput regime: MIXED workgroups ---------------------------------------------------------------
+// Eight waves per workgroup, two per SIMD: waves 0..3 run the MFCC frame role, waves 4..7 the network role with two tiles
+// per wave -- so EVERY SIMD holds, by construction and whatever the dispatcher does, one frame wave and one network wave
+// of each resident workgroup (two workgroups per compute unit under the 128-register budget: 2 + 2 per SIMD, the four
+// tile chains a SIMD used to need four network waves for).  The roles use different pipes (VALU + LDS vs MFMA) and now
+// share every SIMD for the whole launch instead of taking turns at its four wave slots.
+// The workgroups are persistent: frame waves own a contiguous run of (stream, row parity) slots (mfcc_frame_tasks),
+// network waves walk the tile pairs with the stride of the launch.  The last workgroups keep the books, two tiles each.
+constexpr int kMixWaves = 8;
+__device__ __forceinline__ void set_wave_prio(const int p) {       // (s_setprio takes an immediate)
+    if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 3) __builtin_amdgcn_s_setprio(3);
+}
+template <class R, class SH>
+__global__ __launch_bounds__(64 * kMixWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_update_mix_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
+                                                                const int n_mix, const int n_tiles, const int bias_off, const int flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    touch_kernel_arguments<(int)(sizeof(MfccStreamArgs<R>) + sizeof(WaveTables<R>) + sizeof(GruArgs) + 16)>();
+    const int b = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b < n_mix) {
+        float* const B = reinterpret_cast<float*>(smem + bias_off);
+        if (wave < kFrameWaves) {
+            if (flags & 1) {            // (tuning: launch without the frame role -- the barrier of the table commit still has to be met)
+                const TabRegs tr = wave_tables_issue<R>(t);
+                wave_tables_commit<R>(smem, t, tr);
+                return;
+            }
+            set_wave_prio((flags >> 6) & 3);
+            mfcc_frame_tasks<R, SH, true, true>(m, t, smem, b * kFrameWaves, n_mix * kFrameWaves);
+        } else {
+            // the network waves take part in the workgroup's one barrier (the table image's commit: all eight waves carry
+            // pieces of it) and publish the accumulator inits before it
+            const TabRegs tr = wave_tables_issue<R>(t);
+            if (wave == kFrameWaves) pair_bias_to_lds(g, B, lane);
+            if (wave == kFrameWaves + 1) pair_wx_to_lds(g, B + kPairBiasFloats, lane);
+            wave_tables_commit<R>(smem, t, tr);
+            if (flags & 2) return;      // (tuning: launch without the network role)
+            set_wave_prio((flags >> 4) & 3);
+            const int n_pairs = (n_tiles + 1) >> 1;
+            for (int pi = b * 4 + (wave - kFrameWaves); pi < n_pairs; pi += n_mix * 4) gru_tile_pair<true, true>(g, 2 * pi, 2 * pi + 1, n_tiles, lane, B);
+        }
+    } else {
+        if (flags & 1) return;
+        const int tile = (b - n_mix) * 2 + (wave >> 2);
+        if (tile < n_tiles) mfcc_book_tile<R>(m, tile, wave & 3);
+    }
+}
+
+#endif      // PE_TUNING
+
 // Workgroups of the frame role: one wave per task while that fits the machine (4 workgroups of 4 waves per compute
 // unit are resident: LDS and a 128-register budget), more tasks per wave beyond.
 // Launch-shape knobs of the tuning harness (tools/): read from the environment ONLY in -DPE_TUNING builds
@@ -316,6 +383,8 @@ static int env_int(const char* name, int dflt) {
     return dflt;
 #endif
 }
+int tuning_env_int(const char* name, int dflt) { return env_int(name, dflt); }
+
 static int frame_blocks(long long n_tasks, int n_cus, int per_cu_default = 4) {
     static const int per_cu_env = env_int("PE_FRAME_WG_PER_CU", 0);      // tuning knob (tools/): resident frame workgroups per CU
     const int per_cu = per_cu_env ? per_cu_env : per_cu_default;
@@ -388,6 +457,12 @@ static hipError_t launch_r(const GruArgs& a, int mode, hipStream_t s) {
         return hipGetLastError();
     }
     if constexpr (R == 5) {
+#ifdef PE_TUNING
+        if (a.pair && mode == kRing && !a.cw && !a.proj_ring && !a.use_delta && a.waves_per_tile == 1) {
+            hipLaunchKernelGGL(gru_pair_kernel, dim3((tiles + 7) / 8), dim3(256), 0, s, a, tiles);
+            return hipGetLastError();
+        }
+#endif
         if (a.cw) {
             if (mode == kRing && a.waves_per_tile == 4 && cw_four_waves_ok(a)) hipLaunchKernelGGL(gru_cw_kernel, dim3(tiles), dim3(256), kCwLdsBytes, s, a);
             else if (a.use_delta) {
@@ -529,6 +604,24 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
     if (skip == 3) book = 0;
     const dim3 grid(gru_blocks + fb_ + book);
     if constexpr (RG == 5) {
+#ifdef PE_TUNING
+        if (g.pair && !g.cw && !g.proj_ring && !g.use_delta && g.waves_per_tile == 1) {
+            // throughput regime: mixed workgroups (frame waves + two-tiles-per-wave network waves on every SIMD), two resident
+            // per compute unit; persistent -- fewer only when there are not enough tile pairs to give every network wave one
+            static const int per_cu_env = env_int("PE_MIX_WG_PER_CU", 0);
+            const int n_pairs = (tiles + 1) / 2;
+            const int cap = n_cus * (per_cu_env ? per_cu_env : 2);
+            const int need = (n_pairs + 3) / 4;
+            const int n_mix = need < cap ? need : cap;
+            const int bias_off = (int)((lds + 15) & ~(size_t)15);
+            // wave priorities of the two roles (bits 4-5: network, 6-7: frames)
+            static const int prio_net = env_int("PE_MIX_PRIO_NET", 3), prio_frame = env_int("PE_MIX_PRIO_FRAME", 0);
+            const int flags = (skip == 1 ? 1 : 0) | (skip == 2 ? 2 : 0) | ((prio_net & 3) << 4) | ((prio_frame & 3) << 6);
+            hipLaunchKernelGGL((fused_update_mix_kernel<R, ShapeStock>), dim3(n_mix + (tiles + 1) / 2), dim3(64 * kMixWaves), (size_t)bias_off + kPairLdsFloats * sizeof(float), s,
+                               m, t, g, n_mix, tiles, bias_off, flags);
+            return hipGetLastError();
+        }
+#endif
         if (g.cw) {                          // stock width, re-tiled: the four-wave shape wants its LDS (mailboxes + staged ring)
             if (g.waves_per_tile == 4 && cw_four_waves_ok(g)) {
                 hipLaunchKernelGGL((fused_update_kernel<R, ShapeStock, RG, true, false, true>), grid, dim3(256), lds > kCwLdsBytes ? lds : kCwLdsBytes, s, m, t, g, gru_blocks, fb_, tiles, frames_first);

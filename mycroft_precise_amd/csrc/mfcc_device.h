@@ -55,9 +55,10 @@ __device__ __forceinline__ void group_sync() {
 // single updates would, and record the emitted-frame counter after EVERY update (ke_hist, when given) -- that is
 // what tells a batched network launch which window each update saw.
 template <class R>
-__device__ __forceinline__ void mfcc_book_tile(const MfccStreamArgs<R>& a, const int tile) {
+__device__ __forceinline__ void mfcc_book_tile(const MfccStreamArgs<R>& a, const int tile, const int wave_in_tile = -1) {
     const StreamGeom& geo = a.geo;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (wave_in_tile: workgroups of more than four waves keep the books of several tiles, four waves each)
+    const int lane = threadIdx.x & 63, wave = wave_in_tile >= 0 ? wave_in_tile : (int)(threadIdx.x >> 6);
     const int grp = lane >> 4, r = lane & 15;
     const int j = wave * 4 + grp;
     const long long s = (long long)tile * kTileStreams + j;

@@ -151,6 +151,7 @@ struct GruArgs {
     int row_stride;
     float* out;             // [n_streams]
     int row_floats;         // floats per feature row: 16, or 32 for 17..32 coefficients per frame (one-wave kernel, KX = 2)
+    int pair;               // tuning builds only (tools/micro/gru_pair_device.h, PE_PAIR=1): two tiles per network wave
     int waves_per_tile;     // 1: one wave per tile (gru_tile);  4: four waves share a tile (gru_tile_mw);
                             // 16: four waves per tile, sixteen LANES per stream (gru_tile_dpp)
 };
@@ -223,6 +224,8 @@ hipError_t launch_gru_many(const GruArgs& a, int n_updates, int n_padded, hipStr
 // frame_len: no frame computed now becomes visible now)
 hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const WaveTables<double>& t, const GruArgs& g, int n_cus, hipStream_t s);
 hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const WaveTables<float>& t, const GruArgs& g, int n_cus, hipStream_t s);
+// tuning aid (-DPE_TUNING builds only; 0 in the product): an integer knob read from the environment
+int tuning_env_int(const char* name, int dflt);
 hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s);
 hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, const WaveTables<float>& t, int n_cus, hipStream_t s);
 hipError_t launch_gru_small(const GruArgs& a, int input_mode, hipStream_t s);   // units <= 32; 0 feats, 1 ring, 2 rows

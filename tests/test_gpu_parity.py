@@ -1143,6 +1143,19 @@ def _full_size_run(weights, B, n_up, n_check, tol, guard_equal_positions=True, *
     return hip, base, owner, first
 
 
+def test_capacity_batch_65536_streams_properties(stock_weights):
+    """The capacity point of the metric (max concurrent real-time streams; bench.py extra_configs): 65536 streams, float64
+    front end + float32 network on the one-wave-per-tile kernels -- the size-independent properties, and fused == two
+    launches at this size."""
+    from mycroft_precise_amd._lib import HipEngine
+    hip, base, owner, first = _full_size_run(stock_weights, 65536, 33, 24, GUARD_RAW)
+    two = HipEngine(P.pr, stock_weights, n_streams=65536)
+    two.set_fused(False)
+    for u in range(33):
+        assert np.array_equal(two.update(base[u][owner]), first[u]), u
+    two.close()
+
+
 def test_full_batch_wide_gru_4096_streams_properties():
     """BASELINE configs[3]: 256 x 2 layers at 4096 streams = 256 workgroups sharing one L2-resident weight
     stream -- where a stale read or an ordering slip between workgroups would show."""

@@ -22,7 +22,7 @@
 // Float32 fused multiply-adds in a fixed order: deterministic, identical for a stream wherever it sits.
 // Requires 17 <= units <= 20 (R = 5 slot layout of the projection rows) and a.proj_ring.
 #pragma once
-#include "gru_device.h"
+#include "../../mycroft_precise_amd/csrc/gru_device.h"
 
 namespace pe {
 
