@@ -184,33 +184,51 @@ int build_general_tables(pe_engine* e, const double* mel_filters) {
         wn[2 * k] = (R)cosl(-2.0L * PI * k / N);
         wn[2 * k + 1] = (R)sinl(-2.0L * PI * k / N);
     }
-    std::vector<int> ptr(nf + 1, 0), bin;
-    std::vector<R> w;
+    // filterbank as lane runs (mfcc_general_device.h: GeneralTables): every filter's non-zeros, in bin order, in runs of
+    // <= kGeneralRun entries; run r <-> lane r % 64 of round r / 64
+    std::vector<int> run_ptr(nf + 1, 0);
+    std::vector<std::pair<int, R>> entries;
+    std::vector<int> run_first;            // first entry of every run
+    std::vector<int> run_len;
     for (int f = 0; f < nf; ++f) {
+        int in_run = 0;
         for (int k = 0; k < bins; ++k) {
             const double v = mel_filters[(size_t)f * bins + k];
-            if (v != 0.0) { bin.push_back(k); w.push_back((R)v); }
+            if (v == 0.0) continue;
+            if (in_run == 0) { run_first.push_back((int)entries.size()); run_len.push_back(0); }
+            entries.emplace_back(k, (R)v);
+            ++run_len.back();
+            if (++in_run == kGeneralRun) in_run = 0;
         }
-        ptr[f + 1] = (int)bin.size();
+        run_ptr[f + 1] = (int)run_first.size();
     }
-    if (bin.empty()) { bin.push_back(0); w.push_back(R(0)); }
-    std::vector<R> dct((size_t)nc * nf);
+    const int n_runs = (int)run_first.size();
+    const int n_rounds = n_runs > 0 ? (n_runs + 63) / 64 : 1;
+    std::vector<R> run_w((size_t)n_rounds * kGeneralRun * 64, R(0));
+    std::vector<int> run_bin((size_t)n_rounds * kGeneralRun * 64, 0);
+    for (int r = 0; r < n_runs; ++r)
+        for (int i = 0; i < run_len[r]; ++i) {
+            const size_t at = ((size_t)(r / 64) * kGeneralRun + i) * 64 + (r % 64);
+            run_bin[at] = entries[run_first[r] + i].first;
+            run_w[at] = entries[run_first[r] + i].second;
+        }
+    std::vector<R> dct_t((size_t)nf * kGeneralDctCols, R(0));
     for (int c = 0; c < nc; ++c)           // scipy.fftpack.dct(type 2, norm='ortho'): y[c] = 2 f(c) sum_n x[n] cos(pi c (2 n + 1) / (2 N))
         for (int f = 0; f < nf; ++f) {
             const long double scale = c == 0 ? sqrtl(1.0L / (4.0L * nf)) : sqrtl(1.0L / (2.0L * nf));
-            dct[(size_t)c * nf + f] = (R)(2.0L * scale * cosl(PI * c * (2 * f + 1) / (2.0L * nf)));
+            dct_t[(size_t)f * kGeneralDctCols + c] = (R)(2.0L * scale * cosl(PI * c * (2 * f + 1) / (2.0L * nf)));
         }
     R* d_tw = nullptr; R* d_wn = nullptr; R* d_w = nullptr; R* d_dct = nullptr; int* d_ptr = nullptr; int* d_bin = nullptr;
     int rc;
     if ((rc = dev_upload(e, &d_tw, tw))) return rc;
     if ((rc = dev_upload(e, &d_wn, wn))) return rc;
-    if ((rc = dev_upload(e, &d_w, w))) return rc;
-    if ((rc = dev_upload(e, &d_dct, dct))) return rc;
-    if ((rc = dev_upload(e, &d_ptr, ptr))) return rc;
-    if ((rc = dev_upload(e, &d_bin, bin))) return rc;
+    if ((rc = dev_upload(e, &d_w, run_w))) return rc;
+    if ((rc = dev_upload(e, &d_dct, dct_t))) return rc;
+    if ((rc = dev_upload(e, &d_ptr, run_ptr))) return rc;
+    if ((rc = dev_upload(e, &d_bin, run_bin))) return rc;
     int log2m = 0;
     while ((1 << log2m) < M) ++log2m;
-    e->gtab = GeneralTables{d_tw, d_wn, d_ptr, d_bin, d_w, d_dct, N, log2m, nf, nc, e->prm.vectorizer == 3 ? 1 : 0};
+    e->gtab = GeneralTables{d_tw, d_wn, d_w, d_bin, d_ptr, d_dct, N, log2m, nf, nc, e->prm.vectorizer == 3 ? 1 : 0, n_rounds};
     return PE_OK;
 }
 
@@ -464,6 +482,7 @@ GeneralStreamArgs<R> general_args(const pe_engine* e, const int16_t* pcm_dev, in
     a.geo = geom(e);
     a.tab = e->gtab;
     a.pcm = pcm_dev; a.chunk = chunk;
+    a.pcm_pairs_ok = ((chunk & 1) == 0) && ((reinterpret_cast<uintptr_t>(pcm_dev) & 3u) == 0);
     a.carry = e->carry; a.carry_next = e->carry_alt; a.carry_cap = e->carry_cap;
     const int c = e->cur, n = c ^ 1;
     a.st_q = e->st_q[c]; a.st_kc = e->st_kc[c]; a.st_ke = e->st_ke[c];
@@ -529,7 +548,8 @@ GruArgs gru_args(const pe_engine* e) {
     a.waves_per_tile = e->gru_waves ? e->gru_waves : auto_waves;      // (16 = DPP kernel: opt-in)
     if (a.waves_per_tile == 16 && !dpp_ok) a.waves_per_tile = 4;
     if (e->prm.use_delta && !retile) a.waves_per_tile = 1;       // (classic tiling: only the one-wave kernel carries the delta inputs)
-    if (e->row_floats != kRowFloats) a.waves_per_tile = 1;       // ... and the 32-float feature rows
+    if (e->row_floats != kRowFloats && !(gru_small_regs(e->units) == 5 && !e->prm.use_delta && a.waves_per_tile == 4))
+        a.waves_per_tile = 1;       // ... and the 32-float feature rows (stock width: four waves per tile exist, gru_tile_mw5<.., 2>)
     a.cw = retile ? e->cw_blob : nullptr;
     // (tuning builds: PE_PAIR=1 = two tiles per network wave + mixed fused workgroups, tools/micro/gru_pair_device.h --
     //  measured and rejected: an MFMA blocks the VALU of its SIMD for its whole duration)
@@ -765,7 +785,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         for (auto& ev : e->ev)
             if (hipEventCreate(&ev) != hipSuccess) { rc = fail(e, PE_ERR_HIP, "hipEventCreate failed"); break; }
         if (rc) break;
-        const size_t lds = e->general ? general_lds_bytes(p->mfcc_precision == 0 ? 8 : 4, p->n_fft, p->n_filt)
+        const size_t lds = e->general ? general_lds_bytes(p->mfcc_precision == 0 ? 8 : 4, p->n_fft, p->n_filt, e->gtab.n_rounds)
                                       : (size_t)e->table_layout.total + (size_t)kFrameWaves * pe_wave::kScratchReals * (p->mfcc_precision == 0 ? 8 : 4);
         if (lds > 64 * 1024) { rc = fail(e, PE_ERR_UNSUPPORTED, "MFCC kernel would need %zu bytes of LDS per workgroup", lds); break; }
         if ((rc = pe_clear(e, nullptr))) break;

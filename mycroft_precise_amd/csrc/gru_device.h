@@ -448,23 +448,29 @@ __device__ __forceinline__ void gru_tile_mw(const GruArgs& a, const int tile, co
 // theirs while waves 2/3 run phase 2; wave 3, idle during phase 1, computes its own AND tile 2's and
 // hands the latter to wave 2 through LDS.  What stays serial per timestep is two 5-MFMA chains and
 // two LDS hand-offs.
-template <bool PROJ>
+// KX = 2: feature rows of 32 floats (17..32 coefficients per frame, general ListenerParams): the input projection runs over
+// two 16-feature groups, in the order gru_tile<5, MODE, false, 2> issues them
+template <bool PROJ, int KX = 1>
 __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, const int wave, const int lane,
                                              float* S /* [15][64] gate slots + [64][4] tile-2 projection */) {
 #pragma clang fp contract(off)      // every fusion in the gate arithmetic is spelled out: all kernel shapes round alike
     constexpr int R = 5;
+    constexpr int RF = kRowFloats * KX;
+    static_assert(KX == 1 || !PROJ, "projection rows exist for 16-float feature rows");
     float* X2 = S + 3 * R * 64;
     const int g = lane >> 4, j = lane & 15;
     const long long stream = (long long)tile * kTileStreams + j;
     const bool valid = stream < a.n_streams;
     const int T = a.n_features;
 
-    float wx[4], wx2[4], wrA[R], wrB[R], wd[R];
+    float wx[4], wx2[4], wxh[4], wx2h[4], wrA[R], wrB[R], wd[R];
     f32x4 bias, bias2;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         wx[kk] = a.wx[(wave * 4 + kk) * 64 + lane];
         wx2[kk] = a.wx[(2 * 4 + kk) * 64 + lane];
+        wxh[kk] = KX == 2 ? a.wx[((4 + wave) * 4 + kk) * 64 + lane] : 0.f;      // features 16 + 4 g + kk
+        wx2h[kk] = KX == 2 ? a.wx[((4 + 2) * 4 + kk) * 64 + lane] : 0.f;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -493,18 +499,25 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
     // what a wave fetches per timestep: the feature row (4 features per lane) -- or, PROJ, the input projection of
     // ITS OWN output tile as the MFCC stage stored it (then no wave computes projections and nothing is handed over)
     const float* xbase = PROJ ? proj_base(a, tile, j, g) + kProjTileStride * wave
-                              : a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats + 4 * g;
-    const size_t xstride = (size_t)kTileStreams * (PROJ ? kProjRow : kRowFloats);
-    auto load_x = [&](int t) -> f32x4 {
+                              : a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * RF + 4 * g;
+    const size_t xstride = (size_t)kTileStreams * (PROJ ? kProjRow : RF);
+    struct XRow { f32x4 lo, hi; };
+    auto load_x = [&](int t) -> XRow {
         const int tc = t < T ? t : T - 1;
         const uint32_t slot = (first + (uint32_t)tc) & mask;
-        return *reinterpret_cast<const f32x4*>(xbase + (size_t)slot * xstride);
+        XRow r;
+        r.lo = *reinterpret_cast<const f32x4*>(xbase + (size_t)slot * xstride);
+        r.hi = KX == 2 ? *reinterpret_cast<const f32x4*>(xbase + (size_t)slot * xstride + 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        return r;
     };
-    auto xproj = [&](const float (&w)[4], const f32x4& b, const f32x4& x) -> f32x4 {
-        if (PROJ) return x;
-        f32x4 acc = mfma(w[0], x[0], b);
+    auto xproj = [&](const float (&w)[4], const float (&wh)[4], const f32x4& b, const XRow& x) -> f32x4 {
+        if (PROJ) return x.lo;
+        f32x4 acc = mfma(w[0], x.lo[0], b);
 #pragma unroll
-        for (int kk = 1; kk < 4; ++kk) acc = mfma(w[kk], x[kk], acc);
+        for (int kk = 1; kk < 4; ++kk) acc = mfma(w[kk], x.lo[kk], acc);
+        if (KX == 2)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = mfma(wh[kk], x.hi[kk], acc);
         return acc;
     };
     auto lds_barrier = [&]() {
@@ -517,16 +530,16 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
     float h[R], z[R];
 #pragma unroll
     for (int rho = 0; rho < R; ++rho) { h[rho] = 0.f; z[rho] = 0.f; }
-    f32x4 accx = xproj(wx, bias, load_x(0));       // this wave's tile, timestep 0
-    f32x4 x1 = load_x(1);
+    f32x4 accx = xproj(wx, wxh, bias, load_x(0));       // this wave's tile, timestep 0
+    XRow x1 = load_x(1);
     if (wave == 2) PE_GT(1);
 
     for (int t = 0; t < T; ++t) {
         if (wave == 3) {
             // phase 1 of the others: projections of timestep t+1 for tile 3 (own) and tile 2 (wave 2's)
-            const f32x4 an = xproj(wx, bias, x1);
+            const f32x4 an = xproj(wx, wxh, bias, x1);
             if (!PROJ) {
-                const f32x4 a2 = xproj(wx2, bias2, x1);
+                const f32x4 a2 = xproj(wx2, wx2h, bias2, x1);
                 *reinterpret_cast<f32x4*>(X2 + lane * 4) = a2;
             }
             x1 = load_x(t + 2);
@@ -553,7 +566,7 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
 #pragma unroll
             for (int rho = 0; rho < R; ++rho) { z[rho] = Sl[rho * 64]; rr[rho] = Sl[(R + rho) * 64]; }
             f32x4 an;
-            if (PROJ) { an = x1; x1 = load_x(t + 2); }
+            if (PROJ) { an = x1.lo; x1 = load_x(t + 2); }
             else an = *reinterpret_cast<const f32x4*>(X2 + lane * 4);
 #pragma unroll
             for (int rho = 0; rho < R; ++rho) acc = mfma(wrB[rho], rr[rho] * h[rho], acc);
@@ -571,7 +584,7 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
             lds_barrier();                                           // A
 #pragma unroll
             for (int rho = 0; rho < R; ++rho) z[rho] = Sl[rho * 64];
-            accx = xproj(wx, bias, x1);                              // phase 2 of the others
+            accx = xproj(wx, wxh, bias, x1);                         // phase 2 of the others
             x1 = load_x(t + 2);
             lds_barrier();                                           // B
         }
@@ -593,9 +606,10 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
     }
 }
 
-template <int R, bool PROJ = false>
+template <int R, bool PROJ = false, int KX = 1>
 __device__ __forceinline__ void gru_tile_mw_any(const GruArgs& a, const int tile, const int wave, const int lane, float* S) {
-    if constexpr (R == 5) gru_tile_mw5<PROJ>(a, tile, wave, lane, S);
+    static_assert(KX == 1 || R == 5, "32-float feature rows on four waves: the stock width only");
+    if constexpr (R == 5) gru_tile_mw5<PROJ, KX>(a, tile, wave, lane, S);
     else gru_tile_mw<R, PROJ>(a, tile, wave, lane, S);
 }
 

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) void gru_bf16_kernel(const GruArgs a) {
 // Returns the index in the canonical order [network | frames | bookkeeping].
 constexpr int kFramesFirst = 1, kBySimd = 2;       // launch flags of fused_update_kernel (its last argument)
 constexpr int kCwRoleSlot = 1984;                  // four ints of the GRU workgroup's LDS between the mailboxes and the staged ring
-static_assert(CwBox::END <= kCwRoleSlot && kCwRoleSlot + 4 <= CwLds::XR, "role slots overlap");
+static_assert(CwBox::END <= kCwRoleSlot && kCwRoleSlot + 4 <= CwLds::XR && kCwRoleSlot + 4 <= CwBox::SRH4, "role slots overlap");
 __device__ __forceinline__ int role_block(const int b, const int n_gru, const int n_frames, const int frames_first) {
     if (!frames_first || b >= n_gru + n_frames) return b;
     return b < n_frames ? n_gru + b : b - n_frames;
@@ -209,11 +209,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
 }
 
 // ---- GRU: four waves per 16-stream tile (few tiles: fills all four SIMDs of a CU) -----------------
-template <int R, bool PROJ = false>
+template <int R, bool PROJ = false, int KX = 1>
 __global__ __launch_bounds__(256) void gru_mw_kernel(const GruArgs a) {
     __shared__ __attribute__((aligned(16))) float S[3 * R * 64 + 256];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    gru_tile_mw_any<R, PROJ>(a, blockIdx.x, wave, threadIdx.x & 63, S);
+    gru_tile_mw_any<R, PROJ, KX>(a, blockIdx.x, wave, threadIdx.x & 63, S);
 }
 
 #ifdef PE_TUNING
@@ -450,7 +450,13 @@ template <int R>
 static hipError_t launch_r(const GruArgs& a, int mode, hipStream_t s) {
     const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
     if (tiles == 0) return hipSuccess;
-    if (a.row_floats == 2 * kRowFloats) {           // 17..32 coefficients per frame: the one-wave kernel over 32-float rows
+    if (a.row_floats == 2 * kRowFloats) {           // 17..32 coefficients per frame: 32-float rows
+        if constexpr (R == 5) {                     // (stock width, few tiles: four waves per tile, as the 16-float rows get)
+            if (mode == kRing && a.waves_per_tile == 4) {
+                hipLaunchKernelGGL((gru_mw_kernel<R, false, 2>), dim3(tiles), dim3(256), 0, s, a);
+                return hipGetLastError();
+            }
+        }
         if (mode == kRing) hipLaunchKernelGGL((gru_small_kernel<R, kRing, false, 2>), dim3(tiles), dim3(64), 0, s, a);
         else if (mode == kRows) hipLaunchKernelGGL((gru_small_kernel<R, kRows, false, 2>), dim3(tiles), dim3(64), 0, s, a);
         else hipLaunchKernelGGL((gru_small_kernel<R, kFeats, false, 2>), dim3(tiles), dim3(64), 0, s, a);
@@ -692,29 +698,60 @@ hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const WaveTables<do
 hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const WaveTables<float>& t, const GruArgs& g, int n_cus, hipStream_t s) { return launch_fused<float>(m, t, g, n_cus, s); }
 
 // ---- general front end (mfcc_general_device.h): one wave per stream / per frame -------------------------------------
-template <class R>
-__global__ __launch_bounds__(64) void mfcc_general_stream_kernel(const GeneralStreamArgs<R> a) {
+// (<= 128 registers: four waves per SIMD -- a wave walks the LDS round trips of one frame at a time, the others hide them;
+//  BITS = log2(n_fft / 2): the per-lane loops of a frame are unrolled for the transform length)
+// (n_fft = 2048: 25 KB of LDS per wave in float64 leave six waves per compute unit anyway: no register cap there)
+template <class R, int BITS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BITS >= 10 ? 2 : 4))) void mfcc_general_stream_kernel(const GeneralStreamArgs<R> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int s = blockIdx.x;
-    if (s < a.geo.n_streams) general_stream<R>(a, reinterpret_cast<R*>(smem), s, threadIdx.x);
+#ifndef PE_GEN_TWO_WAVES
+#define PE_GEN_TWO_WAVES 0      // two waves per stream (one per frame-row parity): measured SLOWER (62.6 vs 47.7 us per update at 4096 streams:
+                                // the launch is bound by rounds of resident waves, and this doubles the waves)
+#endif
+    const int s = PE_GEN_TWO_WAVES ? blockIdx.x >> 1 : blockIdx.x;
+    if (s < a.geo.n_streams) general_stream<R, BITS>(a, reinterpret_cast<R*>(smem), s, PE_GEN_TWO_WAVES ? blockIdx.x & 1 : 0, threadIdx.x, PE_GEN_TWO_WAVES ? 2 : 1);
 }
-template <class R>
-__global__ __launch_bounds__(64) void mfcc_general_offline_kernel(const GeneralOfflineArgs<R> a) {
+template <class R, int BITS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BITS >= 10 ? 2 : 4))) void mfcc_general_offline_kernel(const GeneralOfflineArgs<R> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    general_offline<R>(a, reinterpret_cast<R*>(smem), blockIdx.x, gridDim.x, threadIdx.x);
+    general_offline<R, BITS>(a, reinterpret_cast<R*>(smem), blockIdx.x, gridDim.x, threadIdx.x);
+}
+template <class R, int BITS>
+static void launch_general_stream_b(const GeneralStreamArgs<R>& a, hipStream_t s) {
+    hipLaunchKernelGGL((mfcc_general_stream_kernel<R, BITS>), dim3((PE_GEN_TWO_WAVES ? 2 : 1) * (unsigned)a.geo.n_streams), dim3(64), general_lds_bytes(sizeof(R), a.tab.n_fft, a.tab.n_filt, a.tab.n_rounds), s, a);
+}
+template <class R, int BITS>
+static void launch_general_offline_b(const GeneralOfflineArgs<R>& a, unsigned blocks, hipStream_t s) {
+    hipLaunchKernelGGL((mfcc_general_offline_kernel<R, BITS>), dim3(blocks), dim3(64), general_lds_bytes(sizeof(R), a.tab.n_fft, a.tab.n_filt, a.tab.n_rounds), s, a);
 }
 template <class R>
 static hipError_t launch_general_stream_t(const GeneralStreamArgs<R>& a, hipStream_t s) {
     if (a.geo.n_streams == 0) return hipSuccess;
-    hipLaunchKernelGGL(mfcc_general_stream_kernel<R>, dim3(a.geo.n_streams), dim3(64), general_lds_bytes(sizeof(R), a.tab.n_fft, a.tab.n_filt), s, a);
+    switch (a.tab.log2m) {
+        case 5: launch_general_stream_b<R, 5>(a, s); break;
+        case 6: launch_general_stream_b<R, 6>(a, s); break;
+        case 7: launch_general_stream_b<R, 7>(a, s); break;
+        case 8: launch_general_stream_b<R, 8>(a, s); break;
+        case 9: launch_general_stream_b<R, 9>(a, s); break;
+        case 10: launch_general_stream_b<R, 10>(a, s); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 template <class R>
 static hipError_t launch_general_offline_t(const GeneralOfflineArgs<R>& a, int n_cus, hipStream_t s) {
     if (a.n_frames <= 0) return hipSuccess;
     const long long cap = (long long)n_cus * 16;
-    hipLaunchKernelGGL(mfcc_general_offline_kernel<R>, dim3((unsigned)(a.n_frames < cap ? a.n_frames : cap)), dim3(64),
-                       general_lds_bytes(sizeof(R), a.tab.n_fft, a.tab.n_filt), s, a);
+    const unsigned blocks = (unsigned)(a.n_frames < cap ? a.n_frames : cap);
+    switch (a.tab.log2m) {
+        case 5: launch_general_offline_b<R, 5>(a, blocks, s); break;
+        case 6: launch_general_offline_b<R, 6>(a, blocks, s); break;
+        case 7: launch_general_offline_b<R, 7>(a, blocks, s); break;
+        case 8: launch_general_offline_b<R, 8>(a, blocks, s); break;
+        case 9: launch_general_offline_b<R, 9>(a, blocks, s); break;
+        case 10: launch_general_offline_b<R, 10>(a, blocks, s); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 hipError_t launch_general_stream_f64(const GeneralStreamArgs<double>& a, hipStream_t s) { return launch_general_stream_t<double>(a, s); }

@@ -565,11 +565,14 @@ def test_general_listener_params_streaming(kw, chunk):
         warnings.simplefilter('ignore')
         eng = HipEngine(hpr, w, n_streams=n)
         many = HipEngine(hpr, w, n_streams=n)
+        one = HipEngine(hpr, w, n_streams=n)
+    one.set_gru_waves(1)                 # (the automatic shape at this size is four waves per tile, 32-float rows included)
     refs = [ol.OracleListener(w, opr) for _ in range(n)]
     many.reserve_updates(4, chunk)
     worst = 0.0
     for u in range(n_up):
         raw = eng.update(pcm[u])
+        assert np.array_equal(one.update(pcm[u]), raw), u                                  # kernel shapes agree bit for bit
         want = np.array([r.update_raw(pcm[u, j].tobytes()) for j, r in enumerate(refs)])
         worst = max(worst, float(np.abs(raw - want).max()))
         if u % 4 == 3:
@@ -580,7 +583,7 @@ def test_general_listener_params_streaming(kw, chunk):
     assert np.abs(feats - np.stack([r.mfccs for r in refs])).max() <= TOL_FEAT32
     # explicit batches (Runner.predict) over the same windows
     assert np.abs(np.asarray(eng.predict(feats)).reshape(-1) - keras_gru.predict(feats, w)[:, 0]).max() <= GUARD_RAW
-    eng.close(); many.close()
+    eng.close(); many.close(); one.close()
 
 
 def test_device_threshold_decoder_and_trigger(stock_weights):

@@ -1,6 +1,6 @@
 // Microbenchmark of the stock GRU window (H = 20, F = 13, T = 29) at one 16-stream tile per compute unit: the shipped
 // four-wave shapes side by side, with shader-clock section timers of one wave per workgroup (-DPE_GRU_TIMERS).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPE_GRU_TIMERS -I mycroft_precise_amd/csrc -I include \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -DPE_CW_BIG_BOX -DPE_GRU_TIMERS -I mycroft_precise_amd/csrc -I include \
 //         tools/micro/gru_chain.hip -o tools/micro/build/gru_chain && tools/micro/build/gru_chain [streams]
 // Prints, per shape: launch time (HIP events over back-to-back launches), the largest deviation from a plain float32
 // CPU evaluation, whether the shapes agree bit for bit, and the mean section stamps over the workgroups.
@@ -10,6 +10,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#ifndef PE_CW_BIG_BOX
+#define PE_CW_BIG_BOX 1       // every split variant of gru_tile_cw in one binary: the larger mailbox area
+#endif
 #include "gru_device.h"
 #include "gru_cw_device.h"
 #include "gru_cw_pack.h"
@@ -22,11 +25,11 @@ __global__ __launch_bounds__(256) void k_mw5(const GruArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     gru_tile_mw5<false>(a, blockIdx.x, wave, threadIdx.x & 63, S);
 }
-template <bool VF>
+template <bool VF, int VAR = 0>
 __global__ __launch_bounds__(256) void k_cw(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float Sd[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    gru_tile_cw<VF>(a, blockIdx.x, wave, threadIdx.x & 63, Sd);
+    gru_tile_cw<VF, VAR>(a, blockIdx.x, wave, threadIdx.x & 63, Sd);
 }
 __global__ __launch_bounds__(64) void k_one(const GruArgs a) { gru_tile<5, kRing, false>(a, blockIdx.x, threadIdx.x); }
 __global__ __launch_bounds__(64) void k_v(const GruArgs a) { gru_tile_v<kRing, false>(a, blockIdx.x, threadIdx.x); }
@@ -113,6 +116,14 @@ int main(int argc, char** argv) {
             if (which == 0) hipLaunchKernelGGL(k_mw5, dim3(tiles), dim3(256), 0, 0, a);
             else if (which == 1) hipLaunchKernelGGL(k_cw<true>, dim3(tiles), dim3(256), cw_lds, 0, a);
             else if (which == 4) hipLaunchKernelGGL(k_cw<false>, dim3(tiles), dim3(256), cw_lds, 0, a);
+            else if (which == 5) hipLaunchKernelGGL((k_cw<false, 1>), dim3(tiles), dim3(256), cw_lds, 0, a);
+            else if (which == 6) hipLaunchKernelGGL((k_cw<false, 2>), dim3(tiles), dim3(256), cw_lds, 0, a);
+            else if (which == 7) hipLaunchKernelGGL((k_cw<false, 3>), dim3(tiles), dim3(256), cw_lds, 0, a);
+            else if (which == 8) hipLaunchKernelGGL((k_cw<false, 5>), dim3(tiles), dim3(256), cw_lds, 0, a);
+            else if (which == 9) hipLaunchKernelGGL((k_cw<false, 4>), dim3(tiles), dim3(256), cw_lds, 0, a);
+            else if (which == 10) hipLaunchKernelGGL((k_cw<false, 8>), dim3(tiles), dim3(256), cw_lds, 0, a);
+            else if (which == 11) hipLaunchKernelGGL((k_cw<false, 21>), dim3(tiles), dim3(256), cw_lds, 0, a);
+            else if (which == 12) hipLaunchKernelGGL((k_cw<false, 20>), dim3(tiles), dim3(256), cw_lds, 0, a);
             else if (which == 2) hipLaunchKernelGGL(k_one, dim3(tiles), dim3(64), 0, 0, a);
             else if (which == 3) hipLaunchKernelGGL(k_v, dim3(tiles), dim3(64), 0, 0, a);
         };
@@ -132,7 +143,7 @@ int main(int argc, char** argv) {
         float ms = 0; hipEventElapsedTime(&ms, e0, e1);
         printf("%-8s %d streams: %.2f us per launch (back to back), max |p - cpu| = %.3g, out[0] = %.7f\n", name, n_streams, ms / reps * 1e3, worst, out[0]);
 #ifdef PE_GRU_TIMERS
-        if (which <= 1 || which == 4) {
+        if (which <= 1 || which >= 4) {
             std::vector<unsigned long long> tm(256 * 32);
             hipMemcpyFromSymbol(tm.data(), HIP_SYMBOL(pe_gru_timers), tm.size() * 8);
             const int nb = tiles < 256 ? tiles : 256;
@@ -155,9 +166,17 @@ int main(int argc, char** argv) {
     run("cw_mfma4", 4);
     run("one", 2);
     run("v", 3);
+    run("cw_var1", 5);       // r partial sums of units 16..19 issued with the X chain
+    run("cw_var2", 6);       // candidate of units 16..19 on Z2, all of z on Z1
+    run("cw_var3", 7);       // both
+    run("cw_var5", 8);       // r partial sums with the X chain + candidate chain / partial sums pinned
+    run("cw_var4", 9);       // candidate chain / partial sums pinned only
+    run("cw_var8", 10);      // R's whole timestep hand-scheduled
+    run("cw_var21", 11);     // var5 + R's mailbox reads before the barrier (tag-validated)
+    run("cw_var20", 12);     // var4 + the same
     for (size_t k = 1; k < outs.size(); ++k) {
         int diff = 0; double md = 0;
-        const int base = k >= 2 && k != 3 ? 1 : 0;      // the re-tiled shapes among themselves, the old ones among themselves
+        const int base = k != 3 ? 1 : 0;      // the re-tiled shapes among themselves, the old ones among themselves
         for (int s = 0; s < n_streams; ++s) { if (memcmp(&outs[base][s], &outs[k][s], 4)) ++diff; md = fmax(md, fabs((double)outs[base][s] - outs[k][s])); }
         printf("shape %zu vs shape %d: %d of %d outputs differ in bits (max %.3g)\n", k, base, diff, n_streams, md);
     }
