@@ -165,7 +165,11 @@ PE_HD double wave_log(double x, const cx<double>* logtab) {
 }
 PE_HD float wave_log(float x, const cx<float>*) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return logf(x);
+    // v_log_f32 (log2, 1 ulp) times ln 2: two instructions where logf() is thirteen (denormal scaling, an extended-precision
+    // product, infinity checks).  The argument is >= 2^-52 (safe_log's clip) or a power of int16 samples: never denormal.
+    // Absolute error <= |ln x| 2^-23 + 1 ulp, i.e. a few 1e-6 at ln 2^-52 = -36: inside the float32 front end's own rounding
+    // (tests: every mfcc_precision = 'f32' case against the float64 oracle).
+    return __builtin_amdgcn_logf(x) * 0.6931471805599453094f;
 #else
     return std::log(x);
 #endif

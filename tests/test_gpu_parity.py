@@ -1120,7 +1120,7 @@ def test_full_batch_4096_streams_properties(stock_weights):
     assert info.n_streams == B and info.ring_slots == 32 and info.device_bytes > B * 2048
 
 
-def _full_size_run(weights, B, n_up, n_check, tol, guard_equal_positions=True, **listener_kw):
+def _full_size_run(weights, B, n_up, n_check, tol, guard_equal_positions=True, oracle_params=None, **listener_kw):
     """Size-independent properties at a BASELINE batch size: every stream is a copy of one of n_check seeded
     streams (shuffled), so (a) the seeded ones are checked against the oracle, (b) identical input must give
     bit-identical output wherever it sits in the batch, (c) clear + replay is bit-identical."""
@@ -1130,7 +1130,7 @@ def _full_size_run(weights, B, n_up, n_check, tol, guard_equal_positions=True, *
     owner = rng.integers(0, n_check, B)
     owner[:n_check] = np.arange(n_check)
     hip = BatchedListener(weights, B, **listener_kw)
-    ref = ol.BatchedOracle(weights, n_check)
+    ref = ol.BatchedOracle(weights, n_check, oracle_params)
     first, worst = [], 0.0
     for u in range(n_up):
         raw = hip.update_raw(base[u][owner])
@@ -1157,6 +1157,26 @@ def test_capacity_batch_65536_streams_properties(stock_weights):
     for u in range(33):
         assert np.array_equal(two.update(base[u][owner]), first[u]), u
     two.close()
+
+
+def test_full_batch_general_front_end_4096_streams_properties():
+    """A non-stock .params file at the BASELINE batch size (params.py:28-118: n_fft 1024, 40 filters, 20 coefficients --
+    the general front end, 32-float feature rows, the four-wave network over them): the size-independent properties and
+    the oracle on the seeded streams; then the one-wave network shape on the same updates, bit for bit."""
+    import warnings
+    from mycroft_precise_amd._lib import HipEngine
+    kw = dict(n_fft=1024, n_filt=40, n_mfcc=20)
+    hpr = P.pr.copy()
+    hpr.__dict__.update(kw)
+    w = synth.make_weights(n_in=20, units=(20,), seed=11)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        hip, base, owner, first = _full_size_run(w, 4096, 33, 16, GUARD_RAW, oracle_params=ol.Params(**kw), params=hpr)
+        one = HipEngine(hpr, w, n_streams=4096)
+    one.set_gru_waves(1)
+    for u in range(33):
+        assert np.array_equal(one.update(base[u][owner]), first[u]), u
+    one.close()
 
 
 def test_full_batch_wide_gru_4096_streams_properties():
