@@ -126,7 +126,11 @@ int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples
  * n_updates x n_streams windows -- for callers that can buffer a few chunks (catch-up, bulk
  * replay, latency-tolerant servers) this fills the machine where a single update of a few thousand
  * streams cannot.  pe_reserve_updates sizes the feature ring, the second leftover buffer and the
- * per-update counters for it (and restarts all streams); n_updates * chunk_samples < 2^30. */
+ * per-update counters for it (and restarts all streams); n_updates * chunk_samples < 2^30.
+ * Engines on the general front end (see pe_params) run the same n updates one after the other inside the call (two launches
+ * each, same bits).  The enlarged ring stays: later single pe_update calls on a reserved engine are unchanged in their
+ * results but, up to 8192 streams, use the one-wave network shape (the critical-wave shape stages exactly 32 ring slots in
+ * LDS) -- reserve only on engines that use pe_update_many. */
 int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samples);
 int pe_update_many(pe_engine* e, const int16_t* pcm_host, int32_t chunk_samples, int32_t n_updates, float* raw_out_host);
 int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples, int32_t n_updates,
