@@ -44,7 +44,8 @@ typedef struct pe_params {
     int32_t sample_rate;     /* 16000                                        params.py:142 */
     int32_t window_samples;  /* 1600   int(sample_rate*window_t+0.5)         params.py:84  */
     int32_t hop_samples;     /* 800    int(sample_rate*hop_t+0.5)            params.py:89  */
-    int32_t n_fft;           /* 512    any power of two in 64..2048          params.py:142 */
+    int32_t n_fft;           /* 512    a power of two in 64..2048, or ANY other
+                                       length in 16..1024 (np.fft.rfft takes any n) params.py:142 */
     int32_t n_filt;          /* 20     mel filters, 1..128                   params.py:142 */
     int32_t n_mfcc;          /* 13     coefficients kept, 1..32, <= n_filt   params.py:142
                                 Front-end kernels: the stock shape (n_fft = 512, <= 64 filters whose runs fit the 64
@@ -52,8 +53,10 @@ typedef struct pe_params {
                                 launch; EVERY OTHER shape in the ranges above runs on the general front end (same
                                 results contract, two launches per update, pe_update_many = the same updates one after
                                 the other).  17..32 coefficients feed the float32 network of <= 32 units without
-                                use_delta only; the bf16 configuration exists for the stock shape only.  Outside the
-                                ranges (n_fft not a power of two, > 2048, ...): PE_ERR_UNSUPPORTED.                  */
+                                use_delta only; the bf16 configuration exists for the stock shape only.  An n_fft that is
+                                not a power of two runs as Bluestein's chirp-z transform over the next power of two
+                                >= 2 n_fft - 1 (one wave's LDS holds it up to n_fft = 1024).  Outside the ranges
+                                (n_fft > 2048, not a power of two and > 1024, < 16, ...): PE_ERR_UNSUPPORTED.          */
     int32_t n_features;      /* 29     T, timesteps per network input        params.py:79  */
     int32_t use_delta;       /* 0      1: network inputs are [x_t, x_t - x_(t-1)]
                                        (vectorization.py:53-59), layer n_in = 2 n_mfcc   params.py:143 */

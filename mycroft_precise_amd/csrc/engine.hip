@@ -173,16 +173,53 @@ int build_tables(pe_engine* e, const double* mel_filters) {
 // Tables of the general front end: twiddles of the packed real FFT, the filterbank as CSR, the DCT-II (ortho) matrix.
 template <class R>
 int build_general_tables(pe_engine* e, const double* mel_filters) {
-    const int N = e->prm.n_fft, M = N / 2, bins = M + 1, nf = e->prm.n_filt, nc = e->prm.n_mfcc;
+    const int N = e->prm.n_fft, bins = N / 2 + 1, nf = e->prm.n_filt, nc = e->prm.n_mfcc;
     const long double PI = 3.14159265358979323846264338327950288L;
-    std::vector<R> tw((size_t)M), wn((size_t)(M / 2 + 1) * 2);       // tw: M / 2 complex = M reals
+    const bool pow2 = general_is_pow2(N);
+    // power of two: packed real transform of M = N / 2 points;  otherwise Bluestein over L = 2^log2m >= 2 N - 1 points
+    const int log2m_blue = general_blue_log2(N);
+    const int M = pow2 ? N / 2 : (1 << log2m_blue);           // length of the complex radix-2 transform in LDS
+    std::vector<R> tw((size_t)M), wn((size_t)(pow2 ? (M / 2 + 1) * 2 : 2));       // tw: M / 2 complex = M reals
     for (int k = 0; k < M / 2; ++k) {
         tw[2 * k] = (R)cosl(-2.0L * PI * k / M);
         tw[2 * k + 1] = (R)sinl(-2.0L * PI * k / M);
     }
-    for (int k = 0; k <= M / 2; ++k) {
-        wn[2 * k] = (R)cosl(-2.0L * PI * k / N);
-        wn[2 * k + 1] = (R)sinl(-2.0L * PI * k / N);
+    if (pow2)
+        for (int k = 0; k <= M / 2; ++k) {
+            wn[2 * k] = (R)cosl(-2.0L * PI * k / N);
+            wn[2 * k + 1] = (R)sinl(-2.0L * PI * k / N);
+        }
+    std::vector<R> chirp, bhat;
+    if (!pow2) {
+        // w[n] = exp(-i pi n^2 / N): the angle from n^2 mod 2 N (exact integers), so large n lose nothing
+        auto wl = [&](long long n, long double& re, long double& im) {
+            const long long r = (n * n) % (2LL * N);
+            const long double a = -PI * (long double)r / (long double)N;
+            re = cosl(a); im = sinl(a);
+        };
+        chirp.resize((size_t)2 * N);
+        for (int n = 0; n < N; ++n) { long double re, im; wl(n, re, im); chirp[2 * n] = (R)re; chirp[2 * n + 1] = (R)im; }
+        // b[m mod L] = conj(w[m]) for |m| < N, zero elsewhere; B = DFT_L(b) (direct, long double, roots from an exact table)
+        const int L = M;
+        std::vector<long double> br((size_t)L, 0.0L), bi((size_t)L, 0.0L), cr((size_t)L), ci((size_t)L);
+        for (int m = -(N - 1); m <= N - 1; ++m) { long double re, im; wl(m, re, im); br[(m + L) % L] = re; bi[(m + L) % L] = -im; }
+        for (int j = 0; j < L; ++j) { cr[j] = cosl(-2.0L * PI * j / L); ci[j] = sinl(-2.0L * PI * j / L); }
+        bhat.resize((size_t)2 * L);
+        int bits = 0;
+        while ((1 << bits) < L) ++bits;
+        for (int k = 0; k < L; ++k) {
+            long double sr = 0.0L, si = 0.0L;
+            for (int m = 0; m < L; ++m) {
+                if (br[m] == 0.0L && bi[m] == 0.0L) continue;
+                const int j = (int)(((long long)k * m) % L);
+                sr += br[m] * cr[j] - bi[m] * ci[j];
+                si += br[m] * ci[j] + bi[m] * cr[j];
+            }
+            unsigned rev = 0;
+            for (int b = 0; b < bits; ++b) rev |= ((unsigned)(k >> b) & 1u) << (bits - 1 - b);
+            bhat[2 * (size_t)rev] = (R)(sr / L);               // bit-reversed position, 1 / L of the inverse transform folded in
+            bhat[2 * (size_t)rev + 1] = (R)(si / L);
+        }
     }
     // filterbank as lane runs (mfcc_general_device.h: GeneralTables): every filter's non-zeros, in bin order, in runs of
     // <= kGeneralRun entries; run r <-> lane r % 64 of round r / 64
@@ -228,7 +265,12 @@ int build_general_tables(pe_engine* e, const double* mel_filters) {
     if ((rc = dev_upload(e, &d_bin, run_bin))) return rc;
     int log2m = 0;
     while ((1 << log2m) < M) ++log2m;
-    e->gtab = GeneralTables{d_tw, d_wn, d_w, d_bin, d_ptr, d_dct, N, log2m, nf, nc, e->prm.vectorizer == 3 ? 1 : 0, n_rounds};
+    R* d_chirp = nullptr; R* d_bhat = nullptr;
+    if (!pow2) {
+        if ((rc = dev_upload(e, &d_chirp, chirp))) return rc;
+        if ((rc = dev_upload(e, &d_bhat, bhat))) return rc;
+    }
+    e->gtab = GeneralTables{d_tw, d_wn, d_w, d_bin, d_ptr, d_dct, N, log2m, nf, nc, e->prm.vectorizer == 3 ? 1 : 0, n_rounds, d_chirp, d_bhat};
     return PE_OK;
 }
 
@@ -658,8 +700,10 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     if (n_streams <= 0) return fail(nullptr, PE_ERR_INVALID, "n_streams must be positive, got %d", n_streams);
     // ListenerParams (params.py:28-118): the stock shape (n_fft = 512, <= 64 filters, <= 16 coefficients) runs on the
     // one-frame-per-wave kernel, every other shape on the general front end (mfcc_general_device.h)
-    if (p->n_fft < 64 || p->n_fft > kGeneralMaxFft || (p->n_fft & (p->n_fft - 1)) != 0)
-        return fail(nullptr, PE_ERR_UNSUPPORTED, "n_fft must be a power of two in 64..%d (got %d)", kGeneralMaxFft, p->n_fft);
+    // ... any n_fft from 16 on: powers of two up to 2048 as a packed real transform, every other length up to 1024 (numpy's
+    // rfft takes any n) through Bluestein's chirp-z form over the next power of two >= 2 n_fft - 1
+    if (p->n_fft < 16 || p->n_fft > kGeneralMaxFft || (!general_is_pow2(p->n_fft) && p->n_fft > kGeneralMaxBlueFft) || (general_is_pow2(p->n_fft) && p->n_fft < 64))
+        return fail(nullptr, PE_ERR_UNSUPPORTED, "n_fft must be a power of two in 64..%d or any other length in 16..%d (got %d)", kGeneralMaxFft, kGeneralMaxBlueFft, p->n_fft);
     if (p->n_mfcc < 1 || p->n_mfcc > kGeneralMaxMfcc) return fail(nullptr, PE_ERR_UNSUPPORTED, "n_mfcc must be in 1..%d (got %d)", kGeneralMaxMfcc, p->n_mfcc);
     if (p->n_filt < 1 || p->n_filt > kGeneralMaxFilt || p->n_mfcc > p->n_filt)
         return fail(nullptr, PE_ERR_UNSUPPORTED, "need 1 <= n_mfcc <= n_filt <= %d (got n_filt=%d n_mfcc=%d)", kGeneralMaxFilt, p->n_filt, p->n_mfcc);

@@ -701,7 +701,7 @@ hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const WaveTables<flo
 // (<= 128 registers: four waves per SIMD -- a wave walks the LDS round trips of one frame at a time, the others hide them;
 //  BITS = log2(n_fft / 2): the per-lane loops of a frame are unrolled for the transform length)
 // (n_fft = 2048: 25 KB of LDS per wave in float64 leave six waves per compute unit anyway: no register cap there)
-template <class R, int BITS>
+template <class R, int BITS, bool BLUE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BITS >= 10 ? 2 : 4))) void mfcc_general_stream_kernel(const GeneralStreamArgs<R> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifndef PE_GEN_TWO_WAVES
@@ -709,24 +709,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BITS >= 10 ?
                                 // the launch is bound by rounds of resident waves, and this doubles the waves)
 #endif
     const int s = PE_GEN_TWO_WAVES ? blockIdx.x >> 1 : blockIdx.x;
-    if (s < a.geo.n_streams) general_stream<R, BITS>(a, reinterpret_cast<R*>(smem), s, PE_GEN_TWO_WAVES ? blockIdx.x & 1 : 0, threadIdx.x, PE_GEN_TWO_WAVES ? 2 : 1);
+    if (s < a.geo.n_streams) general_stream<R, BITS, BLUE>(a, reinterpret_cast<R*>(smem), s, PE_GEN_TWO_WAVES ? blockIdx.x & 1 : 0, threadIdx.x, PE_GEN_TWO_WAVES ? 2 : 1);
 }
-template <class R, int BITS>
+template <class R, int BITS, bool BLUE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BITS >= 10 ? 2 : 4))) void mfcc_general_offline_kernel(const GeneralOfflineArgs<R> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    general_offline<R, BITS>(a, reinterpret_cast<R*>(smem), blockIdx.x, gridDim.x, threadIdx.x);
+    general_offline<R, BITS, BLUE>(a, reinterpret_cast<R*>(smem), blockIdx.x, gridDim.x, threadIdx.x);
 }
-template <class R, int BITS>
+template <class R, int BITS, bool BLUE = false>
 static void launch_general_stream_b(const GeneralStreamArgs<R>& a, hipStream_t s) {
-    hipLaunchKernelGGL((mfcc_general_stream_kernel<R, BITS>), dim3((PE_GEN_TWO_WAVES ? 2 : 1) * (unsigned)a.geo.n_streams), dim3(64), general_lds_bytes(sizeof(R), a.tab.n_fft, a.tab.n_filt, a.tab.n_rounds), s, a);
+    hipLaunchKernelGGL((mfcc_general_stream_kernel<R, BITS, BLUE>), dim3((PE_GEN_TWO_WAVES ? 2 : 1) * (unsigned)a.geo.n_streams), dim3(64), general_lds_bytes(sizeof(R), a.tab.n_fft, a.tab.n_filt, a.tab.n_rounds), s, a);
 }
-template <class R, int BITS>
+template <class R, int BITS, bool BLUE = false>
 static void launch_general_offline_b(const GeneralOfflineArgs<R>& a, unsigned blocks, hipStream_t s) {
-    hipLaunchKernelGGL((mfcc_general_offline_kernel<R, BITS>), dim3(blocks), dim3(64), general_lds_bytes(sizeof(R), a.tab.n_fft, a.tab.n_filt, a.tab.n_rounds), s, a);
+    hipLaunchKernelGGL((mfcc_general_offline_kernel<R, BITS, BLUE>), dim3(blocks), dim3(64), general_lds_bytes(sizeof(R), a.tab.n_fft, a.tab.n_filt, a.tab.n_rounds), s, a);
 }
 template <class R>
 static hipError_t launch_general_stream_t(const GeneralStreamArgs<R>& a, hipStream_t s) {
     if (a.geo.n_streams == 0) return hipSuccess;
+    if (a.tab.chirp) {                      // n_fft not a power of two: Bluestein over L = 2^log2m points
+        switch (a.tab.log2m) {
+            case 7: launch_general_stream_b<R, 7, true>(a, s); break;
+            case 8: launch_general_stream_b<R, 8, true>(a, s); break;
+            case 9: launch_general_stream_b<R, 9, true>(a, s); break;
+            case 10: launch_general_stream_b<R, 10, true>(a, s); break;
+            case 11: launch_general_stream_b<R, 11, true>(a, s); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (a.tab.log2m) {
         case 5: launch_general_stream_b<R, 5>(a, s); break;
         case 6: launch_general_stream_b<R, 6>(a, s); break;
@@ -743,6 +754,17 @@ static hipError_t launch_general_offline_t(const GeneralOfflineArgs<R>& a, int n
     if (a.n_frames <= 0) return hipSuccess;
     const long long cap = (long long)n_cus * 16;
     const unsigned blocks = (unsigned)(a.n_frames < cap ? a.n_frames : cap);
+    if (a.tab.chirp) {
+        switch (a.tab.log2m) {
+            case 7: launch_general_offline_b<R, 7, true>(a, blocks, s); break;
+            case 8: launch_general_offline_b<R, 8, true>(a, blocks, s); break;
+            case 9: launch_general_offline_b<R, 9, true>(a, blocks, s); break;
+            case 10: launch_general_offline_b<R, 10, true>(a, blocks, s); break;
+            case 11: launch_general_offline_b<R, 11, true>(a, blocks, s); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (a.tab.log2m) {
         case 5: launch_general_offline_b<R, 5>(a, blocks, s); break;
         case 6: launch_general_offline_b<R, 6>(a, blocks, s); break;

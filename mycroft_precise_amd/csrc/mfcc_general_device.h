@@ -34,12 +34,17 @@ struct GeneralTables {          // device pointers, built by engine.hip (build_g
     const int* run_ptr;         // [n_filt + 1] first run of every filter
     const void* dct_t;          // [n_filt][kGeneralDctCols] R: DCT-II (ortho) transposed, row f = the weights of filter f for every coefficient
     int n_fft, log2m, n_filt, n_mfcc, log_mode, n_rounds;
+    // n_fft that is not a power of two (np.fft.rfft takes any length, vectorization.py:36-39): Bluestein's chirp-z form
+    // of the DFT over a complex transform of length L = 2^log2m >= 2 n_fft - 1 (general_frame_blue); null otherwise
+    const void* chirp;          // [n_fft] complex R: exp(-i pi n^2 / n_fft)
+    const void* bhat;           // [L] complex R: FFT_L of the wrapped conjugate chirp, / L, in BIT-REVERSED order
 };
 
 #ifndef PE_GEN_ABL
 #define PE_GEN_ABL 0        // tuning aid (wrong results): 1 no leftover copy, 2 samples = 0 (no PCM loads), 4 no FFT stages, 8 no mel / log / DCT
 #endif
 constexpr int kGeneralMaxFft = 2048;
+constexpr int kGeneralMaxBlueFft = 1024;     // non-power-of-two n_fft: the Bluestein transform of 2048 complex points is what one wave's LDS holds in float64
 constexpr int kGeneralMaxFilt = 128;
 constexpr int kGeneralMaxMfcc = 32;
 
@@ -48,12 +53,79 @@ constexpr int kGeneralMaxMfcc = 32;
 // per wave in float64 at n_fft = 1024, i.e. sixteen instead of twelve waves per compute unit -- 4096 streams in ONE round of
 // resident waves instead of two (measured: 47.7 -> us per update).
 __host__ __device__ inline bool general_overlay(int n_fft) { return n_fft <= 1024; }
+__host__ __device__ inline bool general_is_pow2(int n_fft) { return (n_fft & (n_fft - 1)) == 0; }
+// Bluestein transform length for a non-power-of-two n_fft: the next power of two >= 2 n_fft - 1
+__host__ __device__ inline int general_blue_log2(int n_fft) { int b = 7; while ((1 << b) < 2 * n_fft - 1) ++b; return b; }      // (>= 128 points: a butterfly per lane)
 __host__ __device__ inline size_t general_lds_bytes(int real_size, int n_fft, int n_filt, int n_rounds) {
+    if (!general_is_pow2(n_fft))        // Z[L] complex (the power spectrum overlays it), LM, PART
+        return (size_t)real_size * (2 * (1 << general_blue_log2(n_fft)) + (n_filt + 1) + 3 + 64 * n_rounds);
     const int M = n_fft / 2;
     return (size_t)real_size * (2 * M + (general_overlay(n_fft) ? 0 : M + 1) + (n_filt + 1) + 3 + 64 * n_rounds);
 }
 
 __device__ __forceinline__ int bit_reverse(int v, int bits) { return (int)(__brev((unsigned)v) >> (32 - bits)); }
+
+// The part of a frame behind the power spectrum: P[0 .. n_fft / 2] in LDS, psum = this lane's share of the total power.
+template <class R>
+__device__ __forceinline__ void general_frame_tail(const GeneralTables& t, const R* P, R* LM, R* PART, const int lane, R psum, R (&coeff)[1]) {
+    using K = RealK<R>;
+    group_sync();
+    psum = wave_sum(psum);
+    auto vlog = [&](R x) -> R {
+        // sonopy clips at eps (safe_log); speechpy replaces exact zeros only (zero_handling): 0 < x < eps stays x
+        return real_log(t.log_mode == 0 ? (x > K::EPS ? x : K::EPS) : (x == R(0) ? K::EPS : x));
+    };
+    if (!(PE_GEN_ABL & 8)) {
+        // filterbank: every lane one run per round (all table loads of a round first), one partial sum each
+        const R* rw = static_cast<const R*>(t.run_w);
+        for (int r = 0; r < t.n_rounds; ++r) {
+            R acc = R(0);
+            constexpr int HB = kGeneralRun / 2;                 // two batches of reads: half the registers in flight
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                R wv[HB];
+                int bv[HB];
+#pragma unroll
+                for (int i = 0; i < HB; ++i) {
+                    wv[i] = rw[((size_t)r * kGeneralRun + h * HB + i) * 64 + lane];
+                    bv[i] = t.run_bin[((size_t)r * kGeneralRun + h * HB + i) * 64 + lane];
+                }
+#pragma unroll
+                for (int i = 0; i < HB; ++i) acc = real_fma(wv[i], P[bv[i]], acc);
+            }
+            PART[r * 64 + lane] = acc;
+        }
+        group_sync();
+        for (int f = lane; f < t.n_filt; f += 64) {
+            R acc = R(0);
+            for (int i = t.run_ptr[f]; i < t.run_ptr[f + 1]; ++i) acc += PART[i];
+            LM[f] = vlog(acc);
+        }
+    }
+    if (lane == 0) LM[t.n_filt] = vlog(psum);
+    group_sync();
+    // DCT-II (ortho): lane c + 32 h adds the filters of half h for coefficient c (transposed table: a row per filter, the
+    // 32 coefficients side by side), the halves are added across the wave; coefficient 0 := log of the total power
+    R c = R(0);
+    if (!(PE_GEN_ABL & 8)) {
+        const R* dt = static_cast<const R*>(t.dct_t);
+        const int col = lane & 31, hf = lane >> 5, nh = (t.n_filt + 1) >> 1;
+        const int f0 = hf * nh, f1 = f0 + nh < t.n_filt ? f0 + nh : t.n_filt;
+        int f = f0;
+        for (; f + 4 <= f1; f += 4) {
+            R dv[4], lv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dv[i] = dt[(size_t)(f + i) * kGeneralDctCols + col]; lv[i] = LM[f + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c = real_fma(dv[i], lv[i], c);
+        }
+        for (; f < f1; ++f) c = real_fma(dt[(size_t)f * kGeneralDctCols + col], LM[f], c);
+        c += __shfl_xor(c, 32);
+    }
+    if (lane == 0) c = LM[t.n_filt];
+    coeff[0] = lane < t.n_mfcc ? c : R(0);
+    group_sync();
+}
 
 // One frame of M = 2^BITS packed complex points.  point(n) returns point n (samples 2n, 2n + 1 as reals, already scaled,
 // zero beyond the frame length) for 0 <= n < M; it is called for all of a lane's points BEFORE any of them is used, so a
@@ -205,62 +277,100 @@ __device__ __forceinline__ void general_frame_t(const GeneralTables& t, R* S, co
             if (k != M - k) { P[M - k] = pb; psum += pb; }
         }
     }
+    general_frame_tail<R>(t, P, LM, PART, lane, psum, coeff);
+}
+
+// ---- n_fft that is not a power of two: Bluestein -------------------------------------------------------------------------
+// X[k] = sum_n x[n] e^(-2 pi i n k / N) = w[k] sum_n (x[n] w[n]) conj(w[k - n]),  w[m] = e^(-i pi m^2 / N): a circular
+// convolution of length L = 2^BITS >= 2 N - 1, done with two complex radix-2 transforms in the wave's LDS --
+//   a[n] = x[n] w[n] (zero beyond N), natural order  ->  decimation in FREQUENCY (output bit-reversed)
+//   ->  pointwise product with the host-made FFT_L(conj-chirp) / L, stored bit-reversed as well
+//   ->  decimation in TIME with conjugate twiddles (input bit-reversed, output natural) = the inverse transform
+// -- no permutation pass.  |w[k]| = 1, so the power spectrum is |c[k]|^2 / N directly.  sample(n): sample n of the frame as R
+// (already scaled; zero beyond the frame length), 0 <= n < N.
+template <class R, int BITS, class Sample>
+__device__ __forceinline__ void general_frame_blue(const GeneralTables& t, R* S, const int lane, Sample sample, R (&coeff)[1]) {
+    constexpr int L = 1 << BITS, NB = L / 2 / 64;
+    const int N = t.n_fft, bins = N / 2 + 1;
+    cplx<R>* Z = reinterpret_cast<cplx<R>*>(S);
+    R* P = S;                                        // overlays Z (all of a lane's c[k] are read before any P is written)
+    R* LM = S + 2 * L;
+    R* PART = LM + (t.n_filt + 1) + 3;
+    const cplx<R>* tw = static_cast<const cplx<R>*>(t.tw);           // W_L^k, k < L / 2
+    const cplx<R>* chirp = static_cast<const cplx<R>*>(t.chirp);
+    const cplx<R>* bhat = static_cast<const cplx<R>*>(t.bhat);
+    for (int n0 = 0; n0 < L; n0 += 256) {
+        R xv[4];
+        cplx<R> wv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + 64 * i + lane, nc = n < N ? n : 0;
+            xv[i] = (PE_GEN_ABL & 2) ? R(1) : sample(nc);
+            wv[i] = chirp[nc];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + 64 * i + lane;
+            if (n < L) Z[n] = n < N ? cplx<R>{xv[i] * wv[i].x, xv[i] * wv[i].y} : cplx<R>{R(0), R(0)};
+        }
+    }
     group_sync();
-    psum = wave_sum(psum);
-    auto vlog = [&](R x) -> R {
-        // sonopy clips at eps (safe_log); speechpy replaces exact zeros only (zero_handling): 0 < x < eps stays x
-        return real_log(t.log_mode == 0 ? (x > K::EPS ? x : K::EPS) : (x == R(0) ? K::EPS : x));
-    };
-    if (!(PE_GEN_ABL & 8)) {
-        // filterbank: every lane one run per round (all table loads of a round first), one partial sum each
-        const R* rw = static_cast<const R*>(t.run_w);
-        for (int r = 0; r < t.n_rounds; ++r) {
-            R acc = R(0);
-            constexpr int HB = kGeneralRun / 2;                 // two batches of reads: half the registers in flight
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                R wv[HB];
-                int bv[HB];
-#pragma unroll
-                for (int i = 0; i < HB; ++i) {
-                    wv[i] = rw[((size_t)r * kGeneralRun + h * HB + i) * 64 + lane];
-                    bv[i] = t.run_bin[((size_t)r * kGeneralRun + h * HB + i) * 64 + lane];
-                }
-#pragma unroll
-                for (int i = 0; i < HB; ++i) acc = real_fma(wv[i], P[bv[i]], acc);
+    // one radix-2 stage over Z: DIF (a + b, (a - b) w) or DIT with conjugate twiddles (a + b w*, a - b w*)
+    auto stage = [&](const int s, const bool dif) {
+        const int half = 1 << s, tstep = L >> (s + 1);
+#pragma unroll 2
+        for (int k = 0; k < NB; ++k) {
+            const int jb = lane + 64 * k, pos = jb & (half - 1), i0 = ((jb >> s) << (s + 1)) + pos;
+            const cplx<R> w = tw[pos * tstep], av = Z[i0], bv = Z[i0 + half];
+            if (dif) {
+                const R dr = av.x - bv.x, di = av.y - bv.y;
+                Z[i0] = cplx<R>{av.x + bv.x, av.y + bv.y};
+                Z[i0 + half] = cplx<R>{dr * w.x - di * w.y, dr * w.y + di * w.x};
+            } else {
+                const R tr = w.x * bv.x + w.y * bv.y, ti = w.x * bv.y - w.y * bv.x;       // b conj(w)
+                Z[i0] = cplx<R>{av.x + tr, av.y + ti};
+                Z[i0 + half] = cplx<R>{av.x - tr, av.y - ti};
             }
-            PART[r * 64 + lane] = acc;
         }
         group_sync();
-        for (int f = lane; f < t.n_filt; f += 64) {
-            R acc = R(0);
-            for (int i = t.run_ptr[f]; i < t.run_ptr[f + 1]; ++i) acc += PART[i];
-            LM[f] = vlog(acc);
+    };
+    if (!(PE_GEN_ABL & 4)) {
+#pragma unroll 1
+        for (int s = BITS - 1; s >= 0; --s) stage(s, true);
+        for (int p0 = 0; p0 < L; p0 += 256) {
+            cplx<R> bh[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bh[i] = bhat[p0 + 64 * i + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = p0 + 64 * i + lane;
+                const cplx<R> av = Z[p];
+                Z[p] = cplx<R>{av.x * bh[i].x - av.y * bh[i].y, av.x * bh[i].y + av.y * bh[i].x};
+            }
+        }
+        group_sync();
+#pragma unroll 1
+        for (int s = 0; s < BITS; ++s) stage(s, false);
+    }
+    // power spectrum: every lane reads its c[k] first (P overlays Z), then the wave synchronises, then P is written
+    const R inv_n = R(1) / R(N);
+    R psum = R(0);
+    constexpr int NSB = (L / 4 + 1 + 63) / 64;          // bins <= N / 2 + 1 <= L / 4 + 1
+    cplx<R> cv[NSB];
+#pragma unroll
+    for (int i = 0; i < NSB; ++i) { const int k = lane + 64 * i; cv[i] = Z[k < bins ? k : 0]; }
+    group_sync();
+#pragma unroll
+    for (int i = 0; i < NSB; ++i) {
+        const int k = lane + 64 * i;
+        if (k < bins) {
+            const R pk = (cv[i].x * cv[i].x + cv[i].y * cv[i].y) * inv_n;
+            P[k] = pk;
+            // total power as np.sum over the rfft bins does it: every bin once
+            psum += pk;
         }
     }
-    if (lane == 0) LM[t.n_filt] = vlog(psum);
-    group_sync();
-    // DCT-II (ortho): lane c + 32 h adds the filters of half h for coefficient c (transposed table: a row per filter, the
-    // 32 coefficients side by side), the halves are added across the wave; coefficient 0 := log of the total power
-    R c = R(0);
-    if (!(PE_GEN_ABL & 8)) {
-        const R* dt = static_cast<const R*>(t.dct_t);
-        const int col = lane & 31, hf = lane >> 5, nh = (t.n_filt + 1) >> 1;
-        const int f0 = hf * nh, f1 = f0 + nh < t.n_filt ? f0 + nh : t.n_filt;
-        int f = f0;
-        for (; f + 4 <= f1; f += 4) {
-            R dv[4], lv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { dv[i] = dt[(size_t)(f + i) * kGeneralDctCols + col]; lv[i] = LM[f + i]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) c = real_fma(dv[i], lv[i], c);
-        }
-        for (; f < f1; ++f) c = real_fma(dt[(size_t)f * kGeneralDctCols + col], LM[f], c);
-        c += __shfl_xor(c, 32);
-    }
-    if (lane == 0) c = LM[t.n_filt];
-    coeff[0] = lane < t.n_mfcc ? c : R(0);
-    group_sync();
+    general_frame_tail<R>(t, P, LM, PART, lane, psum, coeff);
 }
 
 // (the transform length is a template parameter of the frame -- unrolled per-lane loops -- and of the kernels around it:
@@ -290,7 +400,7 @@ struct GeneralStreamArgs {
 // Two waves per stream: wave `par` takes the due frames kb = first + par, first + par + 2, ... (1024-sample chunks complete one
 // or two frames per update: the second frame of a stream no longer waits for its first), wave 0 also moves the leftover
 // samples and the counters.  Both read the state before the update; only wave 0 writes the state after it.
-template <class R, int BITS>
+template <class R, int BITS, bool BLUE = false>
 __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R* S, const int s, const int par, const int lane, const int n_par = 2) {
     const StreamGeom& geo = a.geo;
     const int C = a.chunk, hop = geo.hop, flen = geo.frame_len, slots = geo.ring_slots;
@@ -309,7 +419,9 @@ __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R*
     for (int kb = (nnew > slots ? nnew - slots : 0) + par; kb < nnew; kb += n_par) {
         const int vb = kb * hop;
         R coeff[1];
-        if (pairs) {
+        if constexpr (BLUE) {
+            general_frame_blue<R, BITS>(a.tab, S, lane, [&](int n) -> R { return n < flen ? (R)vsample(vb + n) * RealK<R>::INV_I16 : R(0); }, coeff);
+        } else if (pairs) {
             general_frame<R, BITS>(a.tab, S, lane, [&](int n) -> cplx<R> {
                 const int m = 2 * n < flen ? 2 * n : 0, v = vb + m;           // (beyond the frame: a valid pair, zeroed below)
                 const int16_t* p = v < q ? car + v : row + (v - q);
@@ -373,15 +485,16 @@ struct GeneralOfflineArgs {
     int row_floats;
 };
 
-template <class R, int BITS>
+template <class R, int BITS, bool BLUE = false>
 __device__ __forceinline__ void general_offline(const GeneralOfflineArgs<R>& a, R* S, const long long first, const long long stride, const int lane) {
     const StreamGeom& geo = a.geo;
-    const int M = a.tab.n_fft >> 1;
+    const int M = BLUE ? (1 << BITS) : (a.tab.n_fft >> 1);          // (BLUE: reals before LM = 2 L)
     for (long long fr = first; fr < a.n_frames; fr += stride) {
         const double* x = a.audio + fr * geo.hop;
         R coeff[1];
         const int flen = geo.frame_len;
-        general_frame<R, BITS>(a.tab, S, lane, [&](int n) -> cplx<R> {
+        if constexpr (BLUE) general_frame_blue<R, BITS>(a.tab, S, lane, [&](int n) -> R { return n < flen ? (R)x[n] : R(0); }, coeff);
+        else general_frame<R, BITS>(a.tab, S, lane, [&](int n) -> cplx<R> {
             const int m0 = 2 * n, m1 = 2 * n + 1;                             // (clamped indices: plain loads, selected afterwards)
             const double x0 = x[m0 < flen ? m0 : 0], x1 = x[m1 < flen ? m1 : 0];
             return cplx<R>{m0 < flen ? (R)x0 : R(0), m1 < flen ? (R)x1 : R(0)};
@@ -389,7 +502,7 @@ __device__ __forceinline__ void general_offline(const GeneralOfflineArgs<R>& a, 
         if (a.out && lane < geo.n_mfcc) a.out[fr * geo.n_mfcc + lane] = (double)coeff[0];
         if (a.out_rows && lane < a.row_floats) a.out_rows[fr * a.row_floats + lane] = lane < geo.n_mfcc ? (float)coeff[0] : 0.0f;
         if (a.out_mels) {
-            const R* LM = S + 2 * M + (general_overlay(a.tab.n_fft) ? 0 : M + 1);
+            const R* LM = S + 2 * M + ((BLUE || general_overlay(a.tab.n_fft)) ? 0 : M + 1);
             for (int f = lane; f < geo.n_filt; f += 64) a.out_mels[fr * geo.n_filt + f] = (double)LM[f];
         }
         group_sync();

@@ -491,8 +491,13 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
             wg_end = wg_end < n_slots ? wg_end : n_slots;
             const long long len = wg_end > wg_begin ? wg_end - wg_begin : 0;
             // cumulative shares in sixteenths by SIMD: 3 | 4 | 5 | 4 (the wave on SIMD 0 sits beside the critical wave)
-            const int lo16 = simd == 0 ? 0 : simd == 1 ? 3 : simd == 2 ? 7 : 12;
-            const int hi16 = simd == 0 ? 3 : simd == 1 ? 7 : simd == 2 ? 12 : 16;
+#ifndef PE_SIMD_SPLIT_A
+#define PE_SIMD_SPLIT_A 3       // cumulative sixteenths: A | B | C | 16 (tuning knob; measured again in round 4: r4p)
+#define PE_SIMD_SPLIT_B 7
+#define PE_SIMD_SPLIT_C 12
+#endif
+            const int lo16 = simd == 0 ? 0 : simd == 1 ? PE_SIMD_SPLIT_A : simd == 2 ? PE_SIMD_SPLIT_B : PE_SIMD_SPLIT_C;
+            const int hi16 = simd == 0 ? PE_SIMD_SPLIT_A : simd == 1 ? PE_SIMD_SPLIT_B : simd == 2 ? PE_SIMD_SPLIT_C : 16;
             sg_begin = wg_begin + (len * lo16 + 8) / 16;
             sg_end = wg_begin + (len * hi16 + 8) / 16;
         }

@@ -52,9 +52,12 @@ def test_create_argument_validation_without_gpu():
     with pytest.raises(ValueError):
         _lib.HipEngine(pr, w, n_streams=0)
     bad = pr.copy()
-    bad.__dict__['n_fft'] = 300                     # (any power of two from 64 to 2048 has a kernel)
+    bad.__dict__['n_fft'] = 1500                    # (powers of two from 64 to 2048 and any other length from 16 to 1024 have kernels)
     with pytest.raises((NotImplementedError, ValueError)):
-        _lib.HipEngine(bad, w, n_streams=1, mel_filters=np.zeros((20, 151)))
+        _lib.HipEngine(bad, w, n_streams=1, mel_filters=np.zeros((20, 751)))
+    bad.__dict__['n_fft'] = 12
+    with pytest.raises((NotImplementedError, ValueError)):
+        _lib.HipEngine(bad, w, n_streams=1, mel_filters=np.zeros((20, 7)))
     bad.__dict__['n_fft'] = 4096
     with pytest.raises((NotImplementedError, ValueError)):
         _lib.HipEngine(bad, w, n_streams=1, mel_filters=np.zeros((20, 2049)))

@@ -513,6 +513,11 @@ GENERAL_PARAMS = [
     dict(n_fft=512, n_filt=80, n_mfcc=32),                                    # stock transform, more filters / coefficients than the wave kernel holds
     dict(n_fft=1024, n_filt=128, n_mfcc=16, window_t=0.05, hop_t=0.02, buffer_t=1.0),
     dict(n_fft=512, n_filt=64, n_mfcc=13),                                    # sonopy bank whose runs need more than 64 lanes
+    # n_fft that is NOT a power of two (np.fft.rfft takes any length, vectorization.py:36-39): Bluestein's chirp-z transform
+    dict(n_fft=400, n_filt=26, n_mfcc=13),                                    # 25 ms at 16 kHz: crop of the 1600-sample window
+    dict(n_fft=1000, n_filt=40, n_mfcc=20),                                   # even, 2 N - 1 just below 2048
+    dict(n_fft=399, n_filt=20, n_mfcc=13),                                    # odd length: 200 bins
+    dict(n_fft=96, n_filt=10, n_mfcc=8, window_t=0.005, hop_t=0.0025, buffer_t=0.2),     # window (80) < n_fft: zero-padded frames
 ]
 
 
@@ -548,7 +553,7 @@ def test_general_listener_params_offline(kw):
     eng.close()
 
 
-@pytest.mark.parametrize('kw', GENERAL_PARAMS[:5], ids=lambda kw: 'fft%d_filt%d_mfcc%d' % (kw['n_fft'], kw['n_filt'], kw['n_mfcc']))
+@pytest.mark.parametrize('kw', GENERAL_PARAMS[:5] + GENERAL_PARAMS[6:9], ids=lambda kw: 'fft%d_filt%d_mfcc%d' % (kw['n_fft'], kw['n_filt'], kw['n_mfcc']))
 @pytest.mark.parametrize('chunk', [1024, 777])
 def test_general_listener_params_streaming(kw, chunk):
     """The same parameter sets through Listener.update's state machine (network_runner.py:125-153): leftover samples,
