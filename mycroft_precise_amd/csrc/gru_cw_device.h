@@ -340,7 +340,8 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
     constexpr bool PC_PINNED = !VF && (VAR & 4) != 0;     // candidate chain and its partial sums interleaved instruction by instruction
     constexpr bool HAND = !VF && (VAR & 8) != 0;          // R's whole timestep as one pinned sequence
     constexpr bool EARLY = !VF && (VAR & 16) != 0 && !C4_ON_Z2 && !HAND;     // R's mailbox reads issued before the barrier, tag-validated
-    static_assert(!(C4_ON_Z2 || EARLY) || CwBox::END2 <= CwLds::XR, "variant bits 1 and 4 need -DPE_CW_BIG_BOX");
+    constexpr bool NOBAR = !VF && (VAR & 32) != 0 && !C4_ON_Z2 && !HAND && !EARLY;   // no s_barrier in the time loop: every hand-off tag-polled
+    static_assert(!(C4_ON_Z2 || EARLY || NOBAR) || CwBox::END2 <= CwLds::XR, "variant bits 1, 4 and 5 need -DPE_CW_BIG_BOX");
     const int g = lane >> 4, j = lane & 15;
     const long long stream = (long long)tile * kTileStreams + j;
     const bool valid = stream < a.n_streams;
@@ -385,7 +386,7 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
     const lds_vint TAGH = (lds_vint)(S + CwBox::TAGH);
     // a helper's "data of step t are in my mailboxes" mark, stored behind the data (DS operations of a wave execute in order)
     auto helper_tag = [&](const int who, const int value) {
-        if (EARLY) {
+        if (EARLY || NOBAR) {
             asm volatile("" ::: "memory");
             if (lane == 0) TAGH[who] = value;
         }
@@ -464,7 +465,7 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
         for (int rho = 0; rho < 5; ++rho) h[rho] = 0.f;
         *reinterpret_cast<f32x4*>(L4 + CwBox::SH4) = f32x4{0.f, 0.f, 0.f, 0.f};
         L1[CwBox::SH1] = 0.f;
-        if (lane == 0) { *TAG = 0; if (C4_ON_Z2) *TAG2 = 0; if (EARLY) { TAGH[0] = 0; TAGH[1] = 0; TAGH[2] = 0; } }
+        if (lane == 0) { *TAG = 0; if (C4_ON_Z2) *TAG2 = 0; if (EARLY || NOBAR) { TAGH[0] = 0; TAGH[1] = 0; TAGH[2] = 0; } }
 #pragma unroll
         for (int rho = 0; rho < 5; ++rho) { cw_pin(wrX[rho]); cw_pin(wrC[rho]); cw_pin(wd[rho]); }
         pin_v(wfr, wvr);
@@ -606,9 +607,20 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
                 read_boxes();
             }
             if (t == 10) PE_GT(4);
-            cw_barrier();                                                   // B(t): z(t) and the inits of step t + 1 are in LDS
+            if (NOBAR) {
+                // no barrier: spin on the helpers' tags (normally already there), the data read behind them in the same pass
+                // (>=: P may legally be one timestep ahead -- its inits are parity-buffered; the spin is bounded so that a
+                //  protocol slip shows up as a wrong result in the harness, not as a hung GPU)
+                for (int spin = 0; spin < (1 << 22); ++spin) {
+                    tg0 = TAGH[0]; tg1 = TAGH[1]; tg2 = TAGH[2];
+                    read_boxes();
+                    if (!__builtin_amdgcn_readfirstlane((tg0 < t + 1) | (tg1 < t + 1) | (tg2 < t + 1))) break;
+                }
+            } else {
+                cw_barrier();                                               // B(t): z(t) and the inits of step t + 1 are in LDS
+            }
             if (t == 10) PE_GT(5);
-            if (!EARLY || __builtin_amdgcn_readfirstlane((tg0 != t + 1) | (tg1 != t + 1) | (tg2 != t + 1))) read_boxes();
+            if (!NOBAR && (!EARLY || __builtin_amdgcn_readfirstlane((tg0 != t + 1) | (tg1 != t + 1) | (tg2 != t + 1)))) read_boxes();
             if (C4_ON_Z2) c4 = L1[CwBox::SC1];
             f32x4 hn;
 #pragma unroll
@@ -662,7 +674,7 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
             for (int q = 0; q < 4; ++q) z[q] = hard_sigmoid(accZ[q]);
             *reinterpret_cast<f32x4*>(L4 + CwBox::SZ4) = z;
             helper_tag(0, t + 1);
-            cw_barrier();                                                   // B(t)
+            if (!NOBAR) cw_barrier();                                       // B(t)  (NOBAR: the next z is not written before R published h(t + 1), i.e. after it read this one)
             accZ = nZ;
             if (C4_ON_Z2) zi = L1[CwBox::PZ + ((t + 1) & 1) * 64];
         }
@@ -716,7 +728,7 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
                 wait_h(t, h);
                 L1[CwBox::SZ1] = hard_sigmoid(zi + v_sum4(partials(wfz, wvz, h)));
                 helper_tag(1, t + 1);
-                cw_barrier();                                               // B(t)
+                if (!NOBAR) cw_barrier();                                   // B(t)
                 zi = v[0];
             }
         }
@@ -752,7 +764,13 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
             *reinterpret_cast<f32x4*>(L4 + CwBox::PC + nb * 256) = p1;
             xn = x_row(t + 2);
             helper_tag(2, t + 1);
-            cw_barrier();                                                   // B(t)
+            if (NOBAR) {
+                // pacing without the barrier: the parity buffer written next (inits of step t + 2) still holds the inits of step
+                // t, which R reads at the end of step t - 1, before it publishes h(t): wait for that tag
+                for (int spin = 0; spin < (1 << 22) && __builtin_amdgcn_readfirstlane(*TAG) < t; ++spin) { }
+            } else {
+                cw_barrier();                                               // B(t)
+            }
         }
     }
 }

@@ -39,6 +39,7 @@ template <class Tv> static Tv* upload(const std::vector<Tv>& v) {
 }
 
 int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IOLBF, 0);      // (a variant that hangs must not take the lines before it along)
     const int n_streams = argc > 1 ? atoi(argv[1]) : 4096, tiles = (n_streams + 15) / 16;
     std::vector<float> kernel((size_t)F * 3 * H), rec((size_t)H * 3 * H), bias(3 * H), wdv(H);
     srand(7);
@@ -124,6 +125,7 @@ int main(int argc, char** argv) {
             else if (which == 10) hipLaunchKernelGGL((k_cw<false, 8>), dim3(tiles), dim3(256), cw_lds, 0, a);
             else if (which == 11) hipLaunchKernelGGL((k_cw<false, 21>), dim3(tiles), dim3(256), cw_lds, 0, a);
             else if (which == 12) hipLaunchKernelGGL((k_cw<false, 20>), dim3(tiles), dim3(256), cw_lds, 0, a);
+            else if (which == 13) hipLaunchKernelGGL((k_cw<false, 37>), dim3(tiles), dim3(256), cw_lds, 0, a);
             else if (which == 2) hipLaunchKernelGGL(k_one, dim3(tiles), dim3(64), 0, 0, a);
             else if (which == 3) hipLaunchKernelGGL(k_v, dim3(tiles), dim3(64), 0, 0, a);
         };
@@ -174,6 +176,7 @@ int main(int argc, char** argv) {
     run("cw_var8", 10);      // R's whole timestep hand-scheduled
     run("cw_var21", 11);     // var5 + R's mailbox reads before the barrier (tag-validated)
     run("cw_var20", 12);     // var4 + the same
+    run("cw_var37", 13);     // var5 without the s_barrier of a timestep: every hand-off tag-polled
     for (size_t k = 1; k < outs.size(); ++k) {
         int diff = 0; double md = 0;
         const int base = k != 3 ? 1 : 0;      // the re-tiled shapes among themselves, the old ones among themselves
