@@ -64,7 +64,15 @@ typedef struct pe_params {
                                 network_runner.py:102,137);  1 = float32 front end        */
     int32_t gru_precision;   /* 0 = float32 matrix cores (reference precision, tol 1e-4);
                                 1 = bf16 operands / float32 accumulate (BASELINE configs[4],
-                                tol 1e-2)                                                    */
+                                tol 1e-2);
+                                2 = float32 precision on the bf16 matrix pipe: every operand as
+                                three bf16 pieces that add up to the float32 value exactly, six
+                                piece products per multiplication, float32 accumulate and state
+                                (tol 1e-4, measured at the float32 kernels' distance to a float64
+                                evaluation); <= 20 units, <= 15 inputs, no use_delta.  On gfx950 the
+                                f32-input MFMAs run at the vector rate and block their SIMD, the
+                                bf16 ones do not: the form for engines that fill the machine
+                                (gru_x3_device.h)                                              */
     int32_t vectorizer;      /* params.py:121-132: 2 = mfccs (sonopy, the default; also serves the
                                 offline mels entry), 3 = speechpy_mfccs (legacy .params files without
                                 a `vectorizer` key, params.py:147,155): one frame fewer per buffer
@@ -216,7 +224,8 @@ int pe_get_stream_state(pe_engine* e, int32_t* q_out, uint32_t* computed_out, ui
 
 /* Kernel sequencing of pe_update*: 1 (default) = when chunk_samples <= window - min(window,
  * n_fft) -- no frame computed by an update can become visible in the same update -- the MFCC
- * and network roles run concurrently inside ONE launch; 0 = always two dependent launches. */
+ * and network roles run concurrently inside ONE launch (networks with a fused instantiation:
+ * gru_precision 0 / 1 on the stock front-end shape); 0 = always two dependent launches. */
 int pe_set_fused(pe_engine* e, int32_t enabled);
 
 /* Input projections: 1 = the MFCC stage stores x.W + b of every frame beside its feature row (256 bytes per frame and

@@ -161,7 +161,7 @@ class HipEngine:
             vec = Vectorizer.mfccs
         p = PeParams(params.sample_rate, params.window_samples, params.hop_samples, params.n_fft,
                      params.n_filt, params.n_mfcc, params.n_features, int(bool(params.use_delta)), prec,
-                     {'f32': 0, 'bf16': 1}[gru_precision], vec, {'f32': 0, 'bf16': 1}[ring_precision])
+                     {'f32': 0, 'bf16': 1, 'x3': 2}[gru_precision], vec, {'f32': 0, 'bf16': 1}[ring_precision])
         if mel_filters is None:
             bank = speechpy_filterbank if vec == Vectorizer.speechpy_mfccs else mel_filterbank
             mel_filters = bank(params.sample_rate, params.n_filt, params.n_fft // 2 + 1)

@@ -82,6 +82,8 @@ struct pe_engine {
     float* wide_wd = nullptr;
     // bf16-operand network (pe_params.gru_precision = 1)
     uint16_t* wx_bf16 = nullptr; uint16_t* wr_bf16 = nullptr; float* wd_bf16 = nullptr;
+    // float32 network as three bf16 pieces per operand on the XDL pipe (pe_params.gru_precision = 2; gru_x3_device.h)
+    uint32_t* x3_blob = nullptr;
     // on-device ThresholdDecoder / TriggerDetector (pe_set_decoder / pe_set_trigger)
     double* cd = nullptr; int cd_len = 0, dec_min_out = 0, dec_out_range = 0; double dec_center = 0.5;
     int32_t* activation = nullptr; double trig_threshold = 0.5; int trig_level = 3, trig_rearm = -8; bool trig_on = false;
@@ -405,6 +407,70 @@ int pack_gru_weights_bf16(pe_engine* e, const pe_gru_layer& L, const float* dens
     return PE_OK;
 }
 
+// Float32 network on the XDL pipe (gru_x3_device.h): every weight as three bf16 pieces (round to nearest even of the
+// running remainder; hi + mid + lo == the float32 weight exactly), arranged as the A operands of
+// v_mfma_f32_16x16x32_bf16: lane (row i = lane & 15, k-group gk = lane >> 4) holds k = 8 gk .. 8 gk + 7.
+// Output tiles 0..2 = z / r / candidate of units 0..15 (row i <-> unit i), tile 3 row 4 g + q = gate q of unit 16 + g.
+// k-group gk carries the source units 4 gk .. 4 gk + 3 (operands 0..2) and 16 + gk (operand 3) -- the units whose
+// values lane group gk owns -- and, on the input side, features 4 gk .. 4 gk + 3 with the bias as pseudo-feature F.
+void split3_bf16(float v, uint16_t (&piece)[3]) {
+    for (int i = 0; i < 3; ++i) {
+        piece[i] = to_bf16(v);
+        const uint32_t b = (uint32_t)piece[i] << 16;
+        float f;
+        std::memcpy(&f, &b, 4);
+        v -= f;                      // exact
+    }
+}
+
+int pack_gru_weights_x3(pe_engine* e, const pe_gru_layer& L, const float* dense_kernel) {
+    const int H = L.units, F = L.n_in;
+    if (e->prm.use_delta || H > 20 || F > 15)
+        return fail(e, PE_ERR_UNSUPPORTED, "gru_precision = 2 (float32 as three bf16 pieces on the XDL pipe) takes <= 20 units, <= 15 inputs, no use_delta (got %d units, %d inputs)", H, F);
+    std::vector<uint32_t> blob((size_t)kX3BlobBytes / 4, 0u);
+    uint16_t* const half = reinterpret_cast<uint16_t*>(blob.data());
+    auto gate_col = [&](int tile, int i, int* col) -> bool {     // A row i of an output tile -> column of the Keras matrices
+        int gate, unit;
+        if (tile < 3) { gate = tile; unit = i; }
+        else { gate = i & 3; unit = 16 + (i >> 2); if (gate == 3) return false; }
+        if (unit >= H) return false;
+        *col = gate * H + unit;
+        return true;
+    };
+    static const int kPiece3[8] = {0, 0, 1, 1, 0, 2, -1, -1};     // operand 3: [hi, hi, mid, mid, hi, lo, -, -]
+    for (int tile = 0; tile < kX3Tiles; ++tile)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, gk = lane >> 4;
+            int col;
+            if (!gate_col(tile, i, &col)) continue;
+            for (int m = 0; m < kX3RecOps; ++m)
+                for (int ek = 0; ek < 8; ++ek) {
+                    const int src = m < 3 ? 4 * gk + (ek & 3) : 16 + gk;
+                    const int piece = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? (ek < 4 ? 0 : 2) : kPiece3[ek];
+                    if (src >= H || piece < 0) continue;
+                    uint16_t pc[3];
+                    split3_bf16(L.recurrent_kernel[(size_t)src * 3 * H + col], pc);
+                    half[((size_t)(kX3ArOff + (tile * kX3RecOps + m) * 64 + lane)) * 8 + ek] = pc[piece];
+                }
+            for (int m = 0; m < kX3InOps; ++m)
+                for (int ek = 0; ek < 8; ++ek) {
+                    const int f = 4 * gk + (ek & 3);
+                    const int piece = m == 0 ? 0 : m == 1 ? 1 : (ek < 4 ? 0 : 2);
+                    if (f > F) continue;
+                    uint16_t pc[3];
+                    split3_bf16(f < F ? L.kernel[(size_t)f * 3 * H + col] : L.bias[col], pc);
+                    half[((size_t)(kX3AxOff + (tile * kX3InOps + m) * 64 + lane)) * 8 + ek] = pc[piece];
+                }
+        }
+    float* const wd = reinterpret_cast<float*>(blob.data()) + (size_t)kX3WdOff * 4;
+    for (int o = 0; o < 5; ++o)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int u = o < 4 ? 4 * (lane >> 4) + o : 16 + (lane >> 4);
+            if (u < H) wd[o * 64 + lane] = dense_kernel[u];
+        }
+    return dev_upload(e, &e->x3_blob, blob);
+}
+
 // Wide / stacked network (gru_wide_device.h): wave w owns output tiles tau = w TPW + t of every gate;
 // row i of a tile <-> unit 16 tau + 4 (i & 3) + (i >> 2); k-step rho, k-slot gk <-> source unit 4 rho + gk
 // (layer 0 input: k-step kk <-> feature 4 gk + kk).  Streams: [wave][k-group][tile][lane] float4.
@@ -572,6 +638,7 @@ GruArgs gru_args(const pe_engine* e) {
     a.frame_len = frame_len_of(e->prm);
     a.bf16 = e->prm.gru_precision == 1;
     a.wx_bf16 = e->wx_bf16; a.wr_bf16 = e->wr_bf16; a.wd_bf16 = e->wd_bf16;
+    a.x3 = e->prm.gru_precision == 2 ? e->x3_blob : nullptr;
     a.feats = nullptr; a.out = nullptr; a.row_stride = 0;
     a.row_floats = e->row_floats;
     // Four waves per tile cut the latency of a tile's chain; that only pays while every tile gets a CU of its
@@ -584,7 +651,7 @@ GruArgs gru_args(const pe_engine* e) {
     // regime (two-pass MFMAs + reductions: 81.0 vs 77.3 us at 65 536 streams), so an engine takes ONE tiling for all
     // of its launches -- every shape of a tiling agrees bit for bit -- by its size.  The critical-wave kernel still
     // wins with two tiles per compute unit (8192 streams, fused: 272 vs 254 M windows/s against one wave per tile).
-    const bool cw_ok = e->cw_blob && e->row_floats == kRowFloats && !a.proj_ring && !a.bf16 && !e->wide && e->gru_waves != 16;
+    const bool cw_ok = e->cw_blob && e->row_floats == kRowFloats && !a.proj_ring && !a.bf16 && !a.x3 && !e->wide && e->gru_waves != 16;
     const bool retile = cw_ok && (e->gru_tiling == 1 || (e->gru_tiling < 0 && e->n_tiles <= 2 * e->n_cus));
     const int auto_waves = retile ? (e->n_tiles <= 2 * e->n_cus ? 4 : 1) : (e->n_tiles <= e->n_cus ? 4 : 1);
     a.waves_per_tile = e->gru_waves ? e->gru_waves : auto_waves;      // (16 = DPP kernel: opt-in)
@@ -645,6 +712,10 @@ bool can_fuse(const pe_engine* e, int chunk) {
     //  so do networks of 21..32 units on the one-wave kernel: their register-resident weights do not fit beside the
     //  frame role's 128-register budget -- fused, that shape spilled 96-240 bytes per lane into the time loop)
     if (!(e->fused && !e->general && !e->wide && e->table_layout.mel_pad == 10 && chunk <= emit_window(e->prm) - frame_len_of(e->prm))) return false;
+    // (gru_x3_device.h: ~220 registers per lane against the frame role's ~100, and one kernel has one budget.  The same
+    //  concurrency as TWO kernels -- the network on a side stream between two events -- was built and measured: 142 vs
+    //  134 us per update at 65 536 streams, 40 vs 24 us at 4096: the event hand-offs cost more than the overlap buys)
+    if (e->prm.gru_precision == 2) return false;
     if (e->prm.gru_precision == 0 && gru_small_regs(e->units) >= 6 && gru_args(e).waves_per_tile != 4) return false;
     if (e->prm.use_delta && e->prm.gru_precision == 0) {        // re-tiled one-wave shape with delta inputs: no fused instantiation
         // (waves_per_tile == 4 is not enough: the four-wave shape needs the 32-slot ring it stages in LDS -- after
@@ -711,7 +782,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     if (p->hop_samples < 1 || p->window_samples < 1 || p->n_features < 1)
         return fail(nullptr, PE_ERR_INVALID, "window/hop/n_features must be positive");
     if (p->mfcc_precision != 0 && p->mfcc_precision != 1) return fail(nullptr, PE_ERR_INVALID, "mfcc_precision must be 0 (f64) or 1 (f32)");
-    if (p->gru_precision != 0 && p->gru_precision != 1) return fail(nullptr, PE_ERR_INVALID, "gru_precision must be 0 (f32) or 1 (bf16 operands)");
+    if (p->gru_precision < 0 || p->gru_precision > 2) return fail(nullptr, PE_ERR_INVALID, "gru_precision must be 0 (f32 MFMA), 1 (bf16 operands) or 2 (f32 as three bf16 pieces per operand on the XDL pipe)");
     if (p->vectorizer != 0 && p->vectorizer != 2 && p->vectorizer != 3)
         return fail(nullptr, PE_ERR_UNSUPPORTED, "vectorizer must be 2 (mfccs) or 3 (speechpy_mfccs); Vectorizer.mels (1) exists in the offline form only (pe_vectorize_mels), got %d", p->vectorizer);
     if (p->ring_precision != 0 && p->ring_precision != 1) return fail(nullptr, PE_ERR_INVALID, "ring_precision must be 0 (f32 rows) or 1 (bf16 rows)");
@@ -818,6 +889,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         }
         else if ((rc = pack_gru_weights(e, L, w->dense_kernel))) break;
         if (p->gru_precision == 1 && (rc = pack_gru_weights_bf16(e, L, w->dense_kernel))) break;
+        if (p->gru_precision == 2 && (rc = pack_gru_weights_x3(e, L, w->dense_kernel))) break;
         // the projection rows exist for the stock-width float32 network (3 R <= 16 slots: 4 output tiles, R = 5) fed
         // from the ring; they pay while the ring stays cache-resident (256 B per frame and stream)
         e->proj_ok = !wide && p->gru_precision == 0 && !p->use_delta && gru_small_regs(L.units) == 5 && !e->proj_w_host.empty();

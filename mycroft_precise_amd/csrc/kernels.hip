@@ -11,6 +11,7 @@
 #include "../../tools/micro/gru_pair_device.h"
 #endif
 #include "gru_bf16_device.h"
+#include "gru_x3_device.h"
 #include "gru_wide_device.h"
 #include "mfcc_general_device.h"
 
@@ -172,6 +173,21 @@ template <int MODE, bool DELTA, bool RB = false>
 __global__ __launch_bounds__(64) void gru_bf16_kernel(const GruArgs a) {
     touch_kernel_arguments<(int)sizeof(GruArgs)>();
     gru_tile_bf16<MODE, DELTA, RB>(a, blockIdx.x, threadIdx.x);
+}
+
+// ---- GRU, float32 as three bf16 pieces per operand on the XDL pipe: one wave per 16-stream tile ------------------
+template <int MODE>
+__global__ __launch_bounds__(64) void gru_x3_kernel(const GruArgs a) {
+    touch_kernel_arguments<(int)sizeof(GruArgs)>();
+    gru_tile_x3<MODE>(a, blockIdx.x, threadIdx.x);
+}
+__global__ __launch_bounds__(64) void gru_many_x3_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
+    const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
+    GruArgs b = a;
+    b.st_ke = a.st_ke + (size_t)u * n_padded;
+    b.out = a.out + (size_t)u * a.n_streams;
+    b.predict_ke = 0;
+    gru_tile_x3<kRing>(b, tile, threadIdx.x);
 }
 
 // Dispatch order of the roles of a fused launch.  Workgroups are handed to the CUs in blockIdx order; `frames_first`
@@ -501,6 +517,14 @@ static hipError_t launch_r(const GruArgs& a, int mode, hipStream_t s) {
 }
 
 hipError_t launch_gru_small(const GruArgs& a, int from_ring, hipStream_t s) {
+    if (a.x3) {
+        const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
+        if (tiles == 0) return hipSuccess;
+        if (from_ring == kRing) hipLaunchKernelGGL(gru_x3_kernel<kRing>, dim3(tiles), dim3(64), 0, s, a);
+        else if (from_ring == kRows) hipLaunchKernelGGL(gru_x3_kernel<kRows>, dim3(tiles), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(gru_x3_kernel<kFeats>, dim3(tiles), dim3(64), 0, s, a);
+        return hipGetLastError();
+    }
     if (a.bf16) {
         const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
         if (tiles == 0) return hipSuccess;
@@ -564,6 +588,10 @@ static hipError_t launch_many_r(const GruArgs& a, int n_updates, int n_padded, h
 hipError_t launch_gru_many(const GruArgs& a, int n_updates, int n_padded, hipStream_t s) {
     const int tiles = (a.n_streams + kTileStreams - 1) / kTileStreams;
     if (tiles == 0 || n_updates == 0) return hipSuccess;
+    if (a.x3) {
+        hipLaunchKernelGGL(gru_many_x3_kernel, dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
+        return hipGetLastError();
+    }
     if (a.bf16) {
         if (a.use_delta && a.ring_bf16) hipLaunchKernelGGL((gru_many_bf16_kernel<true, true>), dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
         else if (a.use_delta) hipLaunchKernelGGL((gru_many_bf16_kernel<true, false>), dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);

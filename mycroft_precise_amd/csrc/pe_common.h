@@ -104,6 +104,15 @@ struct MfccOfflineArgs {
 // ---------------------------------------------------------------------------------------
 // GRU + Dense head (model.py:76-82), register-resident weights, one wave per 16-stream tile
 // ---------------------------------------------------------------------------------------
+// gru_x3_device.h: packed operands of the float32 network on the XDL pipe (pe_params.gru_precision = 2)
+constexpr int kX3Tiles = 4;                 // TZ, TR, TC, TQ
+constexpr int kX3RecOps = 4, kX3InOps = 3;   // A operands per output tile: recurrent, input
+// blob (uint4 = 8 bf16 per lane): [AR: tile][m][lane] | [AX: tile][m][lane] | float wd[5][lane]
+constexpr int kX3ArOff = 0;
+constexpr int kX3AxOff = kX3Tiles * kX3RecOps * 64;                  // in uint4
+constexpr int kX3WdOff = kX3AxOff + kX3Tiles * kX3InOps * 64;        // in uint4 (floats follow)
+constexpr int kX3BlobBytes = kX3WdOff * 16 + 5 * 64 * 4;
+
 struct GruArgs {
     int n_streams;
     int n_features;         // T
@@ -130,6 +139,9 @@ struct GruArgs {
     const void* wx_bf16;    // [6][64] x 8 bf16    input kernel, k = 8 g + e <-> feature; k = 30, 31: bias hi, lo
     const void* wr_bf16;    // [6][64] x 8 bf16    recurrent kernel, k = 8 g + e <-> unit
     const float* wd_bf16;   // [8][64]
+    // float32 network on the XDL pipe, operands as three bf16 pieces (gru_x3_device.h; pe_params.gru_precision = 2):
+    // non-null = the launchers take gru_tile_x3 for every input mode
+    const void* x3;         // [4 tiles][4][64] + [4 tiles][3][64] uint4 of 8 bf16, then float wd[5][64]
     // input: either the feature ring (+ per-stream emitted-frame counters) ...
     const float* ring;
     int ring_bf16;          // rows hold 16 bf16 (32 bytes) instead of 16 floats: bf16-operand kernel only
