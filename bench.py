@@ -254,7 +254,8 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
     the oracle (the checker: never inside a timed region) on the first 8 streams.
     params_kw: ListenerParams overrides (n_fft / n_filt / n_mfcc ...: the general front end, params.py:28-118).
     roofline_kind: 'hbm' (fused launch vs HBM), 'mfma' (network launch vs fp32 MFMA), 'mfma_fused' (fused launch vs fp32
-    MFMA: the capacity point, where the update IS the network + MFCC roles of one launch), 'hbm_mfcc' (MFCC launch vs HBM)."""
+    MFMA: the capacity point, where the update IS the network + MFCC roles of one launch), 'mfma_update_x3' (the same for
+    gru_precision='x3', whose update is two launches), 'hbm_mfcc' (MFCC launch vs HBM)."""
     import warnings
     from oracle import listener as oracle_listener
     hpr, opr = pr, None
@@ -325,10 +326,12 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
                 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
                 'avg_launch_ms': ms, 'algorithmic': '%.1f B/window x %d windows/launch' % (bytes_per_window, streams)}
     else:
-        fused = roofline_kind == 'mfma_fused'
+        fused = roofline_kind in ('mfma_fused', 'mfma_update_x3')
         ms = update_ms if fused else gru_ms
         ach = flop_per_window * streams / (ms * 1e-3) / 1e12
-        kern = ('fused_update_kernel<%s, ShapeStock, 5, false, false, false> (network || MFCC || bookkeeping roles)' % mfcc_name if fused
+        kern = ('mfcc_kernel<%s, ShapeStock, true> then gru_x3_kernel<1> (two dependent launches; the float32 products are formed on the bf16 '
+                'matrix pipe, priced here against the fp32 MFMA peak like the other float32 lines)' % mfcc_name if roofline_kind == 'mfma_update_x3'
+                else 'fused_update_kernel<%s, ShapeStock, 5, false, false, false> (network || MFCC || bookkeeping roles)' % mfcc_name if fused
                 else ('gru_wide_kernel<%d, 1, 4>' % ((units[0] + 63) // 64) if not stock else 'network launch'))
         roof = {'kernel': kern, 'bound': 'mfma',
                 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
@@ -355,7 +358,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=40)
     ap.add_argument('--streams', type=int, default=4096, help='streams per GPU')
     ap.add_argument('--mfcc-precision', choices=['f64', 'f32'], default='f64')
-    ap.add_argument('--gru-precision', choices=['f32', 'bf16'], default='f32',
+    ap.add_argument('--gru-precision', choices=['f32', 'bf16', 'x3'], default='f32',
                     help="bf16 = BASELINE configs[4] arithmetic (bf16 MFMA operands, tol 1e-2); not the headline")
     ap.add_argument('--ring-precision', choices=['f32', 'bf16'], default='f32',
                     help="bf16 = 32-byte bf16 feature rows (BASELINE configs[4]: bf16 MFCC+GRU); needs --gru-precision bf16")
@@ -539,6 +542,11 @@ def main():
                     dict(name='capacity: stock GRU fp32 + f64 MFCC, batch=65536 streams on 1 MI355X (max concurrent real-time streams)', units=(20,), streams=65536,
                          mfcc_precision='f64', gru_precision='f32', ring_precision='f32', steps=100, warmup=40, n_res=32, tol=1e-4,
                          roofline_kind='mfma_fused'),
+                    # ... and the same arithmetic precision with the gate matmuls on the XDL pipe (gru_precision = 'x3':
+                    # every float32 operand as three bf16 pieces, gru_x3_device.h): the f32-input MFMAs block their SIMD
+                    dict(name='capacity (x3): stock GRU fp32 as 3 x bf16 pieces on the XDL pipe + f64 MFCC, batch=65536 streams on 1 MI355X', units=(20,), streams=65536,
+                         mfcc_precision='f64', gru_precision='x3', ring_precision='f32', steps=100, warmup=40, n_res=32, tol=1e-4,
+                         roofline_kind='mfma_update_x3'),
                     # a non-stock .params file (params.py:28-118): the general front end (mfcc_general_device.h)
                     dict(name='general front end: n_fft=1024, n_filt=40, n_mfcc=20 (non-stock ListenerParams), stock-width GRU fp32, batch=4096 streams', units=(20,), streams=4096,
                          mfcc_precision='f64', gru_precision='f32', ring_precision='f32', steps=100, warmup=40, n_res=64, tol=1e-4,
@@ -572,7 +580,7 @@ def main():
             return MFCC_BYTES_PER_WINDOW * B / (ms * 1e-3) / 1e9
 
         mfcc_name = 'double' if args.mfcc_precision == 'f64' else 'float'
-        mfma_peak = MFMA_F32_PEAK_TFLOPS if args.gru_precision == 'f32' else MFMA_BF16_PEAK_TFLOPS
+        mfma_peak = MFMA_F32_PEAK_TFLOPS if args.gru_precision in ('f32', 'x3') else MFMA_BF16_PEAK_TFLOPS      # (x3: float32 products on the bf16 pipe, priced as float32)
         # the engine's own rule (engine.hip: gru_args): stock width re-tiled while tiles <= 2 x CUs (or forced), four waves per
         # tile while tiles <= 2 x CUs on the re-tiled shapes / <= CUs on the classic tiling (or forced)
         n_cus = torch.cuda.get_device_properties(device).multi_processor_count
@@ -585,6 +593,9 @@ def main():
         gru_name = ((('gru_cw_kernel' if retiled else 'gru_mw_kernel<5, false>') if four_waves else
                      ('gru_v_kernel<1>' if retiled else 'gru_small_kernel<5, 1, false>')) if args.gru_precision == 'f32'
                     else 'gru_bf16_kernel<1>')
+        if args.gru_precision == 'x3':
+            fused_name = '%s then gru_x3_kernel<1> (two dependent launches)' % mfcc_kernel
+            gru_name = 'gru_x3_kernel<1>'
         if not stock:
             fused_name = '%s + gru_wide_kernel<%d, 1, 4>' % (mfcc_kernel, (units[0] + 63) // 64)
             gru_name = 'gru_wide_kernel<%d, 1, 4>' % ((units[0] + 63) // 64)
@@ -609,7 +620,7 @@ def main():
                                       'stock' if stock else 'wide %s' % 'x'.join(map(str, units)), args.gru_precision, B,
                                       ' (batch=%d streams sharded across %d x MI355X, RCCL gather over xGMI)' % (n_global, world) if world > 1 else ''),
                        'streams_per_gpu': B, 'global_streams': n_global, 'chunk_samples': CHUNK,
-                       'gru': 'H=%s, T=29, F=13, ' % args.units + ('f32 MFMA 16x16x4' if args.gru_precision == 'f32' else 'bf16 MFMA 16x16x32, f32 accumulate'),
+                       'gru': 'H=%s, T=29, F=13, ' % args.units + ('f32 MFMA 16x16x4' if args.gru_precision == 'f32' else 'f32 operands as 3 x bf16 pieces, 6 piece products on bf16 MFMA 16x16x32, f32 accumulate / gates / state' if args.gru_precision == 'x3' else 'bf16 MFMA 16x16x32, f32 accumulate'),
                        'mfcc_dtype': args.mfcc_precision, 'feature_rows': args.ring_precision,
                        'parallelism': 'streams sharded over %d rank(s), final RCCL gather of probabilities to rank 0' % world},
             'realtime_streams': value / REALTIME_WINDOWS_PER_S,
@@ -645,7 +656,7 @@ def main():
         try:     # spin / streaming microbenchmarks of the same pool ("also report against measured peaks")
             with open(os.path.join(REPO, 'profiles', 'measured_peaks.json')) as f:
                 mp = json.load(f)
-            m_mfma = mp['mfma_f32_16x16x4_tflops'] if args.gru_precision == 'f32' else mp['mfma_bf16_16x16x32_tflops']
+            m_mfma = mp['mfma_f32_16x16x4_tflops'] if args.gru_precision in ('f32', 'x3') else mp['mfma_bf16_16x16x32_tflops']
             line['measured_peaks'] = {'mfma_tflops': m_mfma, 'hbm_read_gbs': mp['hbm_read_gbs'], 'source': 'profiles/measured_peaks.json',
                                       'roofline_frac': line['roofline']['achieved'] / (mp['hbm_read_gbs'] if hbm_bound else m_mfma),
                                       'roofline_gru_frac': line['roofline_gru']['achieved'] / m_mfma,

@@ -1151,6 +1151,93 @@ def _full_size_run(weights, B, n_up, n_check, tol, guard_equal_positions=True, o
     return hip, base, owner, first
 
 
+# ---- gru_precision = 'x3': the float32 network on the bf16 matrix pipe (gru_x3_device.h) ----------------------------
+def test_x3_network_matches_oracle_at_the_float32_guard(stock_weights):
+    """Every operand as three bf16 pieces (hi + mid + lo == the float32 value exactly), six piece products per
+    multiplication, float32 accumulate / gates / state: the float32 kernels' guard against the float32 oracle, and a
+    distance to a FLOAT64 evaluation of the same windows that is the float32 kernels' (not a reduced-precision mode)."""
+    from mycroft_precise_amd._lib import HipEngine
+    kinds = (['tone_noise'] * 30) + ['zeros', 'square', 'square', 'quiet', 'quiet', 'zeros', 'tone_noise']
+    n_up = 40
+    pcm = _stream_batch(kinds, n_up)
+    x3 = HipEngine(P.pr, stock_weights, n_streams=len(kinds), gru_precision='x3')
+    f32 = HipEngine(P.pr, stock_weights, n_streams=len(kinds))
+    assert x3.info().gru_precision == 2
+    ref = ol.BatchedOracle(stock_weights, len(kinds))
+    d64 = {'x3': 0.0, 'f32': 0.0}
+    for u in range(n_up):
+        px, pf = x3.update(pcm[u]), f32.update(pcm[u])
+        want = ref.update_raw(pcm[u])
+        assert np.abs(px.astype(np.float64) - want).max() <= GUARD_RAW, u
+        feats = x3.get_vectors()
+        assert np.array_equal(feats, f32.get_vectors())
+        p64 = keras_gru.predict(feats, stock_weights, dtype=np.float64)[:, 0]
+        d64['x3'] = max(d64['x3'], float(np.abs(px - p64).max()))
+        d64['f32'] = max(d64['f32'], float(np.abs(pf - p64).max()))
+    print('max |p - p_float64|: x3 %.3g, f32 MFMA %.3g' % (d64['x3'], d64['f32']))
+    assert d64['x3'] <= 2 * d64['f32'] + 2e-7
+    x3.close(); f32.close()
+
+
+def test_x3_every_entry_point_agrees_bitwise(stock_weights):
+    """One arithmetic for an engine's launches: pe_update == pe_update_many == pe_predict on the held windows ==
+    pe_evaluate's strided windows (kRing / kFeats / kRows modes of gru_tile_x3), ragged last tile included."""
+    from mycroft_precise_amd._lib import HipEngine
+    n, depth, chunk = 70, 6, 1024
+    kinds = ['tone_noise'] * (n - 3) + ['zeros', 'square', 'quiet']
+    pcm = _stream_batch(kinds, 36, chunk)
+    a = HipEngine(P.pr, stock_weights, n_streams=n, gru_precision='x3')
+    b = HipEngine(P.pr, stock_weights, n_streams=n, gru_precision='x3')
+    b.reserve_updates(depth, chunk)
+    for u in range(0, 36, depth):
+        want = np.stack([a.update(pcm[u + i]) for i in range(depth)])
+        assert np.array_equal(b.update_many(pcm[u:u + depth]), want), u
+        assert np.array_equal(a.predict(a.get_vectors())[:, 0], want[-1]), u
+    a.close(); b.close()
+    # offline evaluation: windows of one row sequence == the same windows as an explicit batch
+    from oracle import sonopy_restated as so
+    eng = HipEngine(P.pr, stock_weights, n_streams=1, gru_precision='x3')
+    audio = synth.stream_pcm(21, 16000 * 5).astype(np.float32) / np.float32(32768.0)
+    got = eng.evaluate(audio, 2)
+    mf = so.mfcc_spec(audio.astype(np.float64), 16000, (1600, 800), num_filt=20, fft_size=512, num_coeffs=13)
+    windows = np.stack([mf[i - 29:i] for i in range(29, len(mf), 2)]).astype(np.float32)
+    assert got.shape == (len(windows), 1)
+    assert np.abs(got - keras_gru.predict(windows, stock_weights)).max() <= GUARD_RAW
+    eng.close()
+
+
+@pytest.mark.parametrize('units,n_in', [(1, 13), (7, 5), (16, 13), (17, 15), (20, 13), (20, 1)])
+def test_x3_widths_and_input_sizes(units, n_in):
+    """Units 1..20 (three full tiles + the quarter tile, zero-padded) and 1..15 inputs (the bias rides as pseudo-feature
+    n_in); explicit batches of ragged size against the oracle."""
+    from mycroft_precise_amd._lib import HipEngine
+    w = synth.make_weights(n_in=n_in, units=(units,), seed=300 + units + n_in)
+    hpr = P.pr.copy()
+    hpr.__dict__.update(n_mfcc=n_in)
+    eng = HipEngine(hpr, w, n_streams=1, gru_precision='x3')
+    rng = np.random.default_rng(units)
+    for n in (1, 17, 50):
+        x = rng.normal(0, 2, (n, 29, n_in)).astype(np.float32)
+        x[:, :, 0] -= 20.0                      # (the log-energy coefficient is large)
+        assert np.abs(eng.predict(x) - keras_gru.predict(x, w)).max() <= GUARD_RAW
+    eng.close()
+
+
+def test_x3_refuses_what_it_has_no_kernel_for():
+    from mycroft_precise_amd._lib import HipEngine
+    for kw, w_kw in ((dict(), dict(units=(21,))), (dict(n_mfcc=16), dict(n_in=16)), (dict(use_delta=True), dict(n_in=26))):
+        hpr = P.pr.copy()
+        hpr.__dict__.update(kw)
+        with pytest.raises(NotImplementedError):
+            HipEngine(hpr, synth.make_weights(seed=1, **w_kw), n_streams=4, gru_precision='x3')
+
+
+def test_x3_capacity_batch_65536_streams_properties(stock_weights):
+    """The capacity point on the XDL pipe (bench.py extra_configs): 65536 streams, the size-independent properties and the
+    oracle on the seeded streams."""
+    _full_size_run(stock_weights, 65536, 33, 24, GUARD_RAW, gru_precision='x3')
+
+
 def test_capacity_batch_65536_streams_properties(stock_weights):
     """The capacity point of the metric (max concurrent real-time streams; bench.py extra_configs): 65536 streams, float64
     front end + float32 network on the one-wave-per-tile kernels -- the size-independent properties, and fused == two
