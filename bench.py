@@ -248,14 +248,15 @@ def wait_for_gpu():
 
 
 def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_precision, ring_precision, steps, warmup, n_res, tol,
-                 params_kw=None, roofline_kind=None):
+                 params_kw=None, roofline_kind=None, gru_tiling=-1):
     """One non-headline configuration on this GPU (N = 1 only, after the headline's timed region): the same step
     definition, its own roofline object, and a parity spot-check of the timed region's last probabilities against
     the oracle (the checker: never inside a timed region) on the first 8 streams.
     params_kw: ListenerParams overrides (n_fft / n_filt / n_mfcc ...: the general front end, params.py:28-118).
     roofline_kind: 'hbm' (fused launch vs HBM), 'mfma' (network launch vs fp32 MFMA), 'mfma_fused' (fused launch vs fp32
     MFMA: the capacity point, where the update IS the network + MFCC roles of one launch), 'mfma_update_x3' (the same for
-    gru_precision='x3', whose update is two launches), 'hbm_mfcc' (MFCC launch vs HBM)."""
+    the float32 network on the bf16 pipe, whose update is two launches), 'hbm_mfcc' (MFCC launch vs HBM).
+    gru_tiling: pe_set_gru_tiling (-1 = the engine's own choice)."""
     import warnings
     from oracle import listener as oracle_listener
     hpr, opr = pr, None
@@ -271,6 +272,9 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
         warnings.simplefilter('ignore')
         engine = HipEngine(hpr, weights, n_streams=streams, device=dev_index, mfcc_precision=mfcc_precision,
                            gru_precision=gru_precision, ring_precision=ring_precision)
+    if gru_tiling >= 0:
+        engine.set_gru_tiling(gru_tiling)
+    tiling_used = engine.gru_tiling()
     pcm = synth_pcm_device(n_res, streams, 0, device)
     out = torch.zeros((streams,), dtype=torch.float32, device=device)
     st = torch.cuda.current_stream().cuda_stream
@@ -341,6 +345,8 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
            'steps': steps, 'warmup': warmup, 'dtype': gru_precision,
            'config': {'workload': name, 'streams_per_gpu': streams, 'gru': 'H=%s' % ','.join(map(str, units)),
                       'mfcc_dtype': mfcc_precision, 'feature_rows': ring_precision,
+                      'gru_form': {-1: 'n/a', 0: 'classic tiling, v_mfma_f32_16x16x4_f32', 1: 're-tiled stock width, v_mfma_f32_16x16x4_f32',
+                                   2: 'float32 operands as 3 x bf16 pieces, 6 piece products on v_mfma_f32_16x16x32_bf16, float32 accumulate / gates / state'}[tiling_used],
                       'resident_pcm_mb': n_res * chunk_bytes / 1e6},
            'stage_ms': {'update_back_to_back': update_ms, 'mfcc_launch_alone': mfcc_ms, 'network_launch_alone': gru_ms},
            'roofline': roof,
@@ -358,12 +364,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=40)
     ap.add_argument('--streams', type=int, default=4096, help='streams per GPU')
     ap.add_argument('--mfcc-precision', choices=['f64', 'f32'], default='f64')
-    ap.add_argument('--gru-precision', choices=['f32', 'bf16', 'x3'], default='f32',
+    ap.add_argument('--gru-precision', choices=['f32', 'bf16'], default='f32',
                     help="bf16 = BASELINE configs[4] arithmetic (bf16 MFMA operands, tol 1e-2); not the headline")
     ap.add_argument('--ring-precision', choices=['f32', 'bf16'], default='f32',
                     help="bf16 = 32-byte bf16 feature rows (BASELINE configs[4]: bf16 MFCC+GRU); needs --gru-precision bf16")
     ap.add_argument('--units', default='20', help="GRU widths, e.g. 20 (stock, default) or 256,256 (BASELINE configs[3])")
-    ap.add_argument('--gru-tiling', type=int, default=-1, help='pe_set_gru_tiling: -1 automatic (default), 0 classic, 1 re-tiled stock width')
+    ap.add_argument('--gru-tiling', type=int, default=-1, help='pe_set_gru_tiling: -1 automatic (default), 0 classic, 1 re-tiled stock width, 2 float32 products on the bf16 pipe')
     ap.add_argument('--gru-waves', type=int, default=0, help='pe_set_gru_waves: 0 automatic (default), 1 or 4 waves per tile')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-configs', action='store_true', help='skip the non-headline BASELINE configurations (wide 256x2, bf16) after the headline')
@@ -538,15 +544,16 @@ def main():
                     dict(name='configs[4] on one GPU: bf16 MFCC rows + bf16 GRU (f32 front end), batch=65536 streams', units=(20,), streams=65536,
                          mfcc_precision='f32', gru_precision='bf16', ring_precision='bf16', steps=100, warmup=40, n_res=32, tol=1e-2),
                     # the metric's second half ("max concurrent real-time streams") is a large-batch figure: the stock
-                    # configuration (float64 MFCC as the reference computes it, float32 GRU) with the machine full
+                    # configuration (float64 MFCC as the reference computes it, float32 GRU) with the machine full.  At this
+                    # size the engine takes the float32 network on the bf16 matrix pipe by itself (gru_x3_device.h: every
+                    # operand as three bf16 pieces; the f32-input MFMAs keep their whole SIMD from issuing) ...
                     dict(name='capacity: stock GRU fp32 + f64 MFCC, batch=65536 streams on 1 MI355X (max concurrent real-time streams)', units=(20,), streams=65536,
                          mfcc_precision='f64', gru_precision='f32', ring_precision='f32', steps=100, warmup=40, n_res=32, tol=1e-4,
-                         roofline_kind='mfma_fused'),
-                    # ... and the same arithmetic precision with the gate matmuls on the XDL pipe (gru_precision = 'x3':
-                    # every float32 operand as three bf16 pieces, gru_x3_device.h): the f32-input MFMAs block their SIMD
-                    dict(name='capacity (x3): stock GRU fp32 as 3 x bf16 pieces on the XDL pipe + f64 MFCC, batch=65536 streams on 1 MI355X', units=(20,), streams=65536,
-                         mfcc_precision='f64', gru_precision='x3', ring_precision='f32', steps=100, warmup=40, n_res=32, tol=1e-4,
                          roofline_kind='mfma_update_x3'),
+                    # ... and the same point forced onto the f32-input MFMAs (classic tiling, fused launch) for comparison
+                    dict(name='capacity, classic tiling forced (pe_set_gru_tiling 0: v_mfma_f32_16x16x4_f32, fused launch), batch=65536 streams', units=(20,), streams=65536,
+                         mfcc_precision='f64', gru_precision='f32', ring_precision='f32', steps=100, warmup=40, n_res=32, tol=1e-4,
+                         roofline_kind='mfma_fused', gru_tiling=0),
                     # a non-stock .params file (params.py:28-118): the general front end (mfcc_general_device.h)
                     dict(name='general front end: n_fft=1024, n_filt=40, n_mfcc=20 (non-stock ListenerParams), stock-width GRU fp32, batch=4096 streams', units=(20,), streams=4096,
                          mfcc_precision='f64', gru_precision='f32', ring_precision='f32', steps=100, warmup=40, n_res=64, tol=1e-4,
@@ -580,12 +587,12 @@ def main():
             return MFCC_BYTES_PER_WINDOW * B / (ms * 1e-3) / 1e9
 
         mfcc_name = 'double' if args.mfcc_precision == 'f64' else 'float'
-        mfma_peak = MFMA_F32_PEAK_TFLOPS if args.gru_precision in ('f32', 'x3') else MFMA_BF16_PEAK_TFLOPS      # (x3: float32 products on the bf16 pipe, priced as float32)
+        mfma_peak = MFMA_F32_PEAK_TFLOPS if args.gru_precision == 'f32' else MFMA_BF16_PEAK_TFLOPS      # (float32 products on the bf16 pipe are priced as float32)
         # the engine's own rule (engine.hip: gru_args): stock width re-tiled while tiles <= 2 x CUs (or forced), four waves per
         # tile while tiles <= 2 x CUs on the re-tiled shapes / <= CUs on the classic tiling (or forced)
         n_cus = torch.cuda.get_device_properties(device).multi_processor_count
         tiles = (B + 15) // 16
-        retiled = (tiles <= 2 * n_cus) if args.gru_tiling < 0 else bool(args.gru_tiling)
+        retiled = (tiles <= 2 * n_cus) if args.gru_tiling < 0 else args.gru_tiling == 1
         four_waves = (tiles <= (2 * n_cus if retiled else n_cus)) if not args.gru_waves else args.gru_waves == 4
         mfcc_kernel = 'mfcc_kernel<%s, ShapeStock, true>' % mfcc_name
         fused_name = ('fused_update_kernel<%s, ShapeStock, 5, %s, false, %s>' % (mfcc_name, 'true' if four_waves else 'false', 'true' if retiled else 'false')
@@ -593,7 +600,8 @@ def main():
         gru_name = ((('gru_cw_kernel' if retiled else 'gru_mw_kernel<5, false>') if four_waves else
                      ('gru_v_kernel<1>' if retiled else 'gru_small_kernel<5, 1, false>')) if args.gru_precision == 'f32'
                     else 'gru_bf16_kernel<1>')
-        if args.gru_precision == 'x3':
+        x3 = args.gru_precision == 'f32' and stock and (args.gru_tiling == 2 or (args.gru_tiling < 0 and tiles >= 8 * n_cus))
+        if x3:
             fused_name = '%s then gru_x3_kernel<1> (two dependent launches)' % mfcc_kernel
             gru_name = 'gru_x3_kernel<1>'
         if not stock:
@@ -620,7 +628,7 @@ def main():
                                       'stock' if stock else 'wide %s' % 'x'.join(map(str, units)), args.gru_precision, B,
                                       ' (batch=%d streams sharded across %d x MI355X, RCCL gather over xGMI)' % (n_global, world) if world > 1 else ''),
                        'streams_per_gpu': B, 'global_streams': n_global, 'chunk_samples': CHUNK,
-                       'gru': 'H=%s, T=29, F=13, ' % args.units + ('f32 MFMA 16x16x4' if args.gru_precision == 'f32' else 'f32 operands as 3 x bf16 pieces, 6 piece products on bf16 MFMA 16x16x32, f32 accumulate / gates / state' if args.gru_precision == 'x3' else 'bf16 MFMA 16x16x32, f32 accumulate'),
+                       'gru': 'H=%s, T=29, F=13, ' % args.units + ('f32 operands as 3 x bf16 pieces, 6 piece products on bf16 MFMA 16x16x32, f32 accumulate / gates / state' if x3 else 'f32 MFMA 16x16x4' if args.gru_precision == 'f32' else 'bf16 MFMA 16x16x32, f32 accumulate'),
                        'mfcc_dtype': args.mfcc_precision, 'feature_rows': args.ring_precision,
                        'parallelism': 'streams sharded over %d rank(s), final RCCL gather of probabilities to rank 0' % world},
             'realtime_streams': value / REALTIME_WINDOWS_PER_S,
@@ -656,7 +664,7 @@ def main():
         try:     # spin / streaming microbenchmarks of the same pool ("also report against measured peaks")
             with open(os.path.join(REPO, 'profiles', 'measured_peaks.json')) as f:
                 mp = json.load(f)
-            m_mfma = mp['mfma_f32_16x16x4_tflops'] if args.gru_precision in ('f32', 'x3') else mp['mfma_bf16_16x16x32_tflops']
+            m_mfma = mp['mfma_f32_16x16x4_tflops'] if args.gru_precision == 'f32' else mp['mfma_bf16_16x16x32_tflops']
             line['measured_peaks'] = {'mfma_tflops': m_mfma, 'hbm_read_gbs': mp['hbm_read_gbs'], 'source': 'profiles/measured_peaks.json',
                                       'roofline_frac': line['roofline']['achieved'] / (mp['hbm_read_gbs'] if hbm_bound else m_mfma),
                                       'roofline_gru_frac': line['roofline_gru']['achieved'] / m_mfma,

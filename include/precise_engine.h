@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PE_ABI_VERSION 3
+#define PE_ABI_VERSION 4
 
 typedef enum pe_status {
     PE_OK = 0,
@@ -64,15 +64,7 @@ typedef struct pe_params {
                                 network_runner.py:102,137);  1 = float32 front end        */
     int32_t gru_precision;   /* 0 = float32 matrix cores (reference precision, tol 1e-4);
                                 1 = bf16 operands / float32 accumulate (BASELINE configs[4],
-                                tol 1e-2);
-                                2 = float32 precision on the bf16 matrix pipe: every operand as
-                                three bf16 pieces that add up to the float32 value exactly, six
-                                piece products per multiplication, float32 accumulate and state
-                                (tol 1e-4, measured at the float32 kernels' distance to a float64
-                                evaluation); <= 20 units, <= 15 inputs, no use_delta.  On gfx950 the
-                                f32-input MFMAs run at the vector rate and block their SIMD, the
-                                bf16 ones do not: the form for engines that fill the machine
-                                (gru_x3_device.h)                                              */
+                                tol 1e-2)                                                    */
     int32_t vectorizer;      /* params.py:121-132: 2 = mfccs (sonopy, the default; also serves the
                                 offline mels entry), 3 = speechpy_mfccs (legacy .params files without
                                 a `vectorizer` key, params.py:147,155): one frame fewer per buffer
@@ -244,13 +236,22 @@ int pe_set_input_projection(pe_engine* e, int32_t enabled);
  * agrees to ~5e-6; slower, kept for measurement). */
 int pe_set_gru_waves(pe_engine* e, int32_t waves_per_tile);
 
-/* Tiling of the stock-width float32 network (17..20 units, model.py:76-82): 1 = three full MFMA tiles + partial sums
- * for units 16..19 (csrc/gru_cw_device.h: shortens the four-wave kernel's timestep), 0 = the classic four tiles,
- * -1 (default) = automatic (re-tiled while the engine has no more than two tiles per compute unit).  Every
- * kernel shape of ONE tiling agrees bit for bit (pe_update / pe_update_many / pe_predict / pe_evaluate, one or four
- * waves, fused or not); the two tilings agree to float32 summation order (<= 1e-6 on the probability).  Ignored by
- * the other networks (other widths, bf16, wide, projection rows); use_delta models of the stock width follow it. */
+/* Form of the float32 network (model.py:76-82), -1 (default) = automatic by engine size:
+ *   0 = the classic four output tiles on v_mfma_f32_16x16x4_f32;
+ *   1 = stock width (17..20 units) re-tiled: three full MFMA tiles + partial sums for units 16..19 (csrc/gru_cw_device.h:
+ *       shortens the four-wave kernel's timestep); automatic while the engine has no more than two tiles per compute unit;
+ *   2 = float32 products on the bf16 matrix pipe (csrc/gru_x3_device.h): every operand as three bf16 pieces that add up
+ *       to the float32 value exactly, six piece products per multiplication, float32 accumulate / gates / state -- the
+ *       float32 tolerance, at the float32 kernels' distance to a float64 evaluation.  <= 20 units, <= 15 inputs, no
+ *       use_delta (PE_ERR_UNSUPPORTED otherwise).  On gfx950 an f32-input MFMA keeps its whole SIMD from issuing while
+ *       it runs and a bf16 MFMA does not; automatic from eight tiles per compute unit on (32 768 streams on MI355X),
+ *       where it takes two launches per update instead of the fused one and is still faster.
+ * Every kernel shape of ONE form agrees bit for bit (pe_update / pe_update_many / pe_predict / pe_evaluate, one or four
+ * waves, fused or not); the forms agree to float32 summation order (<= 1e-6 on the probability).  Ignored by the other
+ * networks (bf16, wide, projection rows); use_delta models of the stock width follow 0 / 1.
+ * pe_get_gru_tiling: the form this engine's launches take now (0 / 1 / 2; -1 for bf16 and wide networks). */
 int pe_set_gru_tiling(pe_engine* e, int32_t tiling);
+int pe_get_gru_tiling(const pe_engine* e);
 
 /* HIP-event timing of the kernels launched by the last *_device/host update on this engine
  * (milliseconds; measured on the stream the kernels ran on).  Enabled with pe_set_timing(e,1).

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PE_LIB') or os.path.join(HERE, 'libprecise_engine.so')
 
 PE_OK, PE_ERR_INVALID, PE_ERR_HIP, PE_ERR_UNSUPPORTED, PE_ERR_NOMEM, PE_ERR_EOF = range(6)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class PeParams(C.Structure):
@@ -76,6 +76,7 @@ EXPORTS = {
     'pe_set_fused': (C.c_int, [C.c_void_p, C.c_int32]),
     'pe_set_gru_waves': (C.c_int, [C.c_void_p, C.c_int32]),
     'pe_set_gru_tiling': (C.c_int, [C.c_void_p, C.c_int32]),
+    'pe_get_gru_tiling': (C.c_int, [C.c_void_p]),
     'pe_set_input_projection': (C.c_int, [C.c_void_p, C.c_int32]),
     'pe_set_timing': (C.c_int, [C.c_void_p, C.c_int32]),
     'pe_get_last_timing': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -161,7 +162,7 @@ class HipEngine:
             vec = Vectorizer.mfccs
         p = PeParams(params.sample_rate, params.window_samples, params.hop_samples, params.n_fft,
                      params.n_filt, params.n_mfcc, params.n_features, int(bool(params.use_delta)), prec,
-                     {'f32': 0, 'bf16': 1, 'x3': 2}[gru_precision], vec, {'f32': 0, 'bf16': 1}[ring_precision])
+                     {'f32': 0, 'bf16': 1}[gru_precision], vec, {'f32': 0, 'bf16': 1}[ring_precision])
         if mel_filters is None:
             bank = speechpy_filterbank if vec == Vectorizer.speechpy_mfccs else mel_filterbank
             mel_filters = bank(params.sample_rate, params.n_filt, params.n_fft // 2 + 1)
@@ -371,8 +372,13 @@ class HipEngine:
         self._check(self._lib.pe_set_gru_waves(self._h, int(waves)))
 
     def set_gru_tiling(self, tiling: int):
-        """-1 automatic, 0 classic four-tile layout, 1 re-tiled stock width (csrc/gru_cw_device.h)."""
+        """-1 automatic, 0 classic four-tile layout, 1 re-tiled stock width (csrc/gru_cw_device.h), 2 float32 products on the
+        bf16 matrix pipe (csrc/gru_x3_device.h; automatic from eight tiles per compute unit on)."""
         self._check(self._lib.pe_set_gru_tiling(self._h, int(tiling)))
+
+    def gru_tiling(self) -> int:
+        """The form this engine's network launches take now: 0 / 1 / 2 as above, -1 for bf16 and wide networks."""
+        return int(self._lib.pe_get_gru_tiling(self._h))
 
     def set_timing(self, enabled: bool):
         self._check(self._lib.pe_set_timing(self._h, int(bool(enabled))))

@@ -56,7 +56,7 @@ struct pe_engine {
     int row_floats = kRowFloats;   // floats per feature row: 32 when a frame has 17..32 coefficients
     int carry_cap = kCarryCap;     // int16 samples of leftover PCM kept per stream (>= frame length)
     GeneralTables gtab{};
-    int gru_tiling = -1;    // stock width: -1 = auto (re-tiled shapes while tiles <= CUs), 0 = classic, 1 = re-tiled (gru_cw_device.h)
+    int gru_tiling = -1;    // -1 = auto (stock width re-tiled while tiles <= 2 CUs; XDL form from 8 tiles per CU on), 0 = classic, 1 = re-tiled (gru_cw_device.h), 2 = XDL form (gru_x3_device.h)
     float* cw_blob = nullptr;
     int n_cus = 256;        // compute units of the device (MI355X: 256)
     float* ring = nullptr;
@@ -82,7 +82,8 @@ struct pe_engine {
     float* wide_wd = nullptr;
     // bf16-operand network (pe_params.gru_precision = 1)
     uint16_t* wx_bf16 = nullptr; uint16_t* wr_bf16 = nullptr; float* wd_bf16 = nullptr;
-    // float32 network as three bf16 pieces per operand on the XDL pipe (pe_params.gru_precision = 2; gru_x3_device.h)
+    // float32 network as three bf16 pieces per operand on the XDL pipe (gru_x3_device.h; tiling 2): packed for every
+    // float32 network of <= 20 units and <= 15 inputs without delta features
     uint32_t* x3_blob = nullptr;
     // on-device ThresholdDecoder / TriggerDetector (pe_set_decoder / pe_set_trigger)
     double* cd = nullptr; int cd_len = 0, dec_min_out = 0, dec_out_range = 0; double dec_center = 0.5;
@@ -423,10 +424,11 @@ void split3_bf16(float v, uint16_t (&piece)[3]) {
     }
 }
 
+// (<= 20 units, <= 15 inputs, no use_delta: the caller checks x3_eligible)
+bool x3_eligible(const pe_params& p, const pe_gru_layer& L) { return p.gru_precision == 0 && !p.use_delta && L.units <= 20 && L.n_in <= 15 && p.n_mfcc <= kRowFloats; }
+
 int pack_gru_weights_x3(pe_engine* e, const pe_gru_layer& L, const float* dense_kernel) {
     const int H = L.units, F = L.n_in;
-    if (e->prm.use_delta || H > 20 || F > 15)
-        return fail(e, PE_ERR_UNSUPPORTED, "gru_precision = 2 (float32 as three bf16 pieces on the XDL pipe) takes <= 20 units, <= 15 inputs, no use_delta (got %d units, %d inputs)", H, F);
     std::vector<uint32_t> blob((size_t)kX3BlobBytes / 4, 0u);
     uint16_t* const half = reinterpret_cast<uint16_t*>(blob.data());
     auto gate_col = [&](int tile, int i, int* col) -> bool {     // A row i of an output tile -> column of the Keras matrices
@@ -638,7 +640,6 @@ GruArgs gru_args(const pe_engine* e) {
     a.frame_len = frame_len_of(e->prm);
     a.bf16 = e->prm.gru_precision == 1;
     a.wx_bf16 = e->wx_bf16; a.wr_bf16 = e->wr_bf16; a.wd_bf16 = e->wd_bf16;
-    a.x3 = e->prm.gru_precision == 2 ? e->x3_blob : nullptr;
     a.feats = nullptr; a.out = nullptr; a.row_stride = 0;
     a.row_floats = e->row_floats;
     // Four waves per tile cut the latency of a tile's chain; that only pays while every tile gets a CU of its
@@ -651,10 +652,17 @@ GruArgs gru_args(const pe_engine* e) {
     // regime (two-pass MFMAs + reductions: 81.0 vs 77.3 us at 65 536 streams), so an engine takes ONE tiling for all
     // of its launches -- every shape of a tiling agrees bit for bit -- by its size.  The critical-wave kernel still
     // wins with two tiles per compute unit (8192 streams, fused: 272 vs 254 M windows/s against one wave per tile).
+    // Engines that fill the machine (>= 8 tiles per compute unit: 32 768 streams on MI355X) take the XDL form of the float32
+    // network (gru_x3_device.h: every operand as three bf16 pieces): an f32-input MFMA keeps its whole SIMD from issuing for
+    // its 8 passes, the bf16 MFMAs cost half the cycles for the same products and do not.  Measured per update, two
+    // launches against the fused classic tiling: 69 vs 79 us at 32 768 streams, 130 vs 154 us at 65 536 (48 vs 43 us at
+    // 16 384: below, the missing fused launch costs more than the cheaper network saves).
+    const bool x3_ok = e->x3_blob && !a.bf16 && !e->wide && !a.proj_ring && e->row_floats == kRowFloats && e->gru_waves != 16;
+    a.x3 = x3_ok && (e->gru_tiling == 2 || (e->gru_tiling < 0 && e->n_tiles >= 8 * e->n_cus)) ? e->x3_blob : nullptr;
     const bool cw_ok = e->cw_blob && e->row_floats == kRowFloats && !a.proj_ring && !a.bf16 && !a.x3 && !e->wide && e->gru_waves != 16;
     const bool retile = cw_ok && (e->gru_tiling == 1 || (e->gru_tiling < 0 && e->n_tiles <= 2 * e->n_cus));
     const int auto_waves = retile ? (e->n_tiles <= 2 * e->n_cus ? 4 : 1) : (e->n_tiles <= e->n_cus ? 4 : 1);
-    a.waves_per_tile = e->gru_waves ? e->gru_waves : auto_waves;      // (16 = DPP kernel: opt-in)
+    a.waves_per_tile = a.x3 ? 1 : e->gru_waves ? e->gru_waves : auto_waves;      // (16 = DPP kernel: opt-in)
     if (a.waves_per_tile == 16 && !dpp_ok) a.waves_per_tile = 4;
     if (e->prm.use_delta && !retile) a.waves_per_tile = 1;       // (classic tiling: only the one-wave kernel carries the delta inputs)
     if (e->row_floats != kRowFloats && !(gru_small_regs(e->units) == 5 && !e->prm.use_delta && a.waves_per_tile == 4))
@@ -715,7 +723,7 @@ bool can_fuse(const pe_engine* e, int chunk) {
     // (gru_x3_device.h: ~220 registers per lane against the frame role's ~100, and one kernel has one budget.  The same
     //  concurrency as TWO kernels -- the network on a side stream between two events -- was built and measured: 142 vs
     //  134 us per update at 65 536 streams, 40 vs 24 us at 4096: the event hand-offs cost more than the overlap buys)
-    if (e->prm.gru_precision == 2) return false;
+    if (gru_args(e).x3) return false;
     if (e->prm.gru_precision == 0 && gru_small_regs(e->units) >= 6 && gru_args(e).waves_per_tile != 4) return false;
     if (e->prm.use_delta && e->prm.gru_precision == 0) {        // re-tiled one-wave shape with delta inputs: no fused instantiation
         // (waves_per_tile == 4 is not enough: the four-wave shape needs the 32-slot ring it stages in LDS -- after
@@ -782,7 +790,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     if (p->hop_samples < 1 || p->window_samples < 1 || p->n_features < 1)
         return fail(nullptr, PE_ERR_INVALID, "window/hop/n_features must be positive");
     if (p->mfcc_precision != 0 && p->mfcc_precision != 1) return fail(nullptr, PE_ERR_INVALID, "mfcc_precision must be 0 (f64) or 1 (f32)");
-    if (p->gru_precision < 0 || p->gru_precision > 2) return fail(nullptr, PE_ERR_INVALID, "gru_precision must be 0 (f32 MFMA), 1 (bf16 operands) or 2 (f32 as three bf16 pieces per operand on the XDL pipe)");
+    if (p->gru_precision != 0 && p->gru_precision != 1) return fail(nullptr, PE_ERR_INVALID, "gru_precision must be 0 (f32) or 1 (bf16 operands)");
     if (p->vectorizer != 0 && p->vectorizer != 2 && p->vectorizer != 3)
         return fail(nullptr, PE_ERR_UNSUPPORTED, "vectorizer must be 2 (mfccs) or 3 (speechpy_mfccs); Vectorizer.mels (1) exists in the offline form only (pe_vectorize_mels), got %d", p->vectorizer);
     if (p->ring_precision != 0 && p->ring_precision != 1) return fail(nullptr, PE_ERR_INVALID, "ring_precision must be 0 (f32 rows) or 1 (bf16 rows)");
@@ -889,7 +897,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         }
         else if ((rc = pack_gru_weights(e, L, w->dense_kernel))) break;
         if (p->gru_precision == 1 && (rc = pack_gru_weights_bf16(e, L, w->dense_kernel))) break;
-        if (p->gru_precision == 2 && (rc = pack_gru_weights_x3(e, L, w->dense_kernel))) break;
+        if (!wide && x3_eligible(*p, L) && (rc = pack_gru_weights_x3(e, L, w->dense_kernel))) break;
         // the projection rows exist for the stock-width float32 network (3 R <= 16 slots: 4 output tiles, R = 5) fed
         // from the ring; they pay while the ring stays cache-resident (256 B per frame and stream)
         e->proj_ok = !wide && p->gru_precision == 0 && !p->use_delta && gru_small_regs(L.units) == 5 && !e->proj_w_host.empty();
@@ -1375,9 +1383,18 @@ int pe_set_gru_waves(pe_engine* e, int32_t waves) {
 
 int pe_set_gru_tiling(pe_engine* e, int32_t tiling) {
     if (!e) return PE_ERR_INVALID;
-    if (tiling < -1 || tiling > 1) return fail(e, PE_ERR_INVALID, "gru tiling must be -1 (auto), 0 (classic) or 1 (re-tiled)");
+    if (tiling < -1 || tiling > 2) return fail(e, PE_ERR_INVALID, "gru tiling must be -1 (auto), 0 (classic), 1 (re-tiled) or 2 (XDL form)");
+    if (tiling == 2 && !e->x3_blob)
+        return fail(e, PE_ERR_UNSUPPORTED, "the XDL form of the float32 network (tiling 2) takes <= 20 units, <= 15 inputs, float32 operands, no use_delta");
     e->gru_tiling = tiling;
     return PE_OK;
+}
+
+int pe_get_gru_tiling(const pe_engine* e) {
+    if (!e) return PE_ERR_INVALID;
+    if (e->wide || e->prm.gru_precision != 0) return -1;
+    const GruArgs a = gru_args(e);
+    return a.x3 ? 2 : a.cw ? 1 : 0;
 }
 
 int pe_set_timing(pe_engine* e, int32_t enabled) {

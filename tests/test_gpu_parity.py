@@ -1125,7 +1125,7 @@ def test_full_batch_4096_streams_properties(stock_weights):
     assert info.n_streams == B and info.ring_slots == 32 and info.device_bytes > B * 2048
 
 
-def _full_size_run(weights, B, n_up, n_check, tol, guard_equal_positions=True, oracle_params=None, **listener_kw):
+def _full_size_run(weights, B, n_up, n_check, tol, guard_equal_positions=True, oracle_params=None, gru_tiling=-1, **listener_kw):
     """Size-independent properties at a BASELINE batch size: every stream is a copy of one of n_check seeded
     streams (shuffled), so (a) the seeded ones are checked against the oracle, (b) identical input must give
     bit-identical output wherever it sits in the batch, (c) clear + replay is bit-identical."""
@@ -1135,6 +1135,8 @@ def _full_size_run(weights, B, n_up, n_check, tol, guard_equal_positions=True, o
     owner = rng.integers(0, n_check, B)
     owner[:n_check] = np.arange(n_check)
     hip = BatchedListener(weights, B, **listener_kw)
+    if gru_tiling >= 0:
+        hip.engine.set_gru_tiling(gru_tiling)
     ref = ol.BatchedOracle(weights, n_check, oracle_params)
     first, worst = [], 0.0
     for u in range(n_up):
@@ -1151,7 +1153,7 @@ def _full_size_run(weights, B, n_up, n_check, tol, guard_equal_positions=True, o
     return hip, base, owner, first
 
 
-# ---- gru_precision = 'x3': the float32 network on the bf16 matrix pipe (gru_x3_device.h) ----------------------------
+# ---- pe_set_gru_tiling(e, 2): the float32 network on the bf16 matrix pipe (gru_x3_device.h) -------------------------
 def test_x3_network_matches_oracle_at_the_float32_guard(stock_weights):
     """Every operand as three bf16 pieces (hi + mid + lo == the float32 value exactly), six piece products per
     multiplication, float32 accumulate / gates / state: the float32 kernels' guard against the float32 oracle, and a
@@ -1160,9 +1162,10 @@ def test_x3_network_matches_oracle_at_the_float32_guard(stock_weights):
     kinds = (['tone_noise'] * 30) + ['zeros', 'square', 'square', 'quiet', 'quiet', 'zeros', 'tone_noise']
     n_up = 40
     pcm = _stream_batch(kinds, n_up)
-    x3 = HipEngine(P.pr, stock_weights, n_streams=len(kinds), gru_precision='x3')
+    x3 = HipEngine(P.pr, stock_weights, n_streams=len(kinds))
+    x3.set_gru_tiling(2)
     f32 = HipEngine(P.pr, stock_weights, n_streams=len(kinds))
-    assert x3.info().gru_precision == 2
+    assert x3.gru_tiling() == 2 and f32.gru_tiling() == 1
     ref = ol.BatchedOracle(stock_weights, len(kinds))
     d64 = {'x3': 0.0, 'f32': 0.0}
     for u in range(n_up):
@@ -1186,8 +1189,9 @@ def test_x3_every_entry_point_agrees_bitwise(stock_weights):
     n, depth, chunk = 70, 6, 1024
     kinds = ['tone_noise'] * (n - 3) + ['zeros', 'square', 'quiet']
     pcm = _stream_batch(kinds, 36, chunk)
-    a = HipEngine(P.pr, stock_weights, n_streams=n, gru_precision='x3')
-    b = HipEngine(P.pr, stock_weights, n_streams=n, gru_precision='x3')
+    a = HipEngine(P.pr, stock_weights, n_streams=n)
+    b = HipEngine(P.pr, stock_weights, n_streams=n)
+    a.set_gru_tiling(2); b.set_gru_tiling(2)
     b.reserve_updates(depth, chunk)
     for u in range(0, 36, depth):
         want = np.stack([a.update(pcm[u + i]) for i in range(depth)])
@@ -1196,7 +1200,8 @@ def test_x3_every_entry_point_agrees_bitwise(stock_weights):
     a.close(); b.close()
     # offline evaluation: windows of one row sequence == the same windows as an explicit batch
     from oracle import sonopy_restated as so
-    eng = HipEngine(P.pr, stock_weights, n_streams=1, gru_precision='x3')
+    eng = HipEngine(P.pr, stock_weights, n_streams=1)
+    eng.set_gru_tiling(2)
     audio = synth.stream_pcm(21, 16000 * 5).astype(np.float32) / np.float32(32768.0)
     got = eng.evaluate(audio, 2)
     mf = so.mfcc_spec(audio.astype(np.float64), 16000, (1600, 800), num_filt=20, fft_size=512, num_coeffs=13)
@@ -1214,7 +1219,8 @@ def test_x3_widths_and_input_sizes(units, n_in):
     w = synth.make_weights(n_in=n_in, units=(units,), seed=300 + units + n_in)
     hpr = P.pr.copy()
     hpr.__dict__.update(n_mfcc=n_in)
-    eng = HipEngine(hpr, w, n_streams=1, gru_precision='x3')
+    eng = HipEngine(hpr, w, n_streams=1)
+    eng.set_gru_tiling(2)
     rng = np.random.default_rng(units)
     for n in (1, 17, 50):
         x = rng.normal(0, 2, (n, 29, n_in)).astype(np.float32)
@@ -1228,23 +1234,41 @@ def test_x3_refuses_what_it_has_no_kernel_for():
     for kw, w_kw in ((dict(), dict(units=(21,))), (dict(n_mfcc=16), dict(n_in=16)), (dict(use_delta=True), dict(n_in=26))):
         hpr = P.pr.copy()
         hpr.__dict__.update(kw)
+        eng = HipEngine(hpr, synth.make_weights(seed=1, **w_kw), n_streams=4)
         with pytest.raises(NotImplementedError):
-            HipEngine(hpr, synth.make_weights(seed=1, **w_kw), n_streams=4, gru_precision='x3')
+            eng.set_gru_tiling(2)
+        assert eng.gru_tiling() in (0, 1)
+        eng.close()
+    eng = HipEngine(P.pr, synth.make_weights(seed=1), n_streams=4, gru_precision='bf16')
+    with pytest.raises(NotImplementedError):
+        eng.set_gru_tiling(2)
+    assert eng.gru_tiling() == -1
+    eng.close()
 
 
-def test_x3_capacity_batch_65536_streams_properties(stock_weights):
-    """The capacity point on the XDL pipe (bench.py extra_configs): 65536 streams, the size-independent properties and the
-    oracle on the seeded streams."""
-    _full_size_run(stock_weights, 65536, 33, 24, GUARD_RAW, gru_precision='x3')
-
-
-def test_capacity_batch_65536_streams_properties(stock_weights):
-    """The capacity point of the metric (max concurrent real-time streams; bench.py extra_configs): 65536 streams, float64
-    front end + float32 network on the one-wave-per-tile kernels -- the size-independent properties, and fused == two
-    launches at this size."""
+def test_x3_is_the_automatic_form_of_engines_that_fill_the_machine(stock_weights):
+    """From eight tiles per compute unit on (32 768 streams on MI355X) the float32 network takes the XDL form by itself;
+    smaller engines keep the f32-input MFMA kernels (their fused launch is worth more than the cheaper network)."""
     from mycroft_precise_amd._lib import HipEngine
-    hip, base, owner, first = _full_size_run(stock_weights, 65536, 33, 24, GUARD_RAW)
+    for n, want in ((4096, 1), (16384, 0), (32768, 2), (65536, 2)):
+        eng = HipEngine(P.pr, stock_weights, n_streams=n)
+        assert eng.gru_tiling() == want, n
+        eng.set_gru_tiling(0)
+        assert eng.gru_tiling() == 0
+        eng.close()
+
+
+@pytest.mark.parametrize('tiling', [-1, 0])
+def test_capacity_batch_65536_streams_properties(stock_weights, tiling):
+    """The capacity point of the metric (max concurrent real-time streams; bench.py extra_configs): 65536 streams, float64
+    front end + float32 network, one wave per tile -- the automatic form (float32 products on the bf16 pipe, two launches)
+    and the classic tiling on the f32-input MFMAs (fused launch): the size-independent properties, and pe_set_fused(0)
+    == the default sequencing at this size."""
+    from mycroft_precise_amd._lib import HipEngine
+    hip, base, owner, first = _full_size_run(stock_weights, 65536, 33, 24, GUARD_RAW, gru_tiling=tiling)
+    assert hip.engine.gru_tiling() == (2 if tiling < 0 else 0)
     two = HipEngine(P.pr, stock_weights, n_streams=65536)
+    two.set_gru_tiling(tiling)
     two.set_fused(False)
     for u in range(33):
         assert np.array_equal(two.update(base[u][owner]), first[u]), u

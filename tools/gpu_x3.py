@@ -16,7 +16,7 @@ B = 512
 n_up = 40
 pcm = synth.batch_pcm(B, n_up)
 ea = _lib.HipEngine(pr, w, n_streams=B, gru_precision='f32')
-eb = _lib.HipEngine(pr, w, n_streams=B, gru_precision='x3')
+eb = _lib.HipEngine(pr, w, n_streams=B); eb.set_gru_tiling(2)
 worst = {'x3_vs_f32': 0.0, 'x3_vs_oracle32': 0.0, 'f32_vs_oracle32': 0.0, 'x3_vs_f64': 0.0, 'f32_vs_f64': 0.0, 'oracle32_vs_f64': 0.0}
 for u in range(n_up):
     pa = ea.update(pcm[u])
@@ -38,8 +38,9 @@ ea.close(); eb.close()
 sizes = [int(s) for s in sys.argv[1:]] or [4096, 8192, 65536]
 for Bn in sizes:
     for gru, fz in (('f32', 1), ('x3', 1), ('bf16', 1)):
-        eng = _lib.HipEngine(pr, w, n_streams=Bn, gru_precision=gru)
-        eng.set_fused(fz)
+        eng = _lib.HipEngine(pr, w, n_streams=Bn, gru_precision='f32' if gru == 'x3' else gru)
+        if gru != 'bf16':
+            eng.set_gru_tiling(2 if gru == 'x3' else 1 if Bn <= 8192 else 0)
         n_res = 16
         pcm_d = (torch.randn((n_res, Bn, 1024), device=dev) * 3000).to(torch.int16)
         out = torch.zeros(Bn, device=dev)
@@ -70,8 +71,10 @@ for Bn in sizes:
         continue
     for gru, mfcc in (('x3', 'f64'), ('f32', 'f64'), ('bf16', 'f32')):
         ring = 'bf16' if gru == 'bf16' else 'f32'
-        e_net = _lib.HipEngine(pr, w, n_streams=Bn, gru_precision=gru, mfcc_precision=mfcc, ring_precision=ring)
-        e_mf = _lib.HipEngine(pr, w, n_streams=Bn, gru_precision=gru, mfcc_precision=mfcc, ring_precision=ring)
+        e_net = _lib.HipEngine(pr, w, n_streams=Bn, gru_precision='f32' if gru == 'x3' else gru, mfcc_precision=mfcc, ring_precision=ring)
+        e_mf = _lib.HipEngine(pr, w, n_streams=Bn, gru_precision='f32' if gru == 'x3' else gru, mfcc_precision=mfcc, ring_precision=ring)
+        if gru != 'bf16':
+            e_net.set_gru_tiling(2 if gru == 'x3' else 0); e_mf.set_gru_tiling(2 if gru == 'x3' else 0)
         n_res = 16
         pcm_d = (torch.randn((n_res, Bn, 1024), device=dev) * 3000).to(torch.int16)
         out = torch.zeros(Bn, device=dev)
