@@ -82,6 +82,7 @@ struct pe_engine {
     float* wide_wd = nullptr;
     // bf16-operand network (pe_params.gru_precision = 1)
     uint16_t* wx_bf16 = nullptr; uint16_t* wr_bf16 = nullptr; float* wd_bf16 = nullptr;
+    uint32_t* b20_blob = nullptr;     // the same network in the layout of gru_b20_device.h (<= 20 units, <= 14 features)
     // float32 network as three bf16 pieces per operand on the XDL pipe (gru_x3_device.h; tiling 2): packed for every
     // float32 network of <= 20 units and <= 15 inputs without delta features
     uint32_t* x3_blob = nullptr;
@@ -473,6 +474,59 @@ int pack_gru_weights_x3(pe_engine* e, const pe_gru_layer& L, const float* dense_
     return dev_upload(e, &e->x3_blob, blob);
 }
 
+// bf16 network of <= 20 units in the five-values-per-lane layout (gru_b20_device.h): output tiles 0..2 = z / r / candidate
+// of units 0..15 (row i <-> unit i), tile 3 row 4 g + q = gate q of unit 16 + g; recurrent k-slot 8 gk + e <-> source unit
+// 4 gk + e (e < 4) / 16 + gk (e = 4); input k-slot 8 gk + e <-> feature 4 gk + e (e < 4; pseudo-features F, F + 1 = bias hi,
+// lo), and 8 gk + 4 + e <-> the first difference of that feature (use_delta: kernel rows F .. 2 F - 1).
+bool b20_eligible(const pe_params& p, const pe_gru_layer& L) {
+    const int F = p.use_delta ? L.n_in / 2 : L.n_in;
+    // (tuning builds only, PE_B20=1: measured and not shipped -- tools/micro/gru_b20_device.h)
+    return tuning_env_int("PE_B20", 0) != 0 && p.gru_precision == 1 && L.units <= 20 && F <= 14 && p.n_mfcc <= kRowFloats;
+}
+
+int pack_gru_weights_b20(pe_engine* e, const pe_gru_layer& L, const float* dense_kernel) {
+    const bool delta = e->prm.use_delta != 0;
+    const int H = L.units, F = delta ? L.n_in / 2 : L.n_in;
+    std::vector<uint32_t> blob((size_t)kB20BlobBytes / 4, 0u);
+    uint16_t* const half = reinterpret_cast<uint16_t*>(blob.data());
+    for (int tile = 0; tile < kB20Tiles; ++tile)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, gk = lane >> 4;
+            int gate, unit;
+            if (tile < 3) { gate = tile; unit = i; }
+            else { gate = i & 3; unit = 16 + (i >> 2); if (gate == 3) continue; }
+            if (unit >= H) continue;
+            const int col = gate * H + unit;
+            for (int ek = 0; ek < 5; ++ek) {
+                const int src = ek < 4 ? 4 * gk + ek : 16 + gk;
+                if (src < H) half[((size_t)(kB20ArOff + tile * 64 + lane)) * 8 + ek] = to_bf16(L.recurrent_kernel[(size_t)src * 3 * H + col]);
+            }
+            for (int ek = 0; ek < 8; ++ek) {
+                const int f = 4 * gk + (ek & 3);
+                uint16_t v = 0;
+                if (ek < 4) {
+                    if (f < F) v = to_bf16(L.kernel[(size_t)f * 3 * H + col]);
+                    else if (f == F || f == F + 1) {
+                        const float b = L.bias[col];
+                        const uint16_t hi = to_bf16(b);
+                        const uint32_t hb = (uint32_t)hi << 16;
+                        float hif;
+                        std::memcpy(&hif, &hb, 4);
+                        v = f == F ? hi : to_bf16(b - hif);
+                    }
+                } else if (delta && f < F) v = to_bf16(L.kernel[(size_t)(F + f) * 3 * H + col]);
+                half[((size_t)(kB20AxOff + tile * 64 + lane)) * 8 + ek] = v;
+            }
+        }
+    float* const wd = reinterpret_cast<float*>(blob.data()) + (size_t)kB20WdOff * 4;
+    for (int o = 0; o < 5; ++o)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int u = o < 4 ? 4 * (lane >> 4) + o : 16 + (lane >> 4);
+            if (u < H) wd[o * 64 + lane] = dense_kernel[u];
+        }
+    return dev_upload(e, &e->b20_blob, blob);
+}
+
 // Wide / stacked network (gru_wide_device.h): wave w owns output tiles tau = w TPW + t of every gate;
 // row i of a tile <-> unit 16 tau + 4 (i & 3) + (i >> 2); k-step rho, k-slot gk <-> source unit 4 rho + gk
 // (layer 0 input: k-step kk <-> feature 4 gk + kk).  Streams: [wave][k-group][tile][lane] float4.
@@ -640,6 +694,7 @@ GruArgs gru_args(const pe_engine* e) {
     a.frame_len = frame_len_of(e->prm);
     a.bf16 = e->prm.gru_precision == 1;
     a.wx_bf16 = e->wx_bf16; a.wr_bf16 = e->wr_bf16; a.wd_bf16 = e->wd_bf16;
+    a.b20 = e->b20_blob;
     a.feats = nullptr; a.out = nullptr; a.row_stride = 0;
     a.row_floats = e->row_floats;
     // Four waves per tile cut the latency of a tile's chain; that only pays while every tile gets a CU of its
@@ -897,6 +952,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         }
         else if ((rc = pack_gru_weights(e, L, w->dense_kernel))) break;
         if (p->gru_precision == 1 && (rc = pack_gru_weights_bf16(e, L, w->dense_kernel))) break;
+        if (!wide && b20_eligible(*p, L) && (rc = pack_gru_weights_b20(e, L, w->dense_kernel))) break;
         if (!wide && x3_eligible(*p, L) && (rc = pack_gru_weights_x3(e, L, w->dense_kernel))) break;
         // the projection rows exist for the stock-width float32 network (3 R <= 16 slots: 4 output tiles, R = 5) fed
         // from the ring; they pay while the ring stays cache-resident (256 B per frame and stream)

@@ -9,6 +9,7 @@
 #ifdef PE_TUNING      // measured and rejected: tuning builds only (tools/build_variants.sh)
 #include "../../tools/micro/gru_dpp_device.h"
 #include "../../tools/micro/gru_pair_device.h"
+#include "../../tools/micro/gru_b20_device.h"
 #endif
 #include "gru_bf16_device.h"
 #include "gru_x3_device.h"
@@ -98,6 +99,9 @@ __global__ __launch_bounds__(64) void gru_many_bf16_kernel(const GruArgs a, cons
     b.st_ke = a.st_ke + (size_t)u * n_padded;
     b.out = a.out + (size_t)u * a.n_streams;
     b.predict_ke = 0;
+#ifdef PE_TUNING
+    if (b.b20) { gru_tile_b20<kRing, DELTA, RB>(b, tile, threadIdx.x); return; }
+#endif
     gru_tile_bf16<kRing, DELTA, RB>(b, tile, threadIdx.x);
 }
 
@@ -172,6 +176,9 @@ hipError_t launch_gru_wide(const WideArgs& a, int mode, hipStream_t s) {
 template <int MODE, bool DELTA, bool RB = false>
 __global__ __launch_bounds__(64) void gru_bf16_kernel(const GruArgs a) {
     touch_kernel_arguments<(int)sizeof(GruArgs)>();
+#ifdef PE_TUNING     // (five values per lane for <= 20 units: measured, not shipped -- tools/micro/gru_b20_device.h)
+    if (a.b20) { gru_tile_b20<MODE, DELTA, RB>(a, blockIdx.x, threadIdx.x); return; }
+#endif
     gru_tile_bf16<MODE, DELTA, RB>(a, blockIdx.x, threadIdx.x);
 }
 
@@ -216,7 +223,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
     if (b < n_gru_blocks) {
         const int wave = threadIdx.x >> 6;
         const int tile = b * tpw + wave;
-        if (wave < tpw && tile < n_tiles) gru_tile_bf16<kRing, DELTA, RB>(g, tile, threadIdx.x & 63);
+        if (wave < tpw && tile < n_tiles) {
+#ifdef PE_TUNING
+            if (g.b20) { gru_tile_b20<kRing, DELTA, RB>(g, tile, threadIdx.x & 63); return; }
+#endif
+            gru_tile_bf16<kRing, DELTA, RB>(g, tile, threadIdx.x & 63);
+        }
     } else if (b < n_gru_blocks + n_frame_blocks) {
         mfcc_frame_tasks<R, SH, true>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
     } else {

@@ -44,7 +44,11 @@ __device__ __forceinline__ float real_fma(float a, float b, float c) { return fm
 // LDS instructions of one wave execute in program order, so a hand-off between lanes of the same
 // wave needs no counter wait -- only the compiler must not move DS accesses across it.
 __device__ __forceinline__ void group_sync() {
+#if defined(PE_GROUP_SYNC_WAIT) && PE_GROUP_SYNC_WAIT      // (bisecting aid of round 4: tools/micro/gru_b20_device.h)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("" ::: "memory");
+#endif
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
 }

@@ -113,6 +113,14 @@ constexpr int kX3AxOff = kX3Tiles * kX3RecOps * 64;                  // in uint4
 constexpr int kX3WdOff = kX3AxOff + kX3Tiles * kX3InOps * 64;        // in uint4 (floats follow)
 constexpr int kX3BlobBytes = kX3WdOff * 16 + 5 * 64 * 4;
 
+// gru_b20_device.h: packed operands of the bf16-operand network of <= 20 units (pe_params.gru_precision = 1)
+constexpr int kB20Tiles = 4;                // TZ, TR, TC, TQ
+// blob (uint4 = 8 bf16 per lane): [AR: tile][lane] | [AX: tile][lane] | float wd[5][lane]
+constexpr int kB20ArOff = 0;
+constexpr int kB20AxOff = kB20Tiles * 64;
+constexpr int kB20WdOff = 2 * kB20Tiles * 64;
+constexpr int kB20BlobBytes = kB20WdOff * 16 + 5 * 64 * 4;
+
 struct GruArgs {
     int n_streams;
     int n_features;         // T
@@ -139,6 +147,8 @@ struct GruArgs {
     const void* wx_bf16;    // [6][64] x 8 bf16    input kernel, k = 8 g + e <-> feature; k = 30, 31: bias hi, lo
     const void* wr_bf16;    // [6][64] x 8 bf16    recurrent kernel, k = 8 g + e <-> unit
     const float* wd_bf16;   // [8][64]
+    // ... and in the five-values-per-lane layout of networks of <= 20 units (gru_b20_device.h): non-null = the bf16 launchers take it
+    const void* b20;
     // float32 network on the XDL pipe, operands as three bf16 pieces (gru_x3_device.h; pe_params.gru_precision = 2):
     // non-null = the launchers take gru_tile_x3 for every input mode
     const void* x3;         // [4 tiles][4][64] + [4 tiles][3][64] uint4 of 8 bf16, then float wd[5][64]

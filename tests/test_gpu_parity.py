@@ -845,6 +845,25 @@ def test_bf16_network_within_1e2_of_oracle(stock_weights, mfcc):
     eng.close()
 
 
+@pytest.mark.parametrize('units,n_in,delta', [(20, 13, False), (7, 5, False), (17, 14, False), (20, 13, True), (24, 13, False), (20, 15, False), (32, 13, True)])
+def test_bf16_network_by_width(units, n_in, delta):
+    """gru_precision='bf16' for widths up to 32 units, with and without delta inputs: explicit batches of ragged size against
+    the float32 oracle at the bf16 tolerance."""
+    from mycroft_precise_amd._lib import HipEngine
+    w = synth.make_weights(n_in=2 * n_in if delta else n_in, units=(units,), seed=500 + units + n_in)
+    hpr = P.pr.copy()
+    hpr.__dict__.update(n_mfcc=n_in, use_delta=delta)
+    eng = HipEngine(hpr, w, n_streams=1, gru_precision='bf16')
+    rng = np.random.default_rng(units)
+    for n in (1, 17, 50):
+        x = rng.normal(0, 2, (n, 29, n_in)).astype(np.float32)
+        if delta:
+            d = np.diff(x, axis=1, prepend=x[:, :1])
+            x = np.concatenate([x, d], axis=2)
+        assert np.abs(eng.predict(x) - keras_gru.predict(x, w)).max() <= 1e-2
+    eng.close()
+
+
 def test_bf16_feature_rows_equal_float32_rows_rounded_at_the_load(stock_weights):
     """ring_precision='bf16' (BASELINE configs[4]: "bf16 MFCC+GRU"): the MFCC stage rounds each row to bf16 where it
     stores it (round to nearest even) -- the same rounding the bf16 network applies to float32 rows when it loads
