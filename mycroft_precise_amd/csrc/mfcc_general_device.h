@@ -419,10 +419,15 @@ __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R*
     for (int kb = (nnew > slots ? nnew - slots : 0) + par; kb < nnew; kb += n_par) {
         const int vb = kb * hop;
         R coeff[1];
+        // (the lane-dependent invariants of a frame -- bit-reversed addresses, table offsets -- are recomputed per frame: hoisted
+        //  out of this one-or-two-trip loop they lived in registers the frame itself needs, and the n_fft = 1024 float64 kernel
+        //  spilled 80 bytes per lane to scratch, reloaded with 26 loads per frame)
+        int lane_k = lane;
+        asm volatile("" : "+v"(lane_k));
         if constexpr (BLUE) {
-            general_frame_blue<R, BITS>(a.tab, S, lane, [&](int n) -> R { return n < flen ? (R)vsample(vb + n) * RealK<R>::INV_I16 : R(0); }, coeff);
+            general_frame_blue<R, BITS>(a.tab, S, lane_k, [&](int n) -> R { return n < flen ? (R)vsample(vb + n) * RealK<R>::INV_I16 : R(0); }, coeff);
         } else if (pairs) {
-            general_frame<R, BITS>(a.tab, S, lane, [&](int n) -> cplx<R> {
+            general_frame<R, BITS>(a.tab, S, lane_k, [&](int n) -> cplx<R> {
                 const int m = 2 * n < flen ? 2 * n : 0, v = vb + m;           // (beyond the frame: a valid pair, zeroed below)
                 const int16_t* p = v < q ? car + v : row + (v - q);
                 const int w2 = *reinterpret_cast<const int*>(p);
@@ -430,7 +435,7 @@ __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R*
                 return cplx<R>{in ? (R)(int)(short)(w2 & 0xffff) * RealK<R>::INV_I16 : R(0), in ? (R)(w2 >> 16) * RealK<R>::INV_I16 : R(0)};
             }, coeff);
         } else {
-            general_frame<R, BITS>(a.tab, S, lane, [&](int n) -> cplx<R> {
+            general_frame<R, BITS>(a.tab, S, lane_k, [&](int n) -> cplx<R> {
                 return cplx<R>{2 * n < flen ? (R)vsample(vb + 2 * n) * RealK<R>::INV_I16 : R(0),
                                2 * n + 1 < flen ? (R)vsample(vb + 2 * n + 1) * RealK<R>::INV_I16 : R(0)};
             }, coeff);
@@ -493,8 +498,10 @@ __device__ __forceinline__ void general_offline(const GeneralOfflineArgs<R>& a, 
         const double* x = a.audio + fr * geo.hop;
         R coeff[1];
         const int flen = geo.frame_len;
-        if constexpr (BLUE) general_frame_blue<R, BITS>(a.tab, S, lane, [&](int n) -> R { return n < flen ? (R)x[n] : R(0); }, coeff);
-        else general_frame<R, BITS>(a.tab, S, lane, [&](int n) -> cplx<R> {
+        int lane_k = lane;                                  // (per-frame recomputation of the lane invariants: general_stream)
+        asm volatile("" : "+v"(lane_k));
+        if constexpr (BLUE) general_frame_blue<R, BITS>(a.tab, S, lane_k, [&](int n) -> R { return n < flen ? (R)x[n] : R(0); }, coeff);
+        else general_frame<R, BITS>(a.tab, S, lane_k, [&](int n) -> cplx<R> {
             const int m0 = 2 * n, m1 = 2 * n + 1;                             // (clamped indices: plain loads, selected afterwards)
             const double x0 = x[m0 < flen ? m0 : 0], x1 = x[m1 < flen ? m1 : 0];
             return cplx<R>{m0 < flen ? (R)x0 : R(0), m1 < flen ? (R)x1 : R(0)};

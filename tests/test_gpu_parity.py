@@ -1294,6 +1294,13 @@ def test_capacity_batch_65536_streams_properties(stock_weights, tiling):
     two.close()
 
 
+def test_full_batch_float32_front_end_4096_streams_properties(stock_weights):
+    """mfcc_precision='f32' beside the float32 network in the fused launch at the BASELINE batch size: the size-independent
+    properties (identical input => bit-identical output at any position, clear + replay) -- the float32 frame role is the
+    one whose results turned out to depend on what runs beside it (profiles/round4/r4v_b20_fused_corruption.log)."""
+    _full_size_run(stock_weights, 4096, 33, 16, TOL_RAW, mfcc_precision='f32')
+
+
 def test_full_batch_general_front_end_4096_streams_properties():
     """A non-stock .params file at the BASELINE batch size (params.py:28-118: n_fft 1024, 40 filters, 20 coefficients --
     the general front end, 32-float feature rows, the four-wave network over them): the size-independent properties and
