@@ -69,3 +69,8 @@ with open(out + '/%s_pmc_summary.csv' % tag, 'w') as fo:
             line = '%s,%s,%d,%.6g' % (k, c, len(v), sum(v) / len(v))
             print(line); fo.write(line + '\n')
 PY
+# gpurun merges at most 64 MiB back: keep the summaries and ONE raw kernel trace (gzip), drop the counter dumps
+cd $OUT
+for f in $(find ${tag}_prof -name "*kernel_trace.csv" 2>/dev/null); do gzip -c "$f" > ${tag}_kernel_trace.csv.gz; done
+rm -rf ${tag}_prof ${tag}_pmc_[0-9]
+du -sh $OUT | tail -1
