@@ -978,3 +978,9 @@ extern "C" int pe_debug_read_wave_times(unsigned long long* out, int n_waves) {
 #endif
 
 }  // namespace pe
+
+#ifdef PE_DBG_CAPTURE
+extern "C" int pe_dbg_capture_read(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pe::pe_dbg_capture), bytes < sizeof(pe::pe_dbg_capture) ? bytes : sizeof(pe::pe_dbg_capture));
+}
+#endif

@@ -257,32 +257,51 @@ __device__ __forceinline__ LaneRuns lane_runs(const pe_wave::Tab<R>& t, int lane
 
 template <class R, class SH>
 __device__ __forceinline__ R mfcc_wave_frame(const pe_wave::Tab<R>& t, const pe_wave::LaneConsts<R>& lc, const LaneRuns& lr, R* S, const int lane,
-                                             const int n_filt, const int n_mfcc, pe_wave::Regs<R>& v, const R pscale, const int log_mode) {
+                                             const int n_filt, const int n_mfcc, pe_wave::Regs<R>& v, const R pscale, const int log_mode, unsigned* dbgw = nullptr) {
     using K = RealK<R>;
     using namespace pe_wave;
     cx<R>* X = reinterpret_cast<cx<R>*>(S);
+#ifdef PE_DBG_CAPTURE
+    auto dbg_sum = [&](int w) {            // order-independent checksum of the lane's eight transform registers
+        if (!dbgw) return;
+        unsigned h = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h += __float_as_uint((float)v.re[r]) * (2u * r + 3u) + __float_as_uint((float)v.im[r]) * (2u * r + 11u);
+        dbgw[w] = h;
+    };
+#else
+    auto dbg_sum = [&](int) {};
+#endif
+    dbg_sum(0);
     PE_T(3);
 #if PE_TW_LDS == 2
     { radix4(v); twiddle3(v, lds_read(&t.tw1[lane]), lds_read(&t.tw1[64 + lane]), lds_read(&t.tw1[128 + lane])); }
 #else
     pass_a(v, lc);
 #endif
+    dbg_sum(1);
 #if PE_XCHG_B_LDS
     exchange_lds(v, X, lane, 4);
 #else
     exchange_b(v);
 #endif
+    dbg_sum(2);
 #if PE_TW_LDS
     { radix4(v); const int m = lane & 15; twiddle3(v, lds_read(&t.tw2[m]), lds_read(&t.tw2[16 + m]), lds_read(&t.tw2[32 + m])); }
     exchange_lds(v, X, lane, 2);
     { radix4(v); const int d = lane & 3; twiddle3(v, lds_read(&t.tw3[d]), lds_read(&t.tw3[4 + d]), lds_read(&t.tw3[8 + d])); }
 #else
     pass_b(v, lc);
+    dbg_sum(3);
     exchange_lds(v, X, lane, 2);
+    dbg_sum(4);
     pass_c(v, lc);
 #endif
+    dbg_sum(5);
     exchange_lds(v, X, lane, 0);
+    dbg_sum(6);
     pass_d(v);
+    dbg_sum(7);
     PE_T(4);
     // mirror exchange: bins 256 - p of this lane's registers 0 / 1 are registers 3 / 2 of the partner lane
     X[xchg_index(lane, 0)] = cx<R>{v.re[2], v.im[2]};
@@ -438,6 +457,10 @@ __device__ __attribute__((noinline)) RawFrame fetch_frame_slow(const int16_t* ca
     return out;
 }
 
+#ifdef PE_DBG_CAPTURE      // bisecting aid (tools/gpu_b20_debug.py): what every frame task of a launch consumed and produced
+constexpr int kDbgStreams = 8192, kDbgWords = 16;
+__device__ unsigned pe_dbg_capture[kDbgStreams * 2 * 64 * kDbgWords];
+#endif
 // SIMD of the compute unit this wave runs on (HW_ID.SIMD_ID: s_getreg_b32 hwreg(HW_REG_HW_ID, 4, 2))
 __device__ __forceinline__ int wave_simd_id() { return (int)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3); }
 
@@ -650,15 +673,29 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
         for (;;) {
             pe_wave::Regs<R> v;
             convert(pcm, v);                                            // the wait for this frame's samples
+#ifdef PE_DBG_CAPTURE
+            const long long dbg_s = (cur.car - a.carry) / kCarryCap;
+            const int dbg_kb = cur.vb / hop;
+            unsigned* const dbg = dbg_s < kDbgStreams ? pe_dbg_capture + ((size_t)(dbg_s * 2 + (dbg_kb & 1)) * 64 + lane) * kDbgWords : nullptr;
+            if (dbg) { dbg[0] = (unsigned)pcm.a0; dbg[1] = (unsigned)pcm.a1; dbg[2] = (unsigned)pcm.a2; dbg[3] = (unsigned)pcm.a3; }
+#endif
             asm volatile("" : "+v"(v.re[0]), "+v"(v.re[3]) : : "memory");  // (the store below must stay below that wait)
             __builtin_amdgcn_sched_barrier(0);
             if (row_prev) store_row();
             FrameTask<R> nxt;
             const bool have_next = next_frame(nxt);
             if (have_next) pcm = request_pcm(nxt);                      // lands while the current frame is transformed
+#ifdef PE_DBG_CAPTURE
+            const R coeff = mfcc_wave_frame<R, SH>(tab, lc, lr, S, lane, geo.n_filt, geo.n_mfcc, v, K::PSCALE_I16, geo.log_mode, dbg ? dbg + 8 : nullptr);
+#else
             const R coeff = mfcc_wave_frame<R, SH>(tab, lc, lr, S, lane, geo.n_filt, geo.n_mfcc, v, K::PSCALE_I16, geo.log_mode);
+#endif
             // coefficient c sits in lanes 4c .. 4c+3: lane c fetches it, and the first 16 lanes store the row as ONE
             // contiguous 64-byte (bf16: 32-byte) write -- 13 coefficients + zero padding, as the clear kernel left it
+#ifdef PE_DBG_CAPTURE
+            if (dbg) { dbg[4] = __float_as_uint((float)coeff); dbg[5] = __float_as_uint((float)S[pe_wave::kLogMelOff + (lane < geo.n_filt ? lane : 0)]);
+                       dbg[6] = __float_as_uint((float)S[pe_wave::kPowerOff + lane]); dbg[7] = __float_as_uint((float)S[pe_wave::kPartOff + lane]); }
+#endif
             const float mine = (lane >> 2) < geo.n_mfcc ? (float)coeff : 0.0f;
             const float xf = __shfl(mine, (lane & 15) * 4, 64);
             xf_prev = xf; row_prev = cur.ring_row;
