@@ -600,7 +600,7 @@ def main():
         gru_name = ((('gru_cw_kernel' if retiled else 'gru_mw_kernel<5, false>') if four_waves else
                      ('gru_v_kernel<1>' if retiled else 'gru_small_kernel<5, 1, false>')) if args.gru_precision == 'f32'
                     else 'gru_bf16_kernel<1>')
-        x3 = args.gru_precision == 'f32' and stock and (args.gru_tiling == 2 or (args.gru_tiling < 0 and tiles >= 8 * n_cus))
+        x3 = args.gru_precision == 'f32' and stock and (args.gru_tiling == 2 or (args.gru_tiling < 0 and tiles > 4 * n_cus))
         if x3:
             fused_name = '%s then gru_x3_kernel<1> (two dependent launches)' % mfcc_kernel
             gru_name = 'gru_x3_kernel<1>'

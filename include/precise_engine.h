@@ -244,8 +244,9 @@ int pe_set_gru_waves(pe_engine* e, int32_t waves_per_tile);
  *       to the float32 value exactly, six piece products per multiplication, float32 accumulate / gates / state -- the
  *       float32 tolerance, at the float32 kernels' distance to a float64 evaluation.  <= 20 units, <= 15 inputs, no
  *       use_delta (PE_ERR_UNSUPPORTED otherwise).  On gfx950 an f32-input MFMA keeps its whole SIMD from issuing while
- *       it runs and a bf16 MFMA does not; automatic from eight tiles per compute unit on (32 768 streams on MI355X),
- *       where it takes two launches per update instead of the fused one and is still faster.
+ *       it runs and a bf16 MFMA does not; automatic for engines with more stream tiles than the machine has SIMDs (more
+ *       than four per compute unit: above 16 384 streams on MI355X), where it takes two launches per update instead of
+ *       the fused one and is still faster.
  * Every kernel shape of ONE form agrees bit for bit (pe_update / pe_update_many / pe_predict / pe_evaluate, one or four
  * waves, fused or not); the forms agree to float32 summation order (<= 1e-6 on the probability).  Ignored by the other
  * networks (bf16, wide, projection rows); use_delta models of the stock width follow 0 / 1.

@@ -373,7 +373,7 @@ class HipEngine:
 
     def set_gru_tiling(self, tiling: int):
         """-1 automatic, 0 classic four-tile layout, 1 re-tiled stock width (csrc/gru_cw_device.h), 2 float32 products on the
-        bf16 matrix pipe (csrc/gru_x3_device.h; automatic from eight tiles per compute unit on)."""
+        bf16 matrix pipe (csrc/gru_x3_device.h; automatic above four stream tiles per compute unit)."""
         self._check(self._lib.pe_set_gru_tiling(self._h, int(tiling)))
 
     def gru_tiling(self) -> int:

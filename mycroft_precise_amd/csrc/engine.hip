@@ -56,7 +56,7 @@ struct pe_engine {
     int row_floats = kRowFloats;   // floats per feature row: 32 when a frame has 17..32 coefficients
     int carry_cap = kCarryCap;     // int16 samples of leftover PCM kept per stream (>= frame length)
     GeneralTables gtab{};
-    int gru_tiling = -1;    // -1 = auto (stock width re-tiled while tiles <= 2 CUs; XDL form from 8 tiles per CU on), 0 = classic, 1 = re-tiled (gru_cw_device.h), 2 = XDL form (gru_x3_device.h)
+    int gru_tiling = -1;    // -1 = auto (stock width re-tiled while tiles <= 2 CUs; XDL form above 4 tiles per CU), 0 = classic, 1 = re-tiled (gru_cw_device.h), 2 = XDL form (gru_x3_device.h)
     float* cw_blob = nullptr;
     int n_cus = 256;        // compute units of the device (MI355X: 256)
     float* ring = nullptr;
@@ -707,13 +707,14 @@ GruArgs gru_args(const pe_engine* e) {
     // regime (two-pass MFMAs + reductions: 81.0 vs 77.3 us at 65 536 streams), so an engine takes ONE tiling for all
     // of its launches -- every shape of a tiling agrees bit for bit -- by its size.  The critical-wave kernel still
     // wins with two tiles per compute unit (8192 streams, fused: 272 vs 254 M windows/s against one wave per tile).
-    // Engines that fill the machine (>= 8 tiles per compute unit: 32 768 streams on MI355X) take the XDL form of the float32
-    // network (gru_x3_device.h: every operand as three bf16 pieces): an f32-input MFMA keeps its whole SIMD from issuing for
-    // its 8 passes, the bf16 MFMAs cost half the cycles for the same products and do not.  Measured per update, two
-    // launches against the fused classic tiling: 69 vs 79 us at 32 768 streams, 130 vs 154 us at 65 536 (48 vs 43 us at
-    // 16 384: below, the missing fused launch costs more than the cheaper network saves).
+    // Engines with more stream tiles than the machine has SIMDs (> 4 tiles per compute unit: more than 16 384 streams on
+    // MI355X) take the XDL form of the float32 network (gru_x3_device.h: every operand as three bf16 pieces): an f32-input
+    // MFMA keeps its whole SIMD from issuing for its 8 passes, the bf16 MFMAs cost half the cycles for the same products and
+    // do not.  Measured per update, two launches against the fused classic tiling: 54 vs 69 us at 20 480 streams, 59 vs 69 at
+    // 24 576, 69 vs 79 at 32 768, 128 vs 154 us at 65 536 -- and 48 vs 43 us at 16 384 (one tile per SIMD: the classic network
+    // still runs in one round of waves, and the missing fused launch costs more than the cheaper network saves).
     const bool x3_ok = e->x3_blob && !a.bf16 && !e->wide && !a.proj_ring && e->row_floats == kRowFloats && e->gru_waves != 16;
-    a.x3 = x3_ok && (e->gru_tiling == 2 || (e->gru_tiling < 0 && e->n_tiles >= 8 * e->n_cus)) ? e->x3_blob : nullptr;
+    a.x3 = x3_ok && (e->gru_tiling == 2 || (e->gru_tiling < 0 && e->n_tiles > 4 * e->n_cus)) ? e->x3_blob : nullptr;
     const bool cw_ok = e->cw_blob && e->row_floats == kRowFloats && !a.proj_ring && !a.bf16 && !a.x3 && !e->wide && e->gru_waves != 16;
     const bool retile = cw_ok && (e->gru_tiling == 1 || (e->gru_tiling < 0 && e->n_tiles <= 2 * e->n_cus));
     const int auto_waves = retile ? (e->n_tiles <= 2 * e->n_cus ? 4 : 1) : (e->n_tiles <= e->n_cus ? 4 : 1);

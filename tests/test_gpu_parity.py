@@ -1266,10 +1266,10 @@ def test_x3_refuses_what_it_has_no_kernel_for():
 
 
 def test_x3_is_the_automatic_form_of_engines_that_fill_the_machine(stock_weights):
-    """From eight tiles per compute unit on (32 768 streams on MI355X) the float32 network takes the XDL form by itself;
-    smaller engines keep the f32-input MFMA kernels (their fused launch is worth more than the cheaper network)."""
+    """With more stream tiles than the machine has SIMDs (above 16 384 streams on MI355X) the float32 network takes the XDL form
+    by itself; smaller engines keep the f32-input MFMA kernels (their fused launch is worth more than the cheaper network)."""
     from mycroft_precise_amd._lib import HipEngine
-    for n, want in ((4096, 1), (16384, 0), (32768, 2), (65536, 2)):
+    for n, want in ((4096, 1), (16384, 0), (20480, 2), (32768, 2), (65536, 2)):
         eng = HipEngine(P.pr, stock_weights, n_streams=n)
         assert eng.gru_tiling() == want, n
         eng.set_gru_tiling(0)
