@@ -241,3 +241,64 @@ def test_keras_restatement_against_a_real_keras_fixture_when_present():
     g, w = np.load(path), np.load(os.path.join(GOLDEN_DIR, 'weights_stock_seed42.npz'))
     weights = {'gru': [(w['kernel'], w['recurrent_kernel'], w['bias'])], 'dense_kernel': w['dense_kernel'], 'dense_bias': w['dense_bias']}
     assert np.abs(keras_gru.predict(g['inputs'], weights) - g['outputs']).max() <= 1e-6
+
+
+def test_three_bf16_pieces_carry_a_float32_product(stock_weights):
+    """The arithmetic claim behind pe_set_gru_tiling 2 (csrc/gru_x3_device.h), restated in numpy: a float32 value is the exact
+    sum of three bf16 pieces (round to nearest even of the running remainder), and the six piece products
+    w_hi v_hi + w_hi v_mid + w_mid v_hi + w_mid v_mid + w_hi v_lo + w_lo v_hi stand for the float32 product to within one
+    float32 rounding -- so a GRU window evaluated that way sits as close to a float64 evaluation as the float32 oracle does."""
+    from oracle import keras_gru
+
+    def to_bf16(v):                      # round to nearest even, as v_cvt_pk_bf16_f32 does
+        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+        return (((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)).view(np.float32)
+
+    def split3(v):
+        r, out = v.astype(np.float32), []
+        for _ in range(3):
+            p = to_bf16(r)
+            out.append(p)
+            r = (r - p).astype(np.float32)          # exact
+        return out
+
+    rng = np.random.default_rng(7)
+    v = np.concatenate([rng.normal(0, 3, 5000), rng.normal(0, 1e-3, 5000), rng.uniform(-40, 40, 5000)]).astype(np.float32)
+    hi, mid, lo = split3(v)
+    assert np.array_equal((hi.astype(np.float64) + mid + lo).astype(np.float32), v)                   # the split is exact
+    w = rng.normal(0, 0.5, v.shape).astype(np.float32)
+    wp, vp = split3(w), [hi, mid, lo]
+    six = sum(wp[i].astype(np.float64) * vp[j] for i, j in ((0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (2, 0)))
+    exact = w.astype(np.float64) * v
+    assert np.all(np.abs(six - exact) <= 2.0 ** -22 * np.abs(exact) + 1e-300)                          # dropped terms: < 2^-22 |w v|
+
+    # a whole window: stock network, 29 x 13 features of realistic size
+    g = stock_weights['gru'][0]
+    W, U, b = g
+    H = U.shape[0]
+    x = (rng.standard_normal((512, 29, 13)) * 4).astype(np.float32)
+    x[:, :, 0] = rng.uniform(-25, 10, (512, 29))
+    terms = ((0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (2, 0))
+
+    def mm(a, B):
+        ap, Bp = split3(a), split3(B)
+        acc = np.zeros((a.shape[0], B.shape[1]), np.float32)
+        for i, j in terms:
+            acc = (acc + ap[i].astype(np.float64) @ Bp[j].astype(np.float64)).astype(np.float32)
+        return acc
+
+    h = np.zeros((512, H), np.float32)
+    for t in range(29):
+        ax = mm(x[:, t], W) + b
+        ah = mm(h, U[:, :2 * H])
+        z = keras_gru.hard_sigmoid((ax[:, :H] + ah[:, :H]).astype(np.float32))
+        r = keras_gru.hard_sigmoid((ax[:, H:2 * H] + ah[:, H:]).astype(np.float32))
+        hh = (ax[:, 2 * H:] + mm((r * h).astype(np.float32), U[:, 2 * H:])).astype(np.float32)
+        h = (z * h + (np.float32(1) - z) * hh).astype(np.float32)
+    logit = h @ stock_weights['dense_kernel'] + stock_weights['dense_bias']
+    p_x3 = (1.0 / (1.0 + np.exp(-logit.astype(np.float64))))[:, 0]
+    p32 = keras_gru.predict(x, stock_weights)[:, 0].astype(np.float64)
+    p64 = keras_gru.predict(x, stock_weights, dtype=np.float64)[:, 0]
+    d_x3, d_32 = np.abs(p_x3 - p64).max(), np.abs(p32 - p64).max()
+    assert d_x3 <= 2 * d_32 + 1e-6, (d_x3, d_32)
+    assert np.abs(p_x3 - p32).max() <= 2e-5                                                             # the float32 guard of the GPU tests
