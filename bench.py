@@ -251,7 +251,7 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
                  params_kw=None, roofline_kind=None, gru_tiling=-1):
     """One non-headline configuration on this GPU (N = 1 only, after the headline's timed region): the same step
     definition, its own roofline object, and a parity spot-check of the timed region's last probabilities against
-    the oracle (the checker: never inside a timed region) on the first 8 streams.
+    the oracle (the checker: never inside a timed region) on the first 256 streams (32 for the wide network).
     params_kw: ListenerParams overrides (n_fft / n_filt / n_mfcc ...: the general front end, params.py:28-118).
     roofline_kind: 'hbm' (fused launch vs HBM), 'mfma' (network launch vs fp32 MFMA), 'mfma_fused' (fused launch vs fp32
     MFMA: the capacity point, where the update IS the network + MFCC roles of one launch), 'mfma_update_x3' (the same for
@@ -290,7 +290,9 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
     run(warmup, steps)
     wait_for_gpu()
     elapsed = time.perf_counter() - t0
-    got = out[:8].cpu().numpy().astype(np.float64)
+    n_check = 256 if stock else 32          # streams replayed by the oracle afterwards (the wide network costs it 35 Mflop per window)
+    n_check = min(n_check, streams)
+    got = out[:n_check].cpu().numpy().astype(np.float64)
     # launch durations: HIP events on the launch stream (bracket of back-to-back updates; the two stages apart)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n_b = min(steps, 100)
@@ -310,9 +312,9 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
     engine.set_timing(False)
     engine.close()
     gru_ms, mfcc_ms = float(np.mean(g_ms)), float(np.mean(m_ms))
-    # parity spot-check: the oracle replays the same chunks for streams 0..7
-    host = pcm[:, :8].cpu().numpy()
-    oracle = oracle_listener.BatchedOracle(weights, 8, opr) if opr is not None else oracle_listener.BatchedOracle(weights, 8)
+    # parity spot-check: the oracle replays the same chunks for streams 0..n_check-1
+    host = pcm[:, :n_check].cpu().numpy()
+    oracle = oracle_listener.BatchedOracle(weights, n_check, opr) if opr is not None else oracle_listener.BatchedOracle(weights, n_check)
     want = None
     for i in range(warmup + steps):
         want = oracle.update_raw(host[i % n_res])
@@ -324,7 +326,7 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
     if roofline_kind in ('hbm', 'hbm_mfcc'):
         ms = update_ms if roofline_kind == 'hbm' else mfcc_ms
         ach = bytes_per_window * streams / (ms * 1e-3) / 1e9
-        kern = ('fused_update_bf16_kernel<%s, ShapeStock>' % mfcc_name if roofline_kind == 'hbm'
+        kern = ('fused_update_bf16_kernel%s<%s, ShapeStock>' % ('_nopk' if mfcc_name == 'float' else '', mfcc_name) if roofline_kind == 'hbm'
                 else 'mfcc_general_stream_kernel<%s> (one HIP event pair per launch)' % mfcc_name)
         roof = {'kernel': kern, 'bound': 'hbm',
                 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
@@ -345,16 +347,108 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
            'steps': steps, 'warmup': warmup, 'dtype': gru_precision,
            'config': {'workload': name, 'streams_per_gpu': streams, 'gru': 'H=%s' % ','.join(map(str, units)),
                       'mfcc_dtype': mfcc_precision, 'feature_rows': ring_precision,
-                      'gru_form': {-1: 'n/a', 0: 'classic tiling, v_mfma_f32_16x16x4_f32', 1: 're-tiled stock width, v_mfma_f32_16x16x4_f32',
-                                   2: 'float32 operands as 3 x bf16 pieces, 6 piece products on v_mfma_f32_16x16x32_bf16, float32 accumulate / gates / state'}[tiling_used],
+                      'gru_form': ({0: 'bf16 operands, eight gate values per lane (gru_bf16_device.h)', 1: 'bf16 operands, five gate values per lane (gru_b20_device.h)'}[tiling_used]
+                                   if gru_precision == 'bf16' else
+                                   {-1: 'streamed-weight wide kernel, v_mfma_f32_16x16x4_f32', 0: 'classic tiling, v_mfma_f32_16x16x4_f32', 1: 're-tiled stock width, v_mfma_f32_16x16x4_f32',
+                                    2: 'float32 operands as 3 x bf16 pieces, 6 piece products on v_mfma_f32_16x16x32_bf16, float32 accumulate / gates / state'}[tiling_used]),
                       'resident_pcm_mb': n_res * chunk_bytes / 1e6},
            'stage_ms': {'update_back_to_back': update_ms, 'mfcc_launch_alone': mfcc_ms, 'network_launch_alone': gru_ms},
            'roofline': roof,
-           'parity': {'max_abs_err': err, 'tol': tol, 'streams_checked': 8, 'ok': bool(err <= tol),
+           'parity': {'max_abs_err': err, 'tol': tol, 'streams_checked': n_check, 'ok': bool(err <= tol),
                       'against': 'oracle.listener.BatchedOracle on the same chunks (checker, outside the timed region)'}}
     if params_kw:
         res['config']['listener_params'] = dict(params_kw)
     return res
+
+
+PCIE_GEN5_X16_GBS = 63.0                       # one direction, the number DESIGN.md section 5 prices the host-fed path against
+
+
+def host_fed_extra(device, dev_index, streams=4096, steps=300, warmup=30):
+    """The host-fed path: chunks arrive in HOST memory, as the reference's engine receives them
+    (precise/scripts/engine.py:60-63, runner/precise_runner/runner.py:62-67) -- pe_update_async / pe_wait with the PCM in
+    pinned buffers of the engine (pe_host_alloc: zero-copy DMA), three updates in flight, chunk u + 1 crossing PCIe under
+    update u.  Reported: windows/s, achieved PCIe GB/s (2048 B per window host -> device), bit-identity with the
+    device-resident path on the same chunks; beside it the same loop from pageable numpy arrays and the synchronous pe_update."""
+    weights = synth.make_weights()
+    engine = HipEngine(pr, weights, n_streams=streams, device=dev_index)
+    n_res = 8
+    dev_pcm = synth_pcm_device(n_res, streams, 0, device)
+    host_pcm = dev_pcm.cpu().numpy()                                   # pageable copy
+    bufs = [engine.host_array((streams, CHUNK), '<i2') for _ in range(n_res)]
+    for b, h in zip(bufs, host_pcm):
+        b[:] = h
+    outs = engine.host_array((3, streams), np.float32)
+
+    def loop(n, first, src):
+        for i in range(n):
+            engine.update_async(src[(first + i) % n_res], outs[i % 3])
+        engine.wait()
+
+    loop(warmup, 0, bufs)
+    t0 = time.perf_counter()
+    loop(steps, warmup, bufs)
+    dt = time.perf_counter() - t0
+    last = outs[(steps - 1) % 3].copy()
+    # the same chunks through the device-resident entry point on a second engine: the bits must agree
+    ref = HipEngine(pr, weights, n_streams=streams, device=dev_index)
+    out_d = torch.zeros((streams,), dtype=torch.float32, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    for i in range(warmup + steps):
+        ref.update_device(dev_pcm[i % n_res].data_ptr(), CHUNK, out_d.data_ptr(), st)
+    torch.cuda.synchronize()
+    same = bool(np.array_equal(out_d.cpu().numpy(), last))
+    ref.close()
+    # pageable sources (copied through the engine's pinned staging at the call), and the synchronous pe_update
+    n2 = max(20, steps // 4)
+    pageable = [host_pcm[i] for i in range(n_res)]
+    loop(10, 0, pageable)
+    t1 = time.perf_counter()
+    loop(n2, 10, pageable)
+    dt_pageable = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    for i in range(n2):
+        engine.update(pageable[i % n_res])
+    dt_sync = time.perf_counter() - t2
+    engine.close()
+    gbs = streams * CHUNK * 2 * steps / dt / 1e9
+    return {'name': 'host-fed: stock GRU fp32 + f64 MFCC, batch=%d streams, chunks in pinned HOST memory (pe_update_async, 3 updates in flight)' % streams,
+            'value': streams * steps / dt, 'unit': 'windows/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
+            'realtime_streams': streams * steps / dt / REALTIME_WINDOWS_PER_S,
+            'pcie': {'bound': 'pcie', 'achieved': gbs, 'peak': PCIE_GEN5_X16_GBS, 'unit': 'GB/s', 'frac': gbs / PCIE_GEN5_X16_GBS,
+                     'algorithmic': '2048 B/window host -> device + 4 B/window back'},
+            'bit_identical_to_device_resident_path': same,
+            'pageable_sources': {'value': streams * n2 / dt_pageable, 'unit': 'windows/s', 'ms_per_step': 1e3 * dt_pageable / n2,
+                                 'note': 'numpy arrays in pageable memory: one CPU copy into the pinned ring per update'},
+            'synchronous_pe_update': {'value': streams * n2 / dt_sync, 'unit': 'windows/s', 'ms_per_step': 1e3 * dt_sync / n2,
+                                      'note': 'hipMemcpy -> launch -> hipMemcpy, nothing overlapped (the drop-in Listener / BatchedListener.update path)'},
+            'config': {'workload': 'host-fed stock configuration', 'streams_per_gpu': streams, 'resident_pcm_mb': 0.0}}
+
+
+def single_stream_latency_extra(n_calls=400):
+    """BASELINE configs[0] on the GPU side: ONE stream through the drop-in Listener.update(bytes) (the call precise-engine makes
+    per 2048-byte chunk, scripts/engine.py:60-63) -- host bytes in, decoded probability out, per-call latency."""
+    import tempfile
+    from mycroft_precise_amd.model import save_weights
+    from mycroft_precise_amd.network_runner import Listener
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, 'synthetic.npz')
+        save_weights(path, synth.make_weights())
+        lis = Listener(path, 2 * CHUNK)
+        pcm = synth.stream_pcm(0, 64 * CHUNK)
+        chunks = [pcm[i * CHUNK:(i + 1) * CHUNK].tobytes() for i in range(64)]
+        for c in chunks[:40]:
+            lis.update(c)
+        lat = []
+        for i in range(n_calls):
+            t0 = time.perf_counter()
+            lis.update(chunks[i % 64])
+            lat.append(time.perf_counter() - t0)
+    lat = np.array(lat) * 1e6
+    return {'name': 'configs[0] on the GPU: 1 stream, Listener.update(2048 bytes) per call (host bytes in, decoded probability out)',
+            'value': 1e6 / float(np.mean(lat)), 'unit': 'windows/s', 'latency_us': {'median': float(np.median(lat)), 'mean': float(np.mean(lat)), 'p99': float(np.percentile(lat, 99))},
+            'realtime_budget_us': 64000.0, 'steps': n_calls,
+            'config': {'workload': 'one stream, one 2048-byte chunk per call, synchronous', 'streams_per_gpu': 1}}
 
 
 def main():
@@ -482,6 +576,7 @@ def main():
         dist.all_gather(every, mine)             # every rank's own clock around the same region
         rank_ms = [1e3 * float(x.item()) / steps for x in every]
         elapsed = max(float(x.item()) for x in every)
+    assert ranks_seen == world, 'the communicator reports %d ranks, the launcher %d' % (ranks_seen, world)
     if rank == 0:
         assert gathered.shape == (steps, n_global)
     finite = bool(torch.isfinite(gathered if rank == 0 else probs).all().item())
@@ -564,6 +659,13 @@ def main():
                 extras.append(extra_config(device=device, dev_index=dev_index, **cfg))
             except Exception as ex:                                  # noqa: BLE001  (an extra must not cost the headline line)
                 extras.append({'name': cfg['name'], 'error': repr(ex)})
+        for label, fn in (('host-fed', lambda: host_fed_extra(device, dev_index)), ('configs[0]', single_stream_latency_extra)):
+            if only and only not in label:
+                continue
+            try:
+                extras.append(fn())
+            except Exception as ex:                                  # noqa: BLE001
+                extras.append({'name': label, 'error': repr(ex)})
 
     def pmc_traffic(kernel):
         """HBM bytes per launch from the committed rocprofv3 PMC summary (bench.py cannot collect PMC
@@ -594,9 +696,10 @@ def main():
         tiles = (B + 15) // 16
         retiled = (tiles <= 2 * n_cus) if args.gru_tiling < 0 else args.gru_tiling == 1
         four_waves = (tiles <= (2 * n_cus if retiled else n_cus)) if not args.gru_waves else args.gru_waves == 4
-        mfcc_kernel = 'mfcc_kernel<%s, ShapeStock, true>' % mfcc_name
-        fused_name = ('fused_update_kernel<%s, ShapeStock, 5, %s, false, %s>' % (mfcc_name, 'true' if four_waves else 'false', 'true' if retiled else 'false')
-                      if args.gru_precision == 'f32' else 'fused_update_bf16_kernel<%s, ShapeStock>' % mfcc_name)
+        nopk = '_nopk' if mfcc_name == 'float' else ''        # kernels.hip: the float32 frame role's kernels are compiled without packed float32
+        mfcc_kernel = 'mfcc_kernel%s<%s, ShapeStock, true>' % (nopk, mfcc_name)
+        fused_name = ('fused_update_kernel%s<%s, ShapeStock, 5, %s, false, %s>' % (nopk, mfcc_name, 'true' if four_waves else 'false', 'true' if retiled else 'false')
+                      if args.gru_precision == 'f32' else 'fused_update_bf16_kernel%s<%s, ShapeStock>' % (nopk, mfcc_name))
         gru_name = ((('gru_cw_kernel' if retiled else 'gru_mw_kernel<5, false>') if four_waves else
                      ('gru_v_kernel<1>' if retiled else 'gru_small_kernel<5, 1, false>')) if args.gru_precision == 'f32'
                     else 'gru_bf16_kernel<1>')
@@ -640,6 +743,7 @@ def main():
             'resident_pcm': {'slabs': n_res, 'mb': n_res * chunk_bytes / 1e6,
                              'note': 'distinct [B][1024] int16 slabs cycled by every pass; independent of --steps'},
             'ranks_seen': ranks_seen, 'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms)},
+            'collective_backend': (dist.get_backend() if world > 1 else None),      # 'nccl' = RCCL over xGMI (one device per rank)
             # dominant kernel of the timed region: the fused launch (GRU role is its long pole)
             'roofline': ({'kernel': fused_name, 'bound': 'hbm', 'achieved': gbs_w(fused_ms), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                           'frac': gbs_w(fused_ms) / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': fused_ms,

@@ -4,4 +4,6 @@ Not a component: one line that hands the import system the MI355X module under t
 import sys
 import mycroft_precise_amd.scripts.engine as _impl
 
+if __name__ == '__main__':      # `python -m precise.scripts.engine model.pb 2048`: the alias runs as __main__, the implementation's own guard does not fire
+    sys.exit(_impl.main())
 sys.modules[__name__] = _impl

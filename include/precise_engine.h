@@ -22,13 +22,14 @@
 #ifndef PRECISE_ENGINE_H
 #define PRECISE_ENGINE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define PE_ABI_VERSION 4
+#define PE_ABI_VERSION 5
 
 typedef enum pe_status {
     PE_OK = 0,
@@ -121,6 +122,25 @@ int pe_clear(pe_engine* e, const uint8_t* mask);
 int pe_update(pe_engine* e, const int16_t* pcm_host, int32_t chunk_samples, float* raw_out_host);
 int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples,
                      float* raw_out_dev, void* hip_stream);
+
+/* Host-fed pipeline: the reference's engine is handed HOST bytes per chunk (precise/scripts/engine.py:60-63,
+ * runner/precise_runner/runner.py:62-67), and pe_update above is copy -> launch -> copy, one after the other.
+ * pe_update_async enqueues the same update and returns: the chunk of update u + 1 crosses PCIe (a copy stream of the
+ * engine's own) while update u runs (a compute stream of the engine's own), the probabilities come back behind the
+ * launch; up to 3 updates are in flight, a 4th call first delivers the oldest.  raw_out_host[n_streams] is valid after
+ * pe_wait (or once 3 more updates have been enqueued).  Results are bit-identical to pe_update / pe_update_device.
+ *   - pageable pcm_host / raw_out_host: copied through the engine's pinned staging ring at the call (the caller's PCM
+ *     buffer is free again when the call returns);
+ *   - buffers from pe_host_alloc (pinned, device-visible; freed by pe_host_free or pe_destroy): ZERO-COPY -- the DMA
+ *     reads / writes them directly, which is what reaches PCIe line rate (a CPU memcpy of 8 MB per update does not);
+ *     such a PCM buffer must stay untouched until pe_wait or until 3 more updates have been enqueued.
+ * Every other entry point that reads or moves the streams' state (pe_update*, pe_clear, pe_get_vectors, ...) first
+ * waits for the updates in flight, so the two styles may be mixed; callers that drive the *_device entry points on
+ * their own non-blocking stream synchronise that stream before switching to pe_update_async (as for pe_clear). */
+int pe_host_alloc(pe_engine* e, size_t bytes, void** out);
+int pe_host_free(pe_engine* e, void* p);
+int pe_update_async(pe_engine* e, const int16_t* pcm_host, int32_t chunk_samples, float* raw_out_host);
+int pe_wait(pe_engine* e);
 
 /* n_updates consecutive pe_update calls in two launches (results bit-identical): chunk u of stream s at
  * pcm[(u * n_streams + s) * chunk_samples], raw_out[u * n_streams + s].  First one launch computes every
@@ -248,9 +268,13 @@ int pe_set_gru_waves(pe_engine* e, int32_t waves_per_tile);
  *       than four per compute unit: above 16 384 streams on MI355X), where it takes two launches per update instead of
  *       the fused one and is still faster.
  * Every kernel shape of ONE form agrees bit for bit (pe_update / pe_update_many / pe_predict / pe_evaluate, one or four
- * waves, fused or not); the forms agree to float32 summation order (<= 1e-6 on the probability).  Ignored by the other
- * networks (bf16, wide, projection rows); use_delta models of the stock width follow 0 / 1.
- * pe_get_gru_tiling: the form this engine's launches take now (0 / 1 / 2; -1 for bf16 and wide networks). */
+ * waves, fused or not); the forms agree to float32 summation order (<= 1e-6 on the probability).  Ignored by the wide
+ * networks and with projection rows; use_delta models of the stock width follow 0 / 1.
+ * bf16-operand networks (gru_precision = 1) have two layouts of the same arithmetic contract (tolerance 1e-2, each bit-stable
+ * across pe_update / pe_update_many / pe_predict): 1 (and -1, the default, where it fits: <= 20 units, <= 14 features) = five
+ * gate values per lane (csrc/gru_b20_device.h: 9 MFMAs per timestep), 0 = eight values per lane (csrc/gru_bf16_device.h: 12
+ * MFMAs, every width up to 32); 2 is refused.
+ * pe_get_gru_tiling: the form this engine's launches take now (0 / 1 / 2; -1 for wide networks; -2 for a null engine). */
 int pe_set_gru_tiling(pe_engine* e, int32_t tiling);
 int pe_get_gru_tiling(const pe_engine* e);
 

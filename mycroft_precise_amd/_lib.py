@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PE_LIB') or os.path.join(HERE, 'libprecise_engine.so')
 
 PE_OK, PE_ERR_INVALID, PE_ERR_HIP, PE_ERR_UNSUPPORTED, PE_ERR_NOMEM, PE_ERR_EOF = range(6)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class PeParams(C.Structure):
@@ -51,6 +51,10 @@ EXPORTS = {
     'pe_clear': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pe_update': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     'pe_update_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'pe_host_alloc': (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    'pe_host_free': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'pe_update_async': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    'pe_wait': (C.c_int, [C.c_void_p]),
     'pe_reserve_updates': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     'pe_update_many': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     'pe_update_many_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -151,6 +155,7 @@ class HipEngine:
         from .params import Vectorizer
         self._lib = load()
         self._h = C.c_void_p()
+        self._pinned, self._async_keep = [], []
         self.n_streams = int(n_streams)
         self.n_features = int(params.n_features)
         self.n_mfcc = int(params.n_mfcc)
@@ -226,6 +231,37 @@ class HipEngine:
         out = np.empty(self.n_streams, dtype=np.float32)
         self._check(self._lib.pe_update(self._h, pcm.ctypes.data, pcm.shape[1], out.ctypes.data))
         return out
+
+    # -- host-fed pipeline (pe_update_async / pe_wait): scripts/engine.py:60-63 hands over host bytes per chunk ----------
+    def host_array(self, shape, dtype) -> np.ndarray:
+        """A numpy array over pinned, device-visible host memory of this engine (pe_host_alloc): ``update_async`` reads PCM
+        from / writes probabilities to such arrays without a staging copy.  Freed with the engine."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._check(self._lib.pe_host_alloc(self._h, max(n, 1), C.byref(p)))
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned.append((p.value, buf))
+        return arr
+
+    def update_async(self, pcm: np.ndarray, out: np.ndarray = None) -> np.ndarray:
+        """Enqueue one update ([n_streams, chunk] int16) and return the float32 [n_streams] array its probabilities will be
+        in after ``wait()`` (or once 3 more updates have been enqueued).  Up to 3 updates are in flight: the next chunk
+        crosses PCIe while this one runs.  ``pcm`` from ``host_array`` is read in place (keep it untouched until then);
+        any other array is copied at the call."""
+        pcm = self._pcm(pcm)
+        if out is None:
+            out = np.empty(self.n_streams, dtype=np.float32)
+        if out.dtype != np.float32 or out.size != self.n_streams or not out.flags.c_contiguous:
+            raise ValueError('out must be a contiguous float32 array of %d elements' % self.n_streams)
+        self._check(self._lib.pe_update_async(self._h, pcm.ctypes.data, pcm.shape[1], out.ctypes.data))
+        self._async_keep = (self._async_keep + [(pcm, out)])[-4:]          # the buffers of the updates in flight stay alive
+        return out
+
+    def wait(self):
+        self._check(self._lib.pe_wait(self._h))
+        self._async_keep = []
 
     def reserve_updates(self, max_updates: int, max_chunk_samples: int):
         """Size the engine for update_many (restarts all streams)."""
@@ -373,11 +409,12 @@ class HipEngine:
 
     def set_gru_tiling(self, tiling: int):
         """-1 automatic, 0 classic four-tile layout, 1 re-tiled stock width (csrc/gru_cw_device.h), 2 float32 products on the
-        bf16 matrix pipe (csrc/gru_x3_device.h; automatic above four stream tiles per compute unit)."""
+        bf16 matrix pipe (csrc/gru_x3_device.h; automatic above four stream tiles per compute unit).  bf16 networks: 1 / -1 = five
+        gate values per lane where the network fits (csrc/gru_b20_device.h), 0 = eight (csrc/gru_bf16_device.h)."""
         self._check(self._lib.pe_set_gru_tiling(self._h, int(tiling)))
 
     def gru_tiling(self) -> int:
-        """The form this engine's network launches take now: 0 / 1 / 2 as above, -1 for bf16 and wide networks."""
+        """The form this engine's network launches take now: 0 / 1 / 2 as above, -1 for wide networks."""
         return int(self._lib.pe_get_gru_tiling(self._h))
 
     def set_timing(self, enabled: bool):

@@ -95,6 +95,21 @@ struct pe_engine {
     bool timing = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool ev_valid = false, ev_has_gru = false;
+    // host-fed pipeline (pe_update_async / pe_wait): a ring of kAsyncDepth updates in flight, each with its own device
+    // buffers and pinned staging; the chunk of update u + 1 crosses PCIe (copy stream) while update u runs (compute stream)
+    static constexpr int kAsyncDepth = 3;
+    struct AsyncSlot {
+        void* pin_in = nullptr; size_t pin_in_bytes = 0;        // pinned staging for callers that hand over pageable memory
+        float* pin_out = nullptr; size_t pin_out_bytes = 0;
+        DeviceBuf dev_in, dev_out;
+        hipEvent_t copied = nullptr, done = nullptr;
+        float* user_out = nullptr; size_t out_bytes = 0;
+        bool direct_out = false, busy = false;
+    } aslot[kAsyncDepth];
+    hipStream_t s_copy = nullptr, s_compute = nullptr;
+    unsigned async_next = 0;
+    int async_inflight = 0;
+    std::vector<std::pair<char*, size_t>> pinned;               // pe_host_alloc'ed ranges (zero-copy sources / destinations)
 };
 
 namespace {
@@ -116,6 +131,11 @@ int fail(pe_engine* e, int code, const char* fmt, ...) {
             return fail((e), PE_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_err), \
                         __FILE__, __LINE__);                                                 \
     } while (0)
+
+int drain_async(pe_engine* e);
+// every entry point that reads or moves the streams' state first lets the updates of pe_update_async finish (they run on the
+// engine's own streams, which no other entry point is ordered against)
+#define PE_DRAIN(e) do { int _drc = drain_async(e); if (_drc) return _drc; } while (0)
 
 template <class T>
 int dev_alloc(pe_engine* e, T** out, size_t count) {
@@ -480,8 +500,8 @@ int pack_gru_weights_x3(pe_engine* e, const pe_gru_layer& L, const float* dense_
 // lo), and 8 gk + 4 + e <-> the first difference of that feature (use_delta: kernel rows F .. 2 F - 1).
 bool b20_eligible(const pe_params& p, const pe_gru_layer& L) {
     const int F = p.use_delta ? L.n_in / 2 : L.n_in;
-    // (tuning builds only, PE_B20=1: measured and not shipped -- tools/micro/gru_b20_device.h)
-    return tuning_env_int("PE_B20", 0) != 0 && p.gru_precision == 1 && L.units <= 20 && F <= 14 && p.n_mfcc <= kRowFloats;
+    // (tuning builds: PE_B20=0 keeps every engine on the eight-values layout)
+    return tuning_env_int("PE_B20", 1) != 0 && p.gru_precision == 1 && L.units <= 20 && F <= 14 && p.n_mfcc <= kRowFloats;
 }
 
 int pack_gru_weights_b20(pe_engine* e, const pe_gru_layer& L, const float* dense_kernel) {
@@ -694,7 +714,7 @@ GruArgs gru_args(const pe_engine* e) {
     a.frame_len = frame_len_of(e->prm);
     a.bf16 = e->prm.gru_precision == 1;
     a.wx_bf16 = e->wx_bf16; a.wr_bf16 = e->wr_bf16; a.wd_bf16 = e->wd_bf16;
-    a.b20 = e->b20_blob;
+    a.b20 = e->gru_tiling == 0 ? nullptr : e->b20_blob;      // bf16 network: five values per lane where it fits (pe_set_gru_tiling(e, 0): eight)
     a.feats = nullptr; a.out = nullptr; a.row_stride = 0;
     a.row_floats = e->row_floats;
     // Four waves per tile cut the latency of a tile's chain; that only pays while every tile gets a CU of its
@@ -759,6 +779,53 @@ int launch_gru_ring(pe_engine* e, float* out_dev, hipStream_t s) {
     GruArgs a = gru_args(e);
     a.out = out_dev;
     return launch_network(e, a, 1, s);
+    return PE_OK;
+}
+
+// ---- host-fed pipeline -------------------------------------------------------------------------------------------
+bool is_pinned(const pe_engine* e, const void* p, size_t bytes) {
+    const char* c = static_cast<const char*>(p);
+    for (const auto& r : e->pinned)
+        if (c >= r.first && c + bytes <= r.first + r.second) return true;
+    return false;
+}
+
+int async_init(pe_engine* e) {
+    if (e->s_compute) return PE_OK;
+    PE_HIP(e, hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking));
+    PE_HIP(e, hipStreamCreateWithFlags(&e->s_compute, hipStreamNonBlocking));
+    for (auto& sl : e->aslot) {
+        PE_HIP(e, hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+        PE_HIP(e, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    return PE_OK;
+}
+
+int ensure_pinned(pe_engine* e, void** p, size_t* have, size_t bytes) {
+    if (*have >= bytes) return PE_OK;
+    if (*p) { (void)hipHostFree(*p); *p = nullptr; *have = 0; }
+    hipError_t err = hipHostMalloc(p, bytes, hipHostMallocDefault);
+    if (err != hipSuccess) return fail(e, PE_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+    *have = bytes;
+    return PE_OK;
+}
+
+// the update in this slot has finished: hand its probabilities to the caller
+int finish_slot(pe_engine* e, pe_engine::AsyncSlot& sl) {
+    if (!sl.busy) return PE_OK;
+    PE_HIP(e, hipEventSynchronize(sl.done));
+    if (!sl.direct_out) std::memcpy(sl.user_out, sl.pin_out, sl.out_bytes);
+    sl.busy = false;
+    --e->async_inflight;
+    return PE_OK;
+}
+
+int drain_async(pe_engine* e) {
+    if (!e || e->async_inflight == 0) return PE_OK;
+    for (int i = 0; i < pe_engine::kAsyncDepth; ++i) {                 // oldest first
+        int rc = finish_slot(e, e->aslot[(e->async_next + i) % pe_engine::kAsyncDepth]);
+        if (rc) return rc;
+    }
     return PE_OK;
 }
 
@@ -985,10 +1052,24 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
 int pe_destroy(pe_engine* e) {
     if (!e) return PE_OK;
     (void)hipSetDevice(e->device);
+    (void)drain_async(e);
     for (void* p : e->allocs) (void)hipFree(p);
     for (DeviceBuf* b : {&e->st_pcm, &e->st_out, &e->st_feats, &e->st_mask, &e->st_audio, &e->st_mfcc, &e->st_conf, &e->st_fired})
         if (b->p) (void)hipFree(b->p);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->s_compute) (void)hipStreamSynchronize(e->s_compute);
+    if (e->s_copy) (void)hipStreamSynchronize(e->s_copy);
+    for (auto& sl : e->aslot) {
+        if (sl.pin_in) (void)hipHostFree(sl.pin_in);
+        if (sl.pin_out) (void)hipHostFree(sl.pin_out);
+        if (sl.dev_in.p) (void)hipFree(sl.dev_in.p);
+        if (sl.dev_out.p) (void)hipFree(sl.dev_out.p);
+        if (sl.copied) (void)hipEventDestroy(sl.copied);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
+    if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
+    for (auto& r : e->pinned) (void)hipHostFree(r.first);
     delete e;
     return PE_OK;
 }
@@ -996,6 +1077,7 @@ int pe_destroy(pe_engine* e) {
 int pe_clear(pe_engine* e, const uint8_t* mask_host) {
     if (!e) return PE_ERR_INVALID;
     PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
     const uint8_t* mask_dev = nullptr;
     if (mask_host) {
         int rc = ensure(e, e->st_mask, (size_t)e->n_streams);
@@ -1016,6 +1098,7 @@ int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, float*
     int rc = check_chunk(e, pcm_dev, chunk);
     if (rc) return rc;
     PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
     if (!raw_out_dev) return fail(e, PE_ERR_INVALID, "raw_out_dev is null");
     return do_update(e, pcm_dev, chunk, raw_out_dev, nullptr, static_cast<hipStream_t>(stream));
 }
@@ -1024,12 +1107,14 @@ int pe_update_vectors_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk
     int rc = check_chunk(e, pcm_dev, chunk);
     if (rc) return rc;
     PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
     return do_update(e, pcm_dev, chunk, nullptr, feats_out_dev, static_cast<hipStream_t>(stream));
 }
 
 int pe_run_device(pe_engine* e, float* raw_out_dev, void* stream) {
     if (!e || !raw_out_dev) return fail(e, PE_ERR_INVALID, "null argument to pe_run_device");
     PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
     return launch_gru_ring(e, raw_out_dev, static_cast<hipStream_t>(stream));
 }
 
@@ -1038,6 +1123,7 @@ int pe_update(pe_engine* e, const int16_t* pcm_host, int32_t chunk, float* raw_o
     if (rc) return rc;
     if (!raw_out_host) return fail(e, PE_ERR_INVALID, "raw_out_host is null");
     PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
     const size_t pcm_bytes = (size_t)e->n_streams * chunk * sizeof(int16_t);
     if ((rc = ensure(e, e->st_pcm, pcm_bytes))) return rc;
     if ((rc = ensure(e, e->st_out, (size_t)e->n_streams * sizeof(float)))) return rc;
@@ -1047,10 +1133,76 @@ int pe_update(pe_engine* e, const int16_t* pcm_host, int32_t chunk, float* raw_o
     return PE_OK;
 }
 
+int pe_host_alloc(pe_engine* e, size_t bytes, void** out) {
+    if (!e || !out || bytes == 0) return fail(e, PE_ERR_INVALID, "bad arguments to pe_host_alloc");
+    PE_HIP(e, hipSetDevice(e->device));
+    void* p = nullptr;
+    hipError_t err = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (err != hipSuccess) return fail(e, PE_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+    e->pinned.emplace_back(static_cast<char*>(p), bytes);
+    *out = p;
+    return PE_OK;
+}
+
+int pe_host_free(pe_engine* e, void* p) {
+    if (!e || !p) return PE_ERR_INVALID;
+    PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);                                      // an update in flight may still read from / write to it
+    for (auto it = e->pinned.begin(); it != e->pinned.end(); ++it)
+        if (it->first == static_cast<char*>(p)) {
+            e->pinned.erase(it);
+            PE_HIP(e, hipHostFree(p));
+            return PE_OK;
+        }
+    return fail(e, PE_ERR_INVALID, "pe_host_free: not a pe_host_alloc'ed pointer of this engine");
+}
+
+int pe_update_async(pe_engine* e, const int16_t* pcm_host, int32_t chunk, float* raw_out_host) {
+    int rc = check_chunk(e, pcm_host, chunk);
+    if (rc) return rc;
+    if (!raw_out_host) return fail(e, PE_ERR_INVALID, "raw_out_host is null");
+    PE_HIP(e, hipSetDevice(e->device));
+    if ((rc = async_init(e))) return rc;
+    pe_engine::AsyncSlot& sl = e->aslot[e->async_next % pe_engine::kAsyncDepth];
+    if ((rc = finish_slot(e, sl))) return rc;          // the ring is full: the oldest update is delivered first
+    const size_t pcm_bytes = (size_t)e->n_streams * chunk * sizeof(int16_t), out_bytes = (size_t)e->n_streams * sizeof(float);
+    if ((rc = ensure(e, sl.dev_in, pcm_bytes))) return rc;
+    if ((rc = ensure(e, sl.dev_out, out_bytes))) return rc;
+    const void* src = pcm_host;
+    if (!is_pinned(e, pcm_host, pcm_bytes)) {          // pageable memory: the caller gets its buffer back at once
+        if ((rc = ensure_pinned(e, &sl.pin_in, &sl.pin_in_bytes, pcm_bytes))) return rc;
+        std::memcpy(sl.pin_in, pcm_host, pcm_bytes);
+        src = sl.pin_in;
+    }
+    sl.direct_out = is_pinned(e, raw_out_host, out_bytes);
+    if (!sl.direct_out) {
+        void* po = sl.pin_out;
+        if ((rc = ensure_pinned(e, &po, &sl.pin_out_bytes, out_bytes))) return rc;
+        sl.pin_out = static_cast<float*>(po);
+    }
+    PE_HIP(e, hipMemcpyAsync(sl.dev_in.p, src, pcm_bytes, hipMemcpyHostToDevice, e->s_copy));
+    PE_HIP(e, hipEventRecord(sl.copied, e->s_copy));
+    PE_HIP(e, hipStreamWaitEvent(e->s_compute, sl.copied, 0));
+    if ((rc = do_update(e, static_cast<const int16_t*>(sl.dev_in.p), chunk, static_cast<float*>(sl.dev_out.p), nullptr, e->s_compute))) return rc;
+    PE_HIP(e, hipMemcpyAsync(sl.direct_out ? raw_out_host : sl.pin_out, sl.dev_out.p, out_bytes, hipMemcpyDeviceToHost, e->s_compute));
+    PE_HIP(e, hipEventRecord(sl.done, e->s_compute));
+    sl.user_out = raw_out_host; sl.out_bytes = out_bytes; sl.busy = true;
+    ++e->async_inflight;
+    ++e->async_next;
+    return PE_OK;
+}
+
+int pe_wait(pe_engine* e) {
+    if (!e) return PE_ERR_INVALID;
+    PE_HIP(e, hipSetDevice(e->device));
+    return drain_async(e);
+}
+
 int pe_update_vectors(pe_engine* e, const int16_t* pcm_host, int32_t chunk, float* feats_out_host) {
     int rc = check_chunk(e, pcm_host, chunk);
     if (rc) return rc;
     PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
     const size_t pcm_bytes = (size_t)e->n_streams * chunk * sizeof(int16_t);
     const size_t feat_bytes = (size_t)e->n_streams * e->prm.n_features * e->prm.n_mfcc * sizeof(float);
     if ((rc = ensure(e, e->st_pcm, pcm_bytes))) return rc;
@@ -1066,6 +1218,7 @@ int pe_update_vectors(pe_engine* e, const int16_t* pcm_host, int32_t chunk, floa
 int pe_get_vectors(pe_engine* e, float* feats_out_host) {
     if (!e || !feats_out_host) return fail(e, PE_ERR_INVALID, "null argument to pe_get_vectors");
     PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
     int rc;
     const size_t feat_bytes = (size_t)e->n_streams * e->prm.n_features * e->prm.n_mfcc * sizeof(float);
     if ((rc = ensure(e, e->st_feats, feat_bytes))) return rc;
@@ -1078,6 +1231,7 @@ int pe_get_vectors(pe_engine* e, float* feats_out_host) {
 int pe_set_vectors(pe_engine* e, const float* feats_host) {
     if (!e || !feats_host) return fail(e, PE_ERR_INVALID, "null argument to pe_set_vectors");
     PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
     int rc;
     if ((rc = pe_clear(e, nullptr))) return rc;
     const size_t feat_bytes = (size_t)e->n_streams * e->prm.n_features * e->prm.n_mfcc * sizeof(float);
@@ -1284,6 +1438,7 @@ int pe_decode(pe_engine* e, const float* raw_host, double* conf_out_host, unsign
 int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samples) {
     if (!e || max_updates < 1 || max_chunk_samples < 1) return fail(e, PE_ERR_INVALID, "bad arguments to pe_reserve_updates");
     PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
     PE_HIP(e, hipDeviceSynchronize());
     const int pending = pending_frames(e->prm);
     const long long frames = ((long long)max_updates * max_chunk_samples + e->prm.hop_samples - 1) / e->prm.hop_samples + 1;
@@ -1316,6 +1471,7 @@ int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, i
     if (!raw_out_dev || n_updates < 1) return fail(e, PE_ERR_INVALID, "bad arguments to pe_update_many_device");
     if (n_updates > e->max_updates || !e->ke_hist) return fail(e, PE_ERR_INVALID, "call pe_reserve_updates(e, >= %d, >= %d) first", n_updates, chunk);
     PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
     const int flen = frame_len_of(e->prm);
     const int pending = pending_frames(e->prm);
     const long long frames = ((long long)n_updates * chunk + e->prm.hop_samples - 1) / e->prm.hop_samples + 1;
@@ -1397,6 +1553,7 @@ int pe_get_info(const pe_engine* e, pe_info* out) {
 int pe_get_stream_state(pe_engine* e, int32_t* q_out, uint32_t* computed_out, uint32_t* emitted_out) {
     if (!e) return PE_ERR_INVALID;
     PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
     PE_HIP(e, hipDeviceSynchronize());
     const size_t n = (size_t)e->n_streams;
     if (q_out) PE_HIP(e, hipMemcpy(q_out, e->st_q[e->cur], n * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1407,6 +1564,7 @@ int pe_get_stream_state(pe_engine* e, int32_t* q_out, uint32_t* computed_out, ui
 
 int pe_set_fused(pe_engine* e, int32_t enabled) {
     if (!e) return PE_ERR_INVALID;
+    PE_DRAIN(e);
     e->fused = enabled != 0;
     return PE_OK;
 }
@@ -1417,6 +1575,7 @@ int pe_set_input_projection(pe_engine* e, int32_t enabled) {
     if (enabled && !e->proj_ok) return fail(e, PE_ERR_UNSUPPORTED, "input-projection rows exist for the float32 network of 17..20 units without delta features only");
     if ((enabled != 0) == e->proj_on) return PE_OK;
     PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
     PE_HIP(e, hipDeviceSynchronize());
     e->proj_on = enabled != 0;
     if (e->proj_on && !e->proj_ring) {
@@ -1434,6 +1593,7 @@ int pe_set_gru_waves(pe_engine* e, int32_t waves) {
     // compiled into tuning builds only
     if (waves == 16) return fail(e, PE_ERR_UNSUPPORTED, "the sixteen-lanes-per-stream kernel exists in -DPE_TUNING builds only (tools/build_variants.sh)");
 #endif
+    PE_DRAIN(e);
     e->gru_waves = waves;
     return PE_OK;
 }
@@ -1443,13 +1603,17 @@ int pe_set_gru_tiling(pe_engine* e, int32_t tiling) {
     if (tiling < -1 || tiling > 2) return fail(e, PE_ERR_INVALID, "gru tiling must be -1 (auto), 0 (classic), 1 (re-tiled) or 2 (XDL form)");
     if (tiling == 2 && !e->x3_blob)
         return fail(e, PE_ERR_UNSUPPORTED, "the XDL form of the float32 network (tiling 2) takes <= 20 units, <= 15 inputs, float32 operands, no use_delta");
+    if (tiling == 1 && e->prm.gru_precision == 1 && !e->b20_blob)
+        return fail(e, PE_ERR_UNSUPPORTED, "the five-values layout of the bf16 network (tiling 1) takes <= 20 units and <= 14 features");
+    PE_DRAIN(e);
     e->gru_tiling = tiling;
     return PE_OK;
 }
 
 int pe_get_gru_tiling(const pe_engine* e) {
-    if (!e) return PE_ERR_INVALID;
-    if (e->wide || e->prm.gru_precision != 0) return -1;
+    if (!e) return -2;               // (not PE_ERR_INVALID = 1, which is a valid answer)
+    if (e->wide) return -1;
+    if (e->prm.gru_precision != 0) return gru_args(e).b20 ? 1 : 0;
     const GruArgs a = gru_args(e);
     return a.x3 ? 2 : a.cw ? 1 : 0;
 }

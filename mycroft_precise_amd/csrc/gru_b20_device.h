@@ -15,32 +15,19 @@
 //     use_delta (vectorization.py:53-59), its first difference in slot 8 g + 4 + e; the bias rides as the weight rows of
 //     pseudo-features F and F + 1 against 1.0 (hi + lo: residual <= 2^-17 |b|), F <= 14.
 //
-// MEASURED AND NOT SHIPPED (round 4; tuning builds only, PE_B20=1): network launch 17.9 vs 28.0 us at 65 536 streams, 6.9 vs
-// 9.2 us at 8192 -- but in the FUSED launch ~0.7 % of the float32 MFCC frames computed beside this role come out slightly
-// wrong (a few input values of an earlier frame: identical streams stop agreeing bit for bit; tools/gpu_b20_debug.py).  The
-// same binary with the role switched off, with its MFMAs compiled out, with the float64 frame role, or with packed float32
-// instructions disabled for the translation unit (-target-feature -packed-fp32-ops) shows none; an s_waitcnt lgkmcnt(0) at
-// every lane hand-off of the frame role removes most.  tools/micro/lds_order.hip rules out LDS reordering inside a wave.
-// Root cause not isolated (profiles/round4/r4v_b20_fused_corruption.log): the eight-values-per-lane kernel stays.
+// Shipped in round 5 as the bf16 network of every engine it fits (<= 20 units, <= 14 features): network launch 17.7 vs 26.9 us
+// at 65 536 streams, 7.2 vs 9.5 us at 8192 (profiles/round5/r5a_time_packed_unpacked.log).  Round 4 built it and held it back:
+// in the FUSED launch ~0.7 % of the float32 MFCC frames computed beside this role came out slightly wrong, timing-dependent
+// (profiles/round4/r4v_b20_fused_corruption.log).  Every kernel that hosts the float32 frame role is now compiled WITHOUT
+// packed float32 instructions (kernels.hip: PE_NO_PK_F32) -- 0 wrong streams in every run of rounds 4 and 5, 1e8-frame soaks
+// at 8192 and 65 536 streams clean (tools/gpu_frame_soak.py), and the frame role is 2-3 % FASTER that way.  The instruction
+// pair behind the round-4 effect was not isolated (tools/micro/pk_swap_hazard.hip replays the emitted sequence: clean).
 #pragma once
-#include "../../mycroft_precise_amd/csrc/gru_bf16_device.h"
+#include "gru_bf16_device.h"
 
 namespace pe {
 
-#ifndef PE_B20_DBG
-#define PE_B20_DBG 0
-#endif
-#if PE_B20_DBG == 1      // (bisecting aid: no XDL instruction in this tile function)
-__device__ __forceinline__ f32x4 b20_mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
-    f32x4 r = c;
-    r[0] += (float)a[0] * (float)b[0]; r[1] += (float)a[1] * (float)b[1]; r[2] += (float)a[2] * (float)b[2]; r[3] += (float)a[3] * (float)b[3];
-    return r;
-}
-#elif PE_B20_DBG == 3      // (bisecting aid: every MFMA followed by idle issue slots)
-__device__ __forceinline__ f32x4 b20_mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) { const f32x4 r = mfma_bf16(a, b, c); __builtin_amdgcn_s_sleep(1); return r; }
-#else
 __device__ __forceinline__ f32x4 b20_mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) { return mfma_bf16(a, b, c); }
-#endif
 
 // two float32 -> one dword of two bf16 (round to nearest even), element 0 in the low half
 __device__ __forceinline__ uint32_t b20_pk(float a, float b) {

@@ -104,7 +104,7 @@ struct MfccOfflineArgs {
 // ---------------------------------------------------------------------------------------
 // GRU + Dense head (model.py:76-82), register-resident weights, one wave per 16-stream tile
 // ---------------------------------------------------------------------------------------
-// gru_x3_device.h: packed operands of the float32 network on the XDL pipe (pe_params.gru_precision = 2)
+// gru_x3_device.h: packed operands of the float32 network on the XDL pipe (pe_set_gru_tiling(e, 2))
 constexpr int kX3Tiles = 4;                 // TZ, TR, TC, TQ
 constexpr int kX3RecOps = 4, kX3InOps = 3;   // A operands per output tile: recurrent, input
 // blob (uint4 = 8 bf16 per lane): [AR: tile][m][lane] | [AX: tile][m][lane] | float wd[5][lane]
@@ -149,7 +149,7 @@ struct GruArgs {
     const float* wd_bf16;   // [8][64]
     // ... and in the five-values-per-lane layout of networks of <= 20 units (gru_b20_device.h): non-null = the bf16 launchers take it
     const void* b20;
-    // float32 network on the XDL pipe, operands as three bf16 pieces (gru_x3_device.h; pe_params.gru_precision = 2):
+    // float32 network on the XDL pipe, operands as three bf16 pieces (gru_x3_device.h; pe_set_gru_tiling(e, 2)):
     // non-null = the launchers take gru_tile_x3 for every input mode
     const void* x3;         // [4 tiles][4][64] + [4 tiles][3][64] uint4 of 8 bf16, then float wd[5][64]
     // input: either the feature ring (+ per-stream emitted-frame counters) ...

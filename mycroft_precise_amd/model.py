@@ -76,8 +76,8 @@ def _sidecar_matches(net_file: str, sidecar: str) -> bool:
             want = str(z['source_sha256'])
         with open(net_file, 'rb') as f:
             return hashlib.sha256(f.read()).hexdigest() == want
-    except (OSError, ValueError):
-        return False
+    except Exception:        # a truncated / corrupt side-car (zipfile.BadZipFile, EOFError, KeyError, ...) is simply "no match":
+        return False         # the native .net reader stays the fallback
 
 
 def load_weights(model_name: str) -> dict:

@@ -86,6 +86,11 @@ class HipRunner(Runner):
         return self.engine.evaluate(audio, hops)
 
 
+# The reference's two runner names (network_runner.py:45-95): `from precise.network_runner import Listener, KerasRunner`
+# (scripts/train_incremental.py:45) and `TensorFlowRunner` resolve to the one implementation here, whatever the file format.
+KerasRunner = TensorFlowRunner = HipRunner
+
+
 def _placeholder_weights(n_in):
     return {'gru': [(np.zeros((n_in, 3), np.float32), np.zeros((1, 3), np.float32), np.zeros(3, np.float32))],
             'dense_kernel': np.zeros((1, 1), np.float32), 'dense_bias': np.zeros(1, np.float32)}
@@ -306,6 +311,21 @@ class BatchedListener:
     def update(self, chunks) -> np.ndarray:
         """-> decoded confidences float64 [n_streams] (ThresholdDecoder.decode on the device)"""
         return self.engine.decode(self.update_raw(chunks))
+
+    # -- host-fed pipeline: what a server that receives audio over the network does (scripts/engine.py:60-63 per stream) --
+    def chunk_buffer(self, chunk_samples: int = 1024) -> np.ndarray:
+        """A pinned [n_streams, chunk_samples] int16 array to receive audio into: ``update_raw_async`` reads it in place
+        (no staging copy), which is what reaches PCIe line rate.  Keep a few and rotate: a buffer is read until ``wait()``
+        or until three more updates have been enqueued."""
+        return self.engine.host_array((self.n_streams, int(chunk_samples)), '<i2')
+
+    def update_raw_async(self, chunks, out: np.ndarray = None) -> np.ndarray:
+        """Enqueue one update; returns the float32 [n_streams] array its raw outputs land in after ``wait()``.  Up to three
+        updates are in flight: chunk u + 1 crosses PCIe while update u runs.  Same bits as ``update_raw``."""
+        return self.engine.update_async(self._pcm(chunks), out)
+
+    def wait(self):
+        self.engine.wait()
 
     def update_detect(self, chunks):
         """-> (confidences float64 [n_streams], activations bool [n_streams]); needs set_trigger()."""

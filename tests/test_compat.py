@@ -97,4 +97,5 @@ def test_aliases_are_one_liners():
             if not f.endswith('.py'):
                 continue
             body = [l for l in open(os.path.join(root, f)).read().split('"""')[-1].splitlines() if l.strip() and not l.strip().startswith('#')]
-            assert len(body) <= 4, (f, body)
+            # (scripts/engine.py: two more lines -- under `python -m` the alias itself is __main__ and must call main())
+            assert len(body) <= (6 if f == 'engine.py' else 4), (f, body)

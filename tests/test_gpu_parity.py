@@ -904,6 +904,47 @@ def test_bf16_feature_rows_equal_float32_rows_rounded_at_the_load(stock_weights)
         HipEngine(P.pr, stock_weights, n_streams=4, ring_precision='bf16')          # bf16 rows feed the bf16 network only
 
 
+def test_bf16_network_layouts(stock_weights):
+    """The two layouts of the bf16 network (pe_set_gru_tiling on a gru_precision = 1 engine): five gate values per lane
+    (gru_b20_device.h: the default up to 20 units / 14 features, round 5) and eight (gru_bf16_device.h: every width up to 32).
+    Same arithmetic contract -- both within 1e-2 of the float32 oracle, streaming and pe_predict --, each bit-stable across
+    fused / two launches / pe_update_many; networks the five-values layout has no room for stay on eight and refuse 1."""
+    from mycroft_precise_amd._lib import HipEngine
+    kinds = (['tone_noise'] * 29) + ['zeros', 'square', 'quiet', 'tone_noise']
+    n_up = 36
+    pcm = _stream_batch(kinds, n_up)
+    ref = ol.BatchedOracle(stock_weights, len(kinds))
+    want = np.stack([ref.update_raw(pcm[u]) for u in range(n_up)])
+    outs = {}
+    for ring in ('f32', 'bf16'):
+        for tiling in (1, 0):
+            engs = [HipEngine(P.pr, stock_weights, n_streams=len(kinds), mfcc_precision='f32', gru_precision='bf16', ring_precision=ring) for _ in range(3)]
+            for e in engs:
+                e.set_gru_tiling(tiling)
+                assert e.gru_tiling() == tiling
+            engs[1].set_fused(False)
+            engs[2].reserve_updates(4, 1024)
+            got = np.stack([engs[0].update(pcm[u]) for u in range(n_up)])
+            two = np.stack([engs[1].update(pcm[u]) for u in range(n_up)])
+            many = np.concatenate([engs[2].update_many(pcm[u:u + 4]) for u in range(0, n_up, 4)])
+            assert np.array_equal(got, two) and np.array_equal(got, many), (ring, tiling)
+            assert np.abs(got - want).max() <= TOL_BF16, (ring, tiling)
+            feats = engs[0].get_vectors()
+            assert np.array_equal(engs[0].predict(feats)[:, 0], got[-1]), (ring, tiling)      # Runner.predict on the same windows, bit for bit
+            outs[(ring, tiling)] = got
+            for e in engs:
+                e.close()
+        assert not np.array_equal(outs[(ring, 0)], outs[(ring, 1)])          # two summation orders, not one kernel twice
+    for w_kw, p_kw in ((dict(units=(24,)), dict()), (dict(n_in=15), dict(n_mfcc=15))):
+        hpr = P.pr.copy()
+        hpr.__dict__.update(p_kw)
+        eng = HipEngine(hpr, synth.make_weights(seed=2, **w_kw), n_streams=4, gru_precision='bf16')
+        assert eng.gru_tiling() == 0
+        with pytest.raises(NotImplementedError):
+            eng.set_gru_tiling(1)
+        eng.close()
+
+
 @pytest.mark.parametrize('units', [8, 20, 32])
 def test_bf16_network_other_widths(units):
     from mycroft_precise_amd._lib import HipEngine
@@ -1248,6 +1289,85 @@ def test_x3_widths_and_input_sizes(units, n_in):
     eng.close()
 
 
+def test_x3_edge_cases_saturation_huge_nonfinite_and_denormal(stock_weights):
+    """The edge cases the f32-input kernels were already held to, in the XDL form (tiling 2, the automatic network above 16 384
+    streams): saturation to EXACTLY 0.0 / 1.0 (ThresholdDecoder.decode short-circuits on those, threshold_decoder.py:46-47),
+    features up to 1e30 (three bf16 pieces carry float32's exponent range), denormal and tiny weights (bf16 pieces of a float32
+    denormal drop bits below 2^-133: absolute error <= 5e-41 per product), and non-finite features: the first piece of inf is
+    inf, the remainder inf - inf = NaN, so a window that contains inf / NaN / |x| >= 3.39e38 comes out NaN -- never a finite
+    wrong number -- and the other windows of the batch are untouched (the f32-input forms and numpy propagate inf / NaN their
+    own way: no form promises more than "non-finite in, non-finite or saturated out")."""
+    from mycroft_precise_amd._lib import HipEngine
+    eng = HipEngine(P.pr, stock_weights, n_streams=1)
+    eng.set_gru_tiling(2)
+    f32 = HipEngine(P.pr, stock_weights, n_streams=1)
+    for scale in (1e4, 1e30):
+        big = np.full((6, 29, 13), scale, np.float32)
+        big[2:4] *= -1
+        big[4:, :, ::2] *= -1
+        want = keras_gru.predict(big, stock_weights)
+        assert np.array_equal(eng.predict(big), want), scale
+        assert np.array_equal(f32.predict(big), want), scale
+        assert set(np.unique(want)) <= {0.0, 1.0}
+    rng = np.random.default_rng(77)
+    x = rng.normal(0, 3, (40, 29, 13)).astype(np.float32)
+    clean = eng.predict(x)
+    bad = x.copy()
+    bad[3, 5, 2] = np.inf
+    bad[11, 0, 12] = -np.inf
+    bad[17, 28, 0] = np.nan
+    bad[22, 9, 7] = np.float32(3.4e38)
+    got = eng.predict(bad)
+    hit = np.zeros(40, bool)
+    hit[[3, 11, 17, 22]] = True
+    assert np.all(np.isnan(got[hit]))
+    assert np.array_equal(got[~hit], clean[~hit])
+    # denormal / tiny weights
+    w = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in stock_weights.items()}
+    k0, r0, b0 = [a.copy() for a in w['gru'][0]]
+    k0[::3, ::5] = np.float32(1e-40); k0[1::3, 1::5] = np.float32(-3e-39); r0[::4, ::7] = np.float32(7e-41); r0[2::4, 3::7] = np.float32(1.2e-38)
+    b0[::6] = np.float32(2e-42)
+    w['gru'] = [(k0, r0, b0)]
+    den = HipEngine(P.pr, w, n_streams=1)
+    den.set_gru_tiling(2)
+    assert np.abs(den.predict(x) - keras_gru.predict(x, w)).max() <= GUARD_RAW
+    den.close(); eng.close(); f32.close()
+
+
+def test_decoder_bin_flips_between_network_forms(model_file, stock_weights):
+    """ThresholdDecoder.decode is a step function of logit(raw) (6400 bins, threshold_decoder.py:45-57) and the three forms of
+    the float32 network agree to float32 summation order: how many decoded values differ AT ALL when an engine crosses a size
+    at which the automatic form changes (8192 / 16 384 streams)?  Counted on the reference fixture's streams (280 decodes, vs
+    the reference's own decoded values) and on 256 synthetic streams x 48 updates (12 288 decodes, forms against each other);
+    never more than one bin.  The counts are recorded in INTEGRATION.md section 7."""
+    from mycroft_precise_amd._lib import HipEngine
+    from mycroft_precise_amd.threshold_decoder import ThresholdDecoder
+    g = golden('listener_chunk2048.npz')
+    dec = ThresholdDecoder(P.pr.threshold_config, P.pr.threshold_center)
+    n = len(g['streams'])
+    pcm = g['pcm'].reshape(n, -1, 1024)
+    fixture = {}
+    for tiling in (0, 1, 2):
+        eng = HipEngine(P.pr, stock_weights, n_streams=n)
+        eng.set_gru_tiling(tiling)
+        decs = np.array([[dec.decode(r) for r in eng.update(np.ascontiguousarray(pcm[:, u]))] for u in range(pcm.shape[1])]).T
+        fixture[tiling] = sum(_decode_flips(decs[i], g['decoded'][i]) for i in range(n))
+        eng.close()
+    B, n_up = 256, 48
+    base = synth.batch_pcm(B, n_up)
+    decoded = {}
+    for tiling in (0, 1, 2):
+        eng = HipEngine(P.pr, stock_weights, n_streams=B)
+        eng.set_gru_tiling(tiling)
+        eng.set_decoder(dec)
+        decoded[tiling] = np.stack([eng.decode(eng.update(base[u])) for u in range(n_up)])
+        eng.close()
+    pairs = {(a, b): _decode_flips(decoded[a], decoded[b]) for a, b in ((0, 1), (1, 2), (0, 2))}
+    print('decoder bin flips vs the reference fixture (280 decodes) by form:', fixture, '; between forms on %d decodes:' % (B * n_up), pairs)
+    assert fixture[1] == DECODE_FLIPS['chunk2048']
+    assert max(fixture.values()) <= 3 and max(pairs.values()) <= B * n_up // 100, (fixture, pairs)
+
+
 def test_x3_refuses_what_it_has_no_kernel_for():
     from mycroft_precise_amd._lib import HipEngine
     for kw, w_kw in ((dict(), dict(units=(21,))), (dict(n_mfcc=16), dict(n_in=16)), (dict(use_delta=True), dict(n_in=26))):
@@ -1261,7 +1381,7 @@ def test_x3_refuses_what_it_has_no_kernel_for():
     eng = HipEngine(P.pr, synth.make_weights(seed=1), n_streams=4, gru_precision='bf16')
     with pytest.raises(NotImplementedError):
         eng.set_gru_tiling(2)
-    assert eng.gru_tiling() == -1
+    assert eng.gru_tiling() == 1             # the stock bf16 network: five values per lane (gru_b20_device.h)
     eng.close()
 
 
@@ -1436,6 +1556,46 @@ def test_waves_owning_more_than_64_streams():
     assert out.returncode == 0 and out.stdout.startswith('ok'), (out.stdout[-500:], out.stderr[-2000:])
 
 
+def test_host_fed_pipeline_equals_synchronous_updates(stock_weights):
+    """pe_update_async / pe_wait (the host-fed path: pinned staging ring, next chunk crossing PCIe under the running update):
+    bit-identical to pe_update whatever the mix of pinned (zero-copy) and pageable buffers, with more updates enqueued
+    than the ring holds, with synchronous entry points in between (they wait for the updates in flight), after a clear."""
+    from mycroft_precise_amd.network_runner import BatchedListener
+    n, n_up = 70, 30
+    kinds = ['tone_noise'] * (n - 3) + ['zeros', 'square', 'quiet']
+    pcm = _stream_batch(kinds, n_up)
+    ref = BatchedListener(stock_weights, n)
+    want = np.stack([ref.update_raw(pcm[u]) for u in range(n_up)])
+    hip = BatchedListener(stock_weights, n)
+    bufs = [hip.chunk_buffer(1024) for _ in range(4)]
+    pinned_out = hip.engine.host_array((n_up, n), np.float32)
+    outs = []
+    for u in range(n_up):
+        if u % 3 == 0:                                    # pageable in, pageable out
+            outs.append(hip.update_raw_async(pcm[u].copy()))
+        else:                                             # pinned in (rotating), pinned out
+            b = bufs[u % 4]
+            b[:] = pcm[u]
+            outs.append(hip.update_raw_async(b, pinned_out[u]))
+        if u == 11:                                       # a synchronous entry point in the middle: sees updates 0..11
+            feats = hip.engine.get_vectors()
+            r2 = BatchedListener(stock_weights, n)
+            for v in range(12):
+                r2.update_raw(pcm[v])
+            assert np.array_equal(feats, r2.engine.get_vectors())
+    hip.wait()
+    assert np.array_equal(np.stack(outs), want)
+    # mixed with the synchronous call and a clear
+    hip.clear()
+    a = hip.update_raw_async(pcm[0])
+    b = hip.update_raw(pcm[1])                             # waits for the one in flight first
+    assert np.array_equal(a, want[0]) and np.array_equal(b, want[1])
+    with pytest.raises(ValueError):
+        hip.engine.update_async(pcm[0], np.empty(n + 1, np.float32))
+    with pytest.raises(EOFError):
+        hip.update_raw_async(np.empty((n, 0), '<i2'))
+
+
 # ---- BASELINE configs[0]: one stream through the engine executable (plumbing) ------------------------
 def test_precise_engine_subprocess_protocol(model_file, stock_weights):
     """PreciseEngine + `python -m mycroft_precise_amd.scripts.engine`: raw int16 on stdin, one ASCII
@@ -1451,3 +1611,20 @@ def test_precise_engine_subprocess_protocol(model_file, stock_weights):
     finally:
         eng.stop()
     assert _decode_flips(got, g['decoded'][0][:12]) == DECODE_FLIPS['engine']
+
+
+def test_reference_module_name_runs_the_engine(model_file, stock_weights):
+    """`python -m precise.scripts.engine model 2048` with compat/ on the path -- the literal command the reference's
+    PreciseEngine spawns (runner.py:48-52): under -m the alias file IS __main__, so it has to start the engine itself
+    (it used to exit 0 without a line, and a PreciseEngine saw immediate EOF)."""
+    from mycroft_precise_amd.runner import PreciseEngine
+    g = golden('listener_chunk2048.npz')
+    env = dict(os.environ, PYTHONPATH=os.path.join(REPO, 'compat') + os.pathsep + REPO + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    eng = PreciseEngine([sys.executable, '-m', 'precise.scripts.engine'], model_file, 2048)
+    eng.proc = subprocess.Popen(eng.exe_args, stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env, cwd=REPO)
+    try:
+        data = g['pcm'][0].tobytes()
+        got = [eng.get_prediction(data[off:off + 2048]) for off in range(0, 2048 * 6, 2048)]
+    finally:
+        eng.stop()
+    assert _decode_flips(got, g['decoded'][0][:6]) == DECODE_FLIPS['engine']
