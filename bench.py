@@ -349,7 +349,10 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
                       'mfcc_dtype': mfcc_precision, 'feature_rows': ring_precision,
                       'gru_form': ({0: 'bf16 operands, eight gate values per lane (gru_bf16_device.h)', 1: 'bf16 operands, five gate values per lane (gru_b20_device.h)'}[tiling_used]
                                    if gru_precision == 'bf16' else
-                                   {-1: 'streamed-weight wide kernel, v_mfma_f32_16x16x4_f32', 0: 'classic tiling, v_mfma_f32_16x16x4_f32', 1: 're-tiled stock width, v_mfma_f32_16x16x4_f32',
+                                   {0: 'streamed float32 weights, v_mfma_f32_16x16x4_f32 (gru_wide_device.h)',
+                                    2: 'streamed float32 weights split into 3 bf16 pieces in registers, products on v_mfma_f32_16x16x32_bf16 (gru_wide_x3_device.h)'}[tiling_used]
+                                   if len(units) > 1 or units[0] > 32 else
+                                   {0: 'classic tiling, v_mfma_f32_16x16x4_f32', 1: 're-tiled stock width, v_mfma_f32_16x16x4_f32',
                                     2: 'float32 operands as 3 x bf16 pieces, 6 piece products on v_mfma_f32_16x16x32_bf16, float32 accumulate / gates / state'}[tiling_used]),
                       'resident_pcm_mb': n_res * chunk_bytes / 1e6},
            'stage_ms': {'update_back_to_back': update_ms, 'mfcc_launch_alone': mfcc_ms, 'network_launch_alone': gru_ms},
@@ -434,6 +437,8 @@ def single_stream_latency_extra(n_calls=400):
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, 'synthetic.npz')
         save_weights(path, synth.make_weights())
+        from mycroft_precise_amd.params import save_params
+        save_params(path)                          # (a model without its .params makes inject_params print a warning -- to stdout, as the reference does)
         lis = Listener(path, 2 * CHUNK)
         pcm = synth.stream_pcm(0, 64 * CHUNK)
         chunks = [pcm[i * CHUNK:(i + 1) * CHUNK].tobytes() for i in range(64)]

@@ -45,8 +45,8 @@ typedef struct pe_params {
     int32_t sample_rate;     /* 16000                                        params.py:142 */
     int32_t window_samples;  /* 1600   int(sample_rate*window_t+0.5)         params.py:84  */
     int32_t hop_samples;     /* 800    int(sample_rate*hop_t+0.5)            params.py:89  */
-    int32_t n_fft;           /* 512    a power of two in 64..2048, or ANY other
-                                       length in 16..1024 (np.fft.rfft takes any n) params.py:142 */
+    int32_t n_fft;           /* 512    ANY length in 16..1024 (np.fft.rfft takes any n),
+                                       or the power of two 2048                       params.py:142 */
     int32_t n_filt;          /* 20     mel filters, 1..128                   params.py:142 */
     int32_t n_mfcc;          /* 13     coefficients kept, 1..32, <= n_filt   params.py:142
                                 Front-end kernels: the stock shape (n_fft = 512, <= 64 filters whose runs fit the 64
@@ -55,9 +55,10 @@ typedef struct pe_params {
                                 results contract, two launches per update, pe_update_many = the same updates one after
                                 the other).  17..32 coefficients feed the float32 network of <= 32 units without
                                 use_delta only; the bf16 configuration exists for the stock shape only.  An n_fft that is
-                                not a power of two runs as Bluestein's chirp-z transform over the next power of two
-                                >= 2 n_fft - 1 (one wave's LDS holds it up to n_fft = 1024).  Outside the ranges
-                                (n_fft > 2048, not a power of two and > 1024, < 16, ...): PE_ERR_UNSUPPORTED.          */
+                                not a power of two >= 64 (16 and 32 included) runs as Bluestein's chirp-z transform over
+                                the next power of two >= max(128, 2 n_fft - 1) (one wave's LDS holds it up to n_fft =
+                                1024).  Outside the ranges (n_fft > 2048, not a power of two and > 1024, < 16, ...):
+                                PE_ERR_UNSUPPORTED.                                                                    */
     int32_t n_features;      /* 29     T, timesteps per network input        params.py:79  */
     int32_t use_delta;       /* 0      1: network inputs are [x_t, x_t - x_(t-1)]
                                        (vectorization.py:53-59), layer n_in = 2 n_mfcc   params.py:143 */
@@ -129,8 +130,8 @@ int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples
  * engine's own) while update u runs (a compute stream of the engine's own), the probabilities come back behind the
  * launch; up to 3 updates are in flight, a 4th call first delivers the oldest.  raw_out_host[n_streams] is valid after
  * pe_wait (or once 3 more updates have been enqueued).  Results are bit-identical to pe_update / pe_update_device.
- *   - pageable pcm_host / raw_out_host: copied through the engine's pinned staging ring at the call (the caller's PCM
- *     buffer is free again when the call returns);
+ *   - pageable pcm_host: staged by the HIP runtime at the call (the caller's PCM buffer is free again when the call
+ *     returns); pageable raw_out_host: filled from the engine's pinned ring when the update is delivered;
  *   - buffers from pe_host_alloc (pinned, device-visible; freed by pe_host_free or pe_destroy): ZERO-COPY -- the DMA
  *     reads / writes them directly, which is what reaches PCIe line rate (a CPU memcpy of 8 MB per update does not);
  *     such a PCM buffer must stay untouched until pe_wait or until 3 more updates have been enqueued.
@@ -268,13 +269,18 @@ int pe_set_gru_waves(pe_engine* e, int32_t waves_per_tile);
  *       than four per compute unit: above 16 384 streams on MI355X), where it takes two launches per update instead of
  *       the fused one and is still faster.
  * Every kernel shape of ONE form agrees bit for bit (pe_update / pe_update_many / pe_predict / pe_evaluate, one or four
- * waves, fused or not); the forms agree to float32 summation order (<= 1e-6 on the probability).  Ignored by the wide
- * networks and with projection rows; use_delta models of the stock width follow 0 / 1.
+ * waves, fused or not); the forms agree to float32 summation order (<= 1e-6 on the probability).  Ignored with projection
+ * rows; use_delta models of the stock width follow 0 / 1.
+ * Wide / stacked networks (33..256 units) have two forms: 0 (and -1, the default) = the streamed-weight kernel on f32-input MFMAs
+ * (csrc/gru_wide_device.h), 2 = float32 products on the bf16 pipe with the float32 weight stream split into three bf16 pieces in
+ * registers, on the matrix pipe, every timestep (csrc/gru_wide_x3_device.h): same tolerance, measured EQUAL in time at 256 x 2
+ * units (five 4-pass MFMAs + twelve vector instructions against four 8-pass MFMAs per tile and 16 source units), kept as the
+ * form whose matrix time would shrink with a narrower weight stream; 1 is refused.
  * bf16-operand networks (gru_precision = 1) have two layouts of the same arithmetic contract (tolerance 1e-2, each bit-stable
  * across pe_update / pe_update_many / pe_predict): 1 (and -1, the default, where it fits: <= 20 units, <= 14 features) = five
  * gate values per lane (csrc/gru_b20_device.h: 9 MFMAs per timestep), 0 = eight values per lane (csrc/gru_bf16_device.h: 12
  * MFMAs, every width up to 32); 2 is refused.
- * pe_get_gru_tiling: the form this engine's launches take now (0 / 1 / 2; -1 for wide networks; -2 for a null engine). */
+ * pe_get_gru_tiling: the form this engine's launches take now (0 / 1 / 2; -2 for a null engine). */
 int pe_set_gru_tiling(pe_engine* e, int32_t tiling);
 int pe_get_gru_tiling(const pe_engine* e);
 

@@ -80,6 +80,9 @@ struct pe_engine {
     float* wide_buf[2][6] = {{nullptr}};     // per layer: wx1, wr1, wx2, wr2, b1, b2
     int wide_kx4[2] = {1, 1};
     float* wide_wd = nullptr;
+    // the same network packed for gru_wide_x3_device.h (row i of tile tau = unit 16 tau + i; k-slot 8 gk + e = source unit 16 kappa + 4 gk + e)
+    float* wide3_buf[2][6] = {{nullptr}};
+    float* wide3_wd = nullptr;
     // bf16-operand network (pe_params.gru_precision = 1)
     uint16_t* wx_bf16 = nullptr; uint16_t* wr_bf16 = nullptr; float* wd_bf16 = nullptr;
     uint32_t* b20_blob = nullptr;     // the same network in the layout of gru_b20_device.h (<= 20 units, <= 14 features)
@@ -598,6 +601,57 @@ int pack_gru_weights_wide(pe_engine* e, const pe_weights* w) {
     return dev_upload(e, &e->wide_wd, wd);
 }
 
+// The same network for gru_wide_x3_device.h: float32 weights (split into bf16 pieces in registers, every timestep), wave w
+// owns output tiles tau = w TPW + t of every gate; row i of a tile <-> unit 16 tau + i; k-group kappa, lane (row i, k-group
+// slot gk) <-> source units 16 kappa + 4 gk + e, e = 0..3 (layer 0 input: feature 4 gk + e).  Streams: [wave][kappa][tile][lane] float4.
+int pack_gru_weights_wide_x3(pe_engine* e, const pe_weights* w) {
+    const int H = w->layers[0].units, WV = 4, TPW = H / (16 * WV), H16 = H / 16;
+    for (int l = 0; l < w->n_layers; ++l) {
+        const pe_gru_layer& L = w->layers[l];
+        const int kin = l == 0 ? 1 : H16;
+        const int F = L.n_in;
+        for (int phase = 0; phase < 2; ++phase) {
+            const int NT = phase == 0 ? 2 * TPW : TPW;
+            std::vector<float> wx((size_t)WV * kin * NT * 64 * 4, 0.f), wr((size_t)WV * H16 * NT * 64 * 4, 0.f);
+            std::vector<float> bias((size_t)WV * NT * 4 * 64, 0.f);
+            for (int wv = 0; wv < WV; ++wv)
+                for (int tl = 0; tl < NT; ++tl) {
+                    const int gate = phase == 0 ? (tl < TPW ? 0 : 1) : 2;
+                    const int tau = wv * TPW + (tl % TPW);
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i = lane & 15, gk = lane >> 4;
+                        const int col = gate * H + 16 * tau + i;
+                        // gate-major streams: [gate within the phase][wave][k-group][tile of the gate][lane] float4 (the kernel walks
+                        // one gate's TPW tiles at a time: wide_x3_accumulate)
+                        const int gsel = phase == 0 ? tl / TPW : 0, tp = tl % TPW;
+                        for (int kap = 0; kap < kin; ++kap)
+                            for (int q = 0; q < 4; ++q) {
+                                const int src = 16 * kap + 4 * gk + q;
+                                wx[(((((size_t)gsel * WV + wv) * kin + kap) * TPW + tp) * 64 + lane) * 4 + q] = src < F ? L.kernel[(size_t)src * 3 * H + col] : 0.f;
+                            }
+                        for (int kap = 0; kap < H16; ++kap)
+                            for (int q = 0; q < 4; ++q)
+                                wr[(((((size_t)gsel * WV + wv) * H16 + kap) * TPW + tp) * 64 + lane) * 4 + q] =
+                                    L.recurrent_kernel[(size_t)(16 * kap + 4 * gk + q) * 3 * H + col];
+                        for (int q = 0; q < 4; ++q)      // C operand: this lane's output rows 4 gk + q
+                            bias[(((size_t)wv * NT + tl) * 4 + q) * 64 + lane] = L.bias[gate * H + 16 * tau + 4 * gk + q];
+                    }
+                }
+            int rc;
+            if ((rc = dev_upload(e, &e->wide3_buf[l][phase == 0 ? 0 : 2], wx))) return rc;
+            if ((rc = dev_upload(e, &e->wide3_buf[l][phase == 0 ? 1 : 3], wr))) return rc;
+            if ((rc = dev_upload(e, &e->wide3_buf[l][phase == 0 ? 4 : 5], bias))) return rc;
+        }
+    }
+    std::vector<float> wd((size_t)WV * TPW * 4 * 64, 0.f);
+    for (int wv = 0; wv < WV; ++wv)
+        for (int tp = 0; tp < TPW; ++tp)
+            for (int q = 0; q < 4; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    wd[(((size_t)wv * TPW + tp) * 4 + q) * 64 + lane] = w->dense_kernel[16 * (wv * TPW + tp) + 4 * (lane >> 4) + q];
+    return dev_upload(e, &e->wide3_wd, wd);
+}
+
 // Samples of the virtual stream that must have arrived, counted from a frame's first sample, before the
 // reference's Listener has that frame in its window: the whole analysis window (sonopy emits one frame per
 // full window), plus one hop for the legacy speechpy front end, whose stack_frames returns
@@ -751,24 +805,33 @@ GruArgs gru_args(const pe_engine* e) {
     return a;
 }
 
+// which form a wide engine's launches take: the XDL form when asked for (pe_set_gru_tiling(e, 2)); the default stays the
+// f32-input MFMA kernel -- measured equal (1.26 ms per launch at 256 x 2, profiles/round5/r5f_wide_forms.log) and float32-exact
+bool wide_uses_x3(const pe_engine* e) { return e->wide && e->gru_tiling == 2; }
+
 // Network launch for any input mode (0 explicit batch, 1 ring, 2 row sequence)
 int launch_network(pe_engine* e, const GruArgs& g, int mode, hipStream_t s) {
     if (e->wide) {
+        // two forms of the streamed-weight network (pe_set_gru_tiling): 0 = f32-input MFMAs (gru_wide_device.h), 2 = float32
+        // products on the bf16 pipe with the float32 weights split in registers (gru_wide_x3_device.h)
+        const bool x3 = wide_uses_x3(e);
+        float* const (*buf)[6] = x3 ? e->wide3_buf : e->wide_buf;
         WideArgs wa{};
         wa.base = g;
         wa.n_layers = e->n_layers;
         wa.units = e->units;
-        wa.wd = e->wide_wd;
+        wa.wd = x3 ? e->wide3_wd : e->wide_wd;
         for (int l = 0; l < e->n_layers; ++l) {
-            wa.layer[l].wx1 = reinterpret_cast<const float4*>(e->wide_buf[l][0]);
-            wa.layer[l].wr1 = reinterpret_cast<const float4*>(e->wide_buf[l][1]);
-            wa.layer[l].wx2 = reinterpret_cast<const float4*>(e->wide_buf[l][2]);
-            wa.layer[l].wr2 = reinterpret_cast<const float4*>(e->wide_buf[l][3]);
-            wa.layer[l].b1 = e->wide_buf[l][4];
-            wa.layer[l].b2 = e->wide_buf[l][5];
+            wa.layer[l].wx1 = reinterpret_cast<const float4*>(buf[l][0]);
+            wa.layer[l].wr1 = reinterpret_cast<const float4*>(buf[l][1]);
+            wa.layer[l].wx2 = reinterpret_cast<const float4*>(buf[l][2]);
+            wa.layer[l].wr2 = reinterpret_cast<const float4*>(buf[l][3]);
+            wa.layer[l].b1 = buf[l][4];
+            wa.layer[l].b2 = buf[l][5];
             wa.layer[l].kx4 = e->wide_kx4[l];
         }
-        PE_HIP(e, launch_gru_wide(wa, mode, s));
+        if (x3) PE_HIP(e, launch_gru_wide_x3(wa, mode, s));
+        else PE_HIP(e, launch_gru_wide(wa, mode, s));
         return PE_OK;
     }
     PE_HIP(e, launch_gru_small(g, mode, s));
@@ -904,8 +967,9 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     // one-frame-per-wave kernel, every other shape on the general front end (mfcc_general_device.h)
     // ... any n_fft from 16 on: powers of two up to 2048 as a packed real transform, every other length up to 1024 (numpy's
     // rfft takes any n) through Bluestein's chirp-z form over the next power of two >= 2 n_fft - 1
-    if (p->n_fft < 16 || p->n_fft > kGeneralMaxFft || (!general_is_pow2(p->n_fft) && p->n_fft > kGeneralMaxBlueFft) || (general_is_pow2(p->n_fft) && p->n_fft < 64))
-        return fail(nullptr, PE_ERR_UNSUPPORTED, "n_fft must be a power of two in 64..%d or any other length in 16..%d (got %d)", kGeneralMaxFft, kGeneralMaxBlueFft, p->n_fft);
+    // (general_is_pow2: powers of two from 64 on; 16 and 32 run as Bluestein transforms over 128 points like every other short length)
+    if (p->n_fft < 16 || p->n_fft > kGeneralMaxFft || (!general_is_pow2(p->n_fft) && p->n_fft > kGeneralMaxBlueFft))
+        return fail(nullptr, PE_ERR_UNSUPPORTED, "n_fft must be any length in 16..%d or a power of two up to %d (got %d)", kGeneralMaxBlueFft, kGeneralMaxFft, p->n_fft);
     if (p->n_mfcc < 1 || p->n_mfcc > kGeneralMaxMfcc) return fail(nullptr, PE_ERR_UNSUPPORTED, "n_mfcc must be in 1..%d (got %d)", kGeneralMaxMfcc, p->n_mfcc);
     if (p->n_filt < 1 || p->n_filt > kGeneralMaxFilt || p->n_mfcc > p->n_filt)
         return fail(nullptr, PE_ERR_UNSUPPORTED, "need 1 <= n_mfcc <= n_filt <= %d (got n_filt=%d n_mfcc=%d)", kGeneralMaxFilt, p->n_filt, p->n_mfcc);
@@ -942,6 +1006,12 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     hipError_t herr = hipSetDevice(device);
     if (herr != hipSuccess) return fail(nullptr, PE_ERR_HIP, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(herr));
 
+    {   // the library holds gfx950 code objects only, and every launch-shape rule in here (tiles per compute unit at which the
+        // network changes form, frame workgroups per compute unit) was measured on MI355X: refuse anything else by name
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(nullptr, PE_ERR_UNSUPPORTED, "device %d is %s: libprecise_engine.so is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    }
     if (p->n_mfcc > kRowFloats && (wide || p->use_delta || p->gru_precision != 0))
         return fail(nullptr, PE_ERR_UNSUPPORTED, "more than 16 coefficients per frame feed the float32 network of <= 32 units without delta features only");
     if (general && (p->gru_precision != 0 || p->ring_precision != 0))
@@ -1017,6 +1087,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
             pe_weights wp{w->n_layers, lp.data(), dp.data(), w->dense_bias};
             e->units = Hp;
             if ((rc = pack_gru_weights_wide(e, &wp))) break;
+            if ((rc = pack_gru_weights_wide_x3(e, &wp))) break;
         }
         else if ((rc = pack_gru_weights(e, L, w->dense_kernel))) break;
         if (p->gru_precision == 1 && (rc = pack_gru_weights_bf16(e, L, w->dense_kernel))) break;
@@ -1168,12 +1239,10 @@ int pe_update_async(pe_engine* e, const int16_t* pcm_host, int32_t chunk, float*
     const size_t pcm_bytes = (size_t)e->n_streams * chunk * sizeof(int16_t), out_bytes = (size_t)e->n_streams * sizeof(float);
     if ((rc = ensure(e, sl.dev_in, pcm_bytes))) return rc;
     if ((rc = ensure(e, sl.dev_out, out_bytes))) return rc;
+    // (pageable memory: hipMemcpyAsync stages it through the runtime's own pinned buffers and returns once the last piece is
+    //  staged -- the caller gets its buffer back at the return of this call either way; measured: 207 us per 8.4 MB update that
+    //  way against 295 us with a memcpy into a pinned ring of the engine's own, 165 us zero-copy from pe_host_alloc'ed memory)
     const void* src = pcm_host;
-    if (!is_pinned(e, pcm_host, pcm_bytes)) {          // pageable memory: the caller gets its buffer back at once
-        if ((rc = ensure_pinned(e, &sl.pin_in, &sl.pin_in_bytes, pcm_bytes))) return rc;
-        std::memcpy(sl.pin_in, pcm_host, pcm_bytes);
-        src = sl.pin_in;
-    }
     sl.direct_out = is_pinned(e, raw_out_host, out_bytes);
     if (!sl.direct_out) {
         void* po = sl.pin_out;
@@ -1601,6 +1670,12 @@ int pe_set_gru_waves(pe_engine* e, int32_t waves) {
 int pe_set_gru_tiling(pe_engine* e, int32_t tiling) {
     if (!e) return PE_ERR_INVALID;
     if (tiling < -1 || tiling > 2) return fail(e, PE_ERR_INVALID, "gru tiling must be -1 (auto), 0 (classic), 1 (re-tiled) or 2 (XDL form)");
+    if (e->wide) {
+        if (tiling == 1) return fail(e, PE_ERR_UNSUPPORTED, "wide networks have two forms: 0 (f32-input MFMAs) and 2 (float32 products on the bf16 pipe)");
+        PE_DRAIN(e);
+        e->gru_tiling = tiling;
+        return PE_OK;
+    }
     if (tiling == 2 && !e->x3_blob)
         return fail(e, PE_ERR_UNSUPPORTED, "the XDL form of the float32 network (tiling 2) takes <= 20 units, <= 15 inputs, float32 operands, no use_delta");
     if (tiling == 1 && e->prm.gru_precision == 1 && !e->b20_blob)
@@ -1612,7 +1687,7 @@ int pe_set_gru_tiling(pe_engine* e, int32_t tiling) {
 
 int pe_get_gru_tiling(const pe_engine* e) {
     if (!e) return -2;               // (not PE_ERR_INVALID = 1, which is a valid answer)
-    if (e->wide) return -1;
+    if (e->wide) return wide_uses_x3(e) ? 2 : 0;
     if (e->prm.gru_precision != 0) return gru_args(e).b20 ? 1 : 0;
     const GruArgs a = gru_args(e);
     return a.x3 ? 2 : a.cw ? 1 : 0;

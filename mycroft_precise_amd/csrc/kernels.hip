@@ -15,6 +15,7 @@
 #include "gru_b20_device.h"
 #include "gru_x3_device.h"
 #include "gru_wide_device.h"
+#include "gru_wide_x3_device.h"
 #include "mfcc_general_device.h"
 
 namespace pe {
@@ -186,6 +187,39 @@ static hipError_t launch_wide_t(const WideArgs& a, int mode, hipStream_t s) {
     else if (mode == kRows) hipLaunchKernelGGL((gru_wide_kernel<TPW, kRows, WAVES>), dim3(tiles), dim3(64 * WAVES), lds, s, a);
     else hipLaunchKernelGGL((gru_wide_kernel<TPW, kFeats, WAVES>), dim3(tiles), dim3(64 * WAVES), lds, s, a);
     return hipGetLastError();
+}
+
+// ---- the same network with the float32 products on the bf16 matrix pipe (gru_wide_x3_device.h; pe_set_gru_tiling(e, 2)) ----
+#ifndef PE_WIDE_X3_KS
+#define PE_WIDE_X3_KS 2         // 2: eight waves per workgroup, the k-groups of every contraction cut in two (widths that are multiples of 128)
+#endif
+template <int TPW, int MODE, int KS>
+__global__ __launch_bounds__(256 * KS) void gru_wide_x3_kernel(const WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    gru_wide_x3_tile<TPW, MODE, KS>(a, blockIdx.x, wave, threadIdx.x & 63, smem);
+}
+
+template <int TPW>
+static hipError_t launch_wide_x3_t(const WideArgs& a, int mode, hipStream_t s) {
+    const int tiles = (a.base.n_streams + kTileStreams - 1) / kTileStreams;
+    if (tiles == 0) return hipSuccess;
+    constexpr int KS = (PE_WIDE_X3_KS == 2 && TPW % 2 == 0) ? 2 : 1;
+    const size_t lds = wide_x3_lds_bytes<TPW>();          // three state vectors + partial sums / z / float32 state of the lead waves
+    if (mode == kRing) hipLaunchKernelGGL((gru_wide_x3_kernel<TPW, kRing, KS>), dim3(tiles), dim3(256 * KS), lds, s, a);
+    else if (mode == kRows) hipLaunchKernelGGL((gru_wide_x3_kernel<TPW, kRows, KS>), dim3(tiles), dim3(256 * KS), lds, s, a);
+    else hipLaunchKernelGGL((gru_wide_x3_kernel<TPW, kFeats, KS>), dim3(tiles), dim3(256 * KS), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gru_wide_x3(const WideArgs& a, int mode, hipStream_t s) {
+    switch (a.units / 64) {
+        case 1: return launch_wide_x3_t<1>(a, mode, s);
+        case 2: return launch_wide_x3_t<2>(a, mode, s);
+        case 3: return launch_wide_x3_t<3>(a, mode, s);
+        case 4: return launch_wide_x3_t<4>(a, mode, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 // 8 waves per workgroup (two per SIMD) for H = 128 / 256 was measured and is NOT faster: 256 x 2 layers, 4096

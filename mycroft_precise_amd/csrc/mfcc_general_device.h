@@ -53,7 +53,8 @@ constexpr int kGeneralMaxMfcc = 32;
 // per wave in float64 at n_fft = 1024, i.e. sixteen instead of twelve waves per compute unit -- 4096 streams in ONE round of
 // resident waves instead of two (measured: 47.7 -> us per update).
 __host__ __device__ inline bool general_overlay(int n_fft) { return n_fft <= 1024; }
-__host__ __device__ inline bool general_is_pow2(int n_fft) { return (n_fft & (n_fft - 1)) == 0; }
+// lengths that take the packed real transform: powers of two from 64 on (a butterfly per lane); 16 and 32 go the Bluestein way
+__host__ __device__ inline bool general_is_pow2(int n_fft) { return (n_fft & (n_fft - 1)) == 0 && n_fft >= 64; }
 // Bluestein transform length for a non-power-of-two n_fft: the next power of two >= 2 n_fft - 1
 __host__ __device__ inline int general_blue_log2(int n_fft) { int b = 7; while ((1 << b) < 2 * n_fft - 1) ++b; return b; }      // (>= 128 points: a butterfly per lane)
 __host__ __device__ inline size_t general_lds_bytes(int real_size, int n_fft, int n_filt, int n_rounds) {
@@ -133,7 +134,6 @@ __device__ __forceinline__ void general_frame_tail(const GeneralTables& t, const
 // After the call: coefficient c (c < n_mfcc) sits in lane c of `coeff`; LM[f] holds the log-mel energy of filter f.
 template <class R, int BITS, class Point>
 __device__ __forceinline__ void general_frame_t(const GeneralTables& t, R* S, const int lane, Point point, R (&coeff)[1]) {
-    using K = RealK<R>;
     constexpr int M = 1 << BITS, NP = (M + 63) / 64, NB = (M / 2 + 63) / 64, NS = (M / 2 + 1 + 63) / 64;
     constexpr bool OVERLAY = BITS <= 9;              // (general_overlay: n_fft <= 1024)
     cplx<R>* Z = reinterpret_cast<cplx<R>*>(S);

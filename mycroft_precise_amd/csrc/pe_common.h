@@ -255,6 +255,7 @@ int gru_small_regs(int units);                  // R = ceil(units/4)
 int gru_wide_waves(int units);                  // waves per workgroup of the wide kernel (the weight packing follows it)
 int gru_small_tiles(int units);                 // NT = ceil(3R/4)
 hipError_t launch_gru_wide(const WideArgs& a, int input_mode, hipStream_t s);      // units 64..256, 1-2 layers
+hipError_t launch_gru_wide_x3(const WideArgs& a, int input_mode, hipStream_t s);   // the same, float32 products on the bf16 pipe (its own weight packing)
 hipError_t launch_gather(const GatherArgs& a, hipStream_t s);
 hipError_t launch_scatter(const GatherArgs& a, int32_t* st_q, uint32_t* st_kc, hipStream_t s);   // a.out is read
 hipError_t launch_clear(const ClearArgs& a, hipStream_t s);

@@ -518,6 +518,9 @@ GENERAL_PARAMS = [
     dict(n_fft=1000, n_filt=40, n_mfcc=20),                                   # even, 2 N - 1 just below 2048
     dict(n_fft=399, n_filt=20, n_mfcc=13),                                    # odd length: 200 bins
     dict(n_fft=96, n_filt=10, n_mfcc=8, window_t=0.005, hop_t=0.0025, buffer_t=0.2),     # window (80) < n_fft: zero-padded frames
+    # the short powers of two (refused until round 5 although 17..63 were served): Bluestein over 128 points
+    dict(n_fft=32, n_filt=8, n_mfcc=6, window_t=0.005, hop_t=0.0025, buffer_t=0.2),
+    dict(n_fft=16, n_filt=5, n_mfcc=4, window_t=0.001, hop_t=0.001, buffer_t=0.05),      # window == n_fft == 16 samples
 ]
 
 
@@ -758,12 +761,17 @@ def test_use_delta_matches_reference_semantics(tmp_path):
 
 # ---- BASELINE configs[3]: wide / stacked GRU (streamed-weight kernel) ------------------------------------
 @pytest.mark.parametrize('units', [(256, 256), (64,), (128, 128), (192,), (256,), (33,), (100,), (128, 64), (72, 200), (250, 250)])
-def test_wide_gru_predict_matches_oracle(units):
+@pytest.mark.parametrize('tiling', [0, 2], ids=['f32mfma', 'xdl'])
+def test_wide_gru_predict_matches_oracle(units, tiling):
     """Widths that are not multiples of 64 (and stacked layers of different widths) run zero-padded to the next
-    multiple: a padded unit's state stays exactly 0."""
+    multiple: a padded unit's state stays exactly 0.  Both forms of the streamed-weight network (pe_set_gru_tiling: 0 =
+    f32-input MFMAs, gru_wide_device.h; 2 = float32 products on the bf16 pipe, the float32 weights split in registers every
+    timestep, gru_wide_x3_device.h -- the default) at the float32 guard."""
     from mycroft_precise_amd._lib import HipEngine
     w = synth.make_weights(units=units, seed=500 + sum(units))
     eng = HipEngine(P.pr, w, n_streams=1)
+    eng.set_gru_tiling(tiling)
+    assert eng.gru_tiling() == tiling
     rng = np.random.default_rng(len(units))
     for n in (1, 17, 70):
         x = rng.normal(0, 2, (n, 29, 13)).astype(np.float32)
@@ -772,13 +780,15 @@ def test_wide_gru_predict_matches_oracle(units):
     eng.close()
 
 
-def test_wide_gru_update_many_equals_consecutive_updates():
+@pytest.mark.parametrize('tiling', [0, 2], ids=['f32mfma', 'xdl'])
+def test_wide_gru_update_many_equals_consecutive_updates(tiling):
     """pe_update_many with the streamed-weight network (one network launch per update of the call)."""
     from mycroft_precise_amd._lib import HipEngine
     w = synth.make_weights(units=(128, 100), seed=9)
     n = 37
     pcm = _stream_batch(['tone_noise'] * (n - 2) + ['zeros', 'square'], 24)
     a, b = HipEngine(P.pr, w, n_streams=n), HipEngine(P.pr, w, n_streams=n)
+    a.set_gru_tiling(tiling); b.set_gru_tiling(tiling)
     b.reserve_updates(6, 1024)
     for u in range(0, 24, 6):
         want = np.stack([a.update(pcm[u + i]) for i in range(6)])
@@ -786,7 +796,8 @@ def test_wide_gru_update_many_equals_consecutive_updates():
     a.close(); b.close()
 
 
-def test_wide_gru_streaming_and_offline_match_oracle():
+@pytest.mark.parametrize('tiling', [0, 2], ids=['f32mfma', 'xdl'])
+def test_wide_gru_streaming_and_offline_match_oracle(tiling):
     """configs[3] (256 x 2 layers) behind the same streaming front end: BatchedListener updates, masked
     clear, and the offline evaluator."""
     from mycroft_precise_amd.network_runner import BatchedListener, HipRunner
@@ -795,6 +806,7 @@ def test_wide_gru_streaming_and_offline_match_oracle():
     n, n_up = 21, 36
     pcm = _stream_batch(['tone_noise'] * (n - 3) + ['zeros', 'square', 'quiet'], n_up)
     hip = BatchedListener(w, n)
+    hip.engine.set_gru_tiling(tiling)
     refs = [ol.OracleListener(w) for _ in range(n)]
     for u in range(n_up):
         if u == 20:
@@ -806,6 +818,7 @@ def test_wide_gru_streaming_and_offline_match_oracle():
         want = np.array([r.update_raw(pcm[u, j].tobytes()) for j, r in enumerate(refs)])
         assert np.abs(raw - want).max() <= GUARD_RAW, u
     runner = HipRunner(weights=w)
+    runner.engine.set_gru_tiling(tiling)
     audio = synth.stream_pcm(9, 16000 * 4).astype(np.float32) / np.float32(32768.0)
     got = runner.evaluate(audio, 2048)
     mf = so.mfcc_spec(audio.astype(np.float64), 16000, (1600, 800))
@@ -1441,11 +1454,13 @@ def test_full_batch_general_front_end_4096_streams_properties():
     one.close()
 
 
-def test_full_batch_wide_gru_4096_streams_properties():
+@pytest.mark.parametrize('tiling', [0, 2], ids=['f32mfma', 'xdl'])
+def test_full_batch_wide_gru_4096_streams_properties(tiling):
     """BASELINE configs[3]: 256 x 2 layers at 4096 streams = 256 workgroups sharing one L2-resident weight
     stream -- where a stale read or an ordering slip between workgroups would show."""
     w = synth.make_weights(units=(256, 256), seed=5)
-    hip, base, owner, first = _full_size_run(w, 4096, 31, 16, GUARD_RAW)
+    hip, base, owner, first = _full_size_run(w, 4096, 31, 16, GUARD_RAW, gru_tiling=tiling)
+    assert hip.engine.gru_tiling() == tiling
     # Runner.predict on the windows the streams hold now == the streaming output, bit for bit
     feats = hip.engine.get_vectors()
     assert np.array_equal(hip.engine.predict(feats)[:, 0], first[-1])

@@ -15,6 +15,9 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 dev = torch.device('cuda:0')
 w = synth.make_weights(pr.n_mfcc, units)
 eng = _lib.HipEngine(pr, w, n_streams=B)
+if os.environ.get('PE_WIDE_TILING'):
+    eng.set_gru_tiling(int(os.environ['PE_WIDE_TILING']))      # 0 = f32-input MFMAs, 2 = float32 products on the bf16 pipe
+print('form', eng.gru_tiling(), end='  ')
 pcm = (torch.randn((40, B, 1024), device=dev) * 3000).to(torch.int16)
 out = torch.zeros(B, device=dev)
 st = torch.cuda.current_stream().cuda_stream
