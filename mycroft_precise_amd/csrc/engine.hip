@@ -789,6 +789,7 @@ GruArgs gru_args(const pe_engine* e) {
     // still runs in one round of waves, and the missing fused launch costs more than the cheaper network saves).
     const bool x3_ok = e->x3_blob && !a.bf16 && !e->wide && !a.proj_ring && e->row_floats == kRowFloats && e->gru_waves != 16;
     a.x3 = x3_ok && (e->gru_tiling == 2 || (e->gru_tiling < 0 && e->n_tiles > 4 * e->n_cus)) ? e->x3_blob : nullptr;
+    a.x3w = e->x3_blob;
     const bool cw_ok = e->cw_blob && e->row_floats == kRowFloats && !a.proj_ring && !a.bf16 && !a.x3 && !e->wide && e->gru_waves != 16;
     const bool retile = cw_ok && (e->gru_tiling == 1 || (e->gru_tiling < 0 && e->n_tiles <= 2 * e->n_cus));
     const int auto_waves = retile ? (e->n_tiles <= 2 * e->n_cus ? 4 : 1) : (e->n_tiles <= e->n_cus ? 4 : 1);

@@ -31,6 +31,7 @@
 #pragma once
 #include "gru_device.h"
 #include "gru_cw_pack.h"
+#include "gru_x3_device.h"     // (round 5, PE_CW_VAR bit 6: the timing experiment with XDL chains on wave R)
 
 namespace pe {
 
@@ -341,6 +342,12 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
     constexpr bool HAND = !VF && (VAR & 8) != 0;          // R's whole timestep as one pinned sequence
     constexpr bool EARLY = !VF && (VAR & 16) != 0 && !C4_ON_Z2 && !HAND;     // R's mailbox reads issued before the barrier, tag-validated
     constexpr bool NOBAR = !VF && (VAR & 32) != 0 && !C4_ON_Z2 && !HAND && !EARLY;   // no s_barrier in the time loop: every hand-off tag-polled
+    // bit 6 (round 5, VERDICT r4 #6: "the one variant that is still an estimate"): R's two chains as float32 products on the bf16
+    // pipe (gru_x3_device.h: four dependent 4-pass MFMAs instead of five dependent 8-pass ones + five two-pass partial sums +
+    // a cross-lane reduction), h and r.h split into three bf16 pieces on R.  TIMING EXPERIMENT ONLY: the helpers keep their
+    // float32 layout (unit 4 q + g), R computes in the x3 layout (unit 4 g + q) -- the instruction stream of the real thing,
+    // wrong numbers; tuning builds, never the product (profiles/round5/r5g_cw_x3_chain.log).
+    constexpr bool X3R = !VF && (VAR & 64) != 0;
     static_assert(!(C4_ON_Z2 || EARLY || NOBAR) || CwBox::END2 <= CwLds::XR, "variant bits 1, 4 and 5 need -DPE_CW_BIG_BOX");
     const int g = lane >> 4, j = lane & 15;
     const long long stream = (long long)tile * kTileStreams + j;
@@ -477,10 +484,62 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
         float ri = L2[CwBox::PV], ci = L2[CwBox::PV + 1];
         __builtin_amdgcn_s_waitcnt(0xc07f);
         PE_GT(1);
+        // (bit 6) the XDL operands of the r tile, the candidate tile and the quarter tile
+        bf16x8 x3ar[3][kX3RecOps];
+        X3Ident x3id = x3_identity(lane);
+        uint4 x3keep = {0u, 0u, 0u, 0u};
+        if (X3R) {
+            const uint4* blob = reinterpret_cast<const uint4*>(a.x3w);
+#pragma unroll
+            for (int tsel = 0; tsel < 3; ++tsel)
+#pragma unroll
+                for (int m = 0; m < kX3RecOps; ++m) x3ar[tsel][m] = __builtin_bit_cast(bf16x8, blob[kX3ArOff + ((tsel + 1) * kX3RecOps + m) * 64 + lane]);
+        }
         for (int t = 0; t < T; ++t) {
             if (t == 10) PE_GT(2);
             // phase 1: r.  Units 0..15: + h.U on TX; units 16..19: partial sums, reduced across the lane groups
             f32x4 pr;
+            if (X3R) {
+                auto recur = [&](const bf16x8 (&w)[kX3RecOps], const X3Ops& o, const uint4& b3, f32x4 c) -> f32x4 {
+                    c = mfma_bf16(w[0], __builtin_bit_cast(bf16x8, o.b0), c);
+                    c = mfma_bf16(w[1], __builtin_bit_cast(bf16x8, o.b0), c);
+                    c = mfma_bf16(w[2], __builtin_bit_cast(bf16x8, o.b2), c);
+                    c = mfma_bf16(w[3], __builtin_bit_cast(bf16x8, b3), c);
+                    return c;
+                };
+                const f32x4 hq = {h[0], h[1], h[2], h[3]};
+                const X3Ops oh = x3_split_tile(hq, x3keep, x3id);
+                const uint4 oh4 = x3_split_one(h[4]);
+                const f32x4 arr = recur(x3ar[0], oh, oh4, accX);
+                const f32x4 aq = recur(x3ar[2], oh, oh4, f32x4{0.f, ri, ci, 0.f});
+                f32x4 rhq;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rhq[q] = hard_sigmoid(arr[q]) * h[q];
+                const float rh4 = hard_sigmoid(aq[1]) * h[4];
+                const X3Ops orh = x3_split_tile(rhq, x3keep, x3id);
+                const uint4 orh4 = x3_split_one(rh4);
+                accC = recur(x3ar[1], orh, orh4, accC);
+                const f32x4 aq2 = recur(x3ar[2], orh, orh4, aq);
+                if (t == 10) PE_GT(4);
+                cw_barrier();                                                   // B(t)
+                if (t == 10) PE_GT(5);
+                const int nbx = (t + 1) & 1;
+                const f32x4 zx = *reinterpret_cast<const f32x4*>(L4 + CwBox::SZ4);
+                const float z4x = L1[CwBox::SZ1];
+                const f32x4 nXx = *reinterpret_cast<const f32x4*>(L4 + CwBox::PX + nbx * 256);
+                const f32x4 nCx = *reinterpret_cast<const f32x4*>(L4 + CwBox::PC + nbx * 256);
+                const float nrix = L2[CwBox::PV + nbx * 128], ncix = L2[CwBox::PV + nbx * 128 + 1];
+                f32x4 hnx;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hnx[q] = h[q] = gru_blend(zx[q], h[q], accC[q]);
+                h[4] = gru_blend(z4x, h[4], aq2[2]);
+                *reinterpret_cast<f32x4*>(L4 + CwBox::SH4) = hnx;
+                L1[CwBox::SH1] = h[4];
+                if (lane == 0) *TAG = t + 1;
+                accX = nXx; accC = nCx; ri = nrix; ci = ncix;
+                if (t == 10) PE_GT(6);
+                continue;
+            }
             if (HAND) {
                 // The whole timestep of R as ONE pinned instruction sequence (sched_barrier between the groups).  What the
                 // order encodes (measured with tools/micro/gru_chain.hip, round 4): a dependent eight-pass MFMA can issue

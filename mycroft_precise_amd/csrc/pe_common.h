@@ -152,6 +152,7 @@ struct GruArgs {
     // float32 network on the XDL pipe, operands as three bf16 pieces (gru_x3_device.h; pe_set_gru_tiling(e, 2)):
     // non-null = the launchers take gru_tile_x3 for every input mode
     const void* x3;         // [4 tiles][4][64] + [4 tiles][3][64] uint4 of 8 bf16, then float wd[5][64]
+    const void* x3w;        // the same blob whatever form the launches take (PE_CW_VAR bit 6, the timing experiment of gru_cw_device.h), may be null
     // input: either the feature ring (+ per-stream emitted-frame counters) ...
     const float* ring;
     int ring_bf16;          // rows hold 16 bf16 (32 bytes) instead of 16 floats: bf16-operand kernel only
