@@ -161,6 +161,30 @@ def _cpu_round(cpus, streams_per_core, seconds):
             'value': windows / compute}
 
 
+def _cpu_torch_batched(threads, n_streams, seconds):
+    from oracle.torch_batched import TorchBatchedOracle
+    prev = torch.get_num_threads()
+    torch.set_num_threads(int(threads))
+    try:
+        weights = synth.make_weights(seed=42)
+        base = synth.batch_pcm(64, 8, CHUNK)
+        pcm = torch.from_numpy(np.ascontiguousarray(np.tile(base, (1, n_streams // 64, 1))))
+        oracle = TorchBatchedOracle(weights, n_streams)
+        for u in range(5):
+            oracle.update_raw(pcm[u % 8])
+        n, t0 = 0, time.perf_counter()
+        while True:
+            oracle.update_raw(pcm[n % 8])
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds:
+                break
+    finally:
+        torch.set_num_threads(prev)
+    return {'value': n_streams * n / dt, 'unit': 'windows/s', 'threads': int(threads), 'streams': n_streams, 'compute_s': dt,
+            'sample': 'torch-CPU restatement, %d intra-op threads, %d streams per update, %d updates in %.1f s' % (threads, n_streams, n, dt)}
+
+
 def cpu_baseline(seconds=4.0, streams_per_core=128):
     """Oracle ("port" of the reference's sonopy + Keras arithmetic, vectorised over streams) on the host cores, on a
     bounded sample of the same workload: ONE process per PHYSICAL core, pinned to it (sched_setaffinity; the second
@@ -184,8 +208,18 @@ def cpu_baseline(seconds=4.0, streams_per_core=128):
         os.sched_setaffinity(0, prev)
     r = _cpu_round(cpus, streams_per_core, seconds)
     alone = max(1024 * n_alone / t_alone, streams_per_core * n_a128 / t_a128)
-    return {'value': r['value'], 'unit': 'windows/s', 'cores': cores, 'physical_cores': cores, 'logical_cpus': logical,
-            'pinned': True, 'kind': 'port',
+    # BASELINE.md B2 "numpy / torch-CPU": the same restatement on torch's multi-threaded CPU kernels, ONE process, the GPU's own
+    # batch (4096 streams per update), every physical core as an intra-op thread -- after the forked numpy workers are gone
+    # (forking a process whose thread pool is already running can hang).  Whichever is faster is the baseline's `value`.
+    tb = None
+    try:
+        tb = _cpu_torch_batched(cores, 4096, 2.0)
+    except Exception as ex:                                  # noqa: BLE001  (the baseline must not cost the bench its line)
+        tb = {'error': repr(ex)}
+    best_is_torch = bool(tb and tb.get('value', 0.0) > r['value'])
+    return {'value': tb['value'] if best_is_torch else r['value'], 'unit': 'windows/s', 'cores': cores, 'physical_cores': cores, 'logical_cpus': logical,
+            'pinned': True, 'kind': 'port', 'implementation': 'torch-CPU batched (oracle/torch_batched.py)' if best_is_torch else 'numpy, one pinned process per physical core (oracle/listener.py)',
+            'numpy_multiprocess': {'value': r['value'], 'unit': 'windows/s'}, 'torch_batched': tb,
             'compute_s': r['compute_s'], 'wall_s': r['wall_s'] + t_alone + t_a128,
             'per_core': r['value'] / cores, 'single_core_alone': alone,
             'single_core_alone_1024_streams': 1024 * n_alone / t_alone,

@@ -302,3 +302,20 @@ def test_three_bf16_pieces_carry_a_float32_product(stock_weights):
     d_x3, d_32 = np.abs(p_x3 - p64).max(), np.abs(p32 - p64).max()
     assert d_x3 <= 2 * d_32 + 1e-6, (d_x3, d_32)
     assert np.abs(p_x3 - p32).max() <= 2e-5                                                             # the float32 guard of the GPU tests
+
+
+def test_torch_batched_restatement_equals_the_numpy_oracle():
+    """oracle/torch_batched.py (bench.py's second CPU baseline, BASELINE.md B2 "numpy / torch-CPU") against the numpy oracle it
+    restates: features to float64 round-off, probabilities to float32 summation order -- stock and wide networks."""
+    torch = pytest.importorskip('torch')
+    from oracle.torch_batched import TorchBatchedOracle
+    from mycroft_precise_amd import synth
+    for units in ((20,), (48, 40)):
+        w = synth.make_weights(units=units, seed=3)
+        B, n_up = 24, 40
+        pcm = synth.batch_pcm(B, n_up)
+        a, b = ol.BatchedOracle(w, B), TorchBatchedOracle(w, B)
+        for u in range(n_up):
+            pa, pb = a.update_raw(pcm[u]), b.update_raw(pcm[u])
+            assert np.abs(pa.astype(np.float64) - pb).max() <= 1e-6, (units, u)
+        assert np.abs(a.mfccs - b.mfccs.numpy()).max() <= 1e-9
