@@ -5,6 +5,9 @@
 #include <type_traits>
 #include "mfcc_device.h"
 #include "mfcc_wave_device.h"
+#ifdef PE_TUNING
+#include "mfcc_quad_device.h"       // (round 5 experiment: four frames per wave)
+#endif
 #include "gru_device.h"
 #include "gru_cw_device.h"
 #ifdef PE_TUNING      // measured and rejected: tuning builds only (tools/build_variants.sh)
@@ -77,6 +80,54 @@ template <class R, class SH, bool SINGLE = false>
 __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(SH::WPE))) PE_NO_PK_F32 void mfcc_kernel_nopk(const MfccStreamArgs<R> a, const WaveTables<R> t, const int n_frame_blocks) {
     mfcc_kernel_body<R, SH, SINGLE>(a, t, n_frame_blocks);
 }
+
+#ifdef PE_TUNING
+// ---- MFCC, four frames per wave (mfcc_quad_device.h): the frame role of one update with dword sample pairs ----------------------------
+// ONE workgroup per CU, as many waves as the register file and the LDS take (float64: 12 waves of <= 168 registers and 11 KB of
+// scratch; float32: 16 waves of <= 128 registers); LDS: [scratch of wave 0 .. W-1][table image of the one-frame kernel from its log
+// table on][quad twiddles].  The frame waves keep the books of their own streams between passes (mfcc_quad_tasks): as trailing
+// workgroups of this launch the bookkeeping role would reserve its 60-150 KB per workgroup and run behind the frames, not beside.
+#ifndef PE_QUAD_WAVES
+template <class R> constexpr int kQuadWaves = sizeof(R) == 8 ? 12 : 16;
+#else
+template <class R> constexpr int kQuadWaves = PE_QUAD_WAVES;
+#endif
+template <class R>
+__device__ __forceinline__ void mfcc_quad_body(const MfccStreamArgs<R>& a, const WaveTables<R>& t, const pe_wave::cx<R>* qtab, const int n_frame_blocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int W = kQuadWaves<R>;
+    PE_T(0);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int skip = t.L.logtab;
+    const int n16 = (t.L.total - skip) >> 4;
+    unsigned char* const image = smem + W * kQuadScratchBytes<R>;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(t.blob) + skip);
+        uint4* dst = reinterpret_cast<uint4*>(image);
+        for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+        const uint4* qs = reinterpret_cast<const uint4*>(qtab);
+        uint4* qd = reinterpret_cast<uint4*>(image + (size_t)n16 * 16);
+        constexpr int nq = kQuadTwElems * 2 * (int)sizeof(R) / 16;
+        for (int i = threadIdx.x; i < nq; i += blockDim.x) qd[i] = qs[i];
+    }
+    __syncthreads();
+    const pe_wave::Tab<R> tab = pe_wave::bind<R>(image, t.L, skip);
+    const pe_wave::cx<R>* qtw = reinterpret_cast<const pe_wave::cx<R>*>(image + (size_t)n16 * 16);
+    PE_T(1);
+    mfcc_quad_tasks<R, ShapeStock>(a, tab, qtw, qtw + 256, smem + (size_t)wave * kQuadScratchBytes<R>, (int)blockIdx.x * W, n_frame_blocks * W);
+    PE_T(15);
+}
+template <class R>
+__global__ __launch_bounds__(64 * kQuadWaves<R>) void mfcc_quad_kernel(const MfccStreamArgs<R> a, const WaveTables<R> t, const pe_wave::cx<R>* qtab, const int n_frame_blocks) {
+    mfcc_quad_body<R>(a, t, qtab, n_frame_blocks);
+}
+template <class R>
+__global__ __launch_bounds__(64 * kQuadWaves<R>) PE_NO_PK_F32 void mfcc_quad_kernel_nopk(const MfccStreamArgs<R> a, const WaveTables<R> t, const pe_wave::cx<R>* qtab, const int n_frame_blocks) {
+    mfcc_quad_body<R>(a, t, qtab, n_frame_blocks);
+}
+template <class R>
+static size_t quad_lds(const WaveTables<R>& t) { return (size_t)kQuadWaves<R> * kQuadScratchBytes<R> + (size_t)(t.L.total - t.L.logtab) + (size_t)kQuadTwElems * 2 * sizeof(R); }
+#endif  // PE_TUNING
 
 // network for a whole batch of updates: workgroup (one wave) b serves update b / n_tiles, tile b % n_tiles
 template <int R, bool PROJ>
@@ -542,6 +593,31 @@ static hipError_t launch_mfcc(const MfccStreamArgs<R>& a, const WaveTables<R>& t
     }
     return hipGetLastError();
 }
+// four frames per wave: the frame role of ONE update of a stock-shape engine whose geometry allows dword sample pairs
+#ifdef PE_TUNING
+template <class R>
+static hipError_t launch_mfcc_quad(const MfccStreamArgs<R>& a, const WaveTables<R>& t, const void* qtab, int n_cus, hipStream_t s) {
+    constexpr int W = kQuadWaves<R>;
+    const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
+    if (!blob_matches_shape(t) || t.L.mel_pad != ShapeStock::MEL) return hipErrorInvalidValue;
+    static const int per_cu = env_int("PE_QUAD_WG_PER_CU", 1);
+    const long long need = ((long long)a.geo.n_streams + 4 * W - 1) / (4 * W);        // at least four streams per wave
+    const long long cap = (long long)n_cus * per_cu;
+    const int fb = (int)(need < cap ? (need < 1 ? 1 : need) : cap);
+    const pe_wave::cx<R>* q = reinterpret_cast<const pe_wave::cx<R>*>(qtab);
+    static bool once = false;
+    if (!once) {
+        once = true;
+        if constexpr (std::is_same<R, float>::value) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfcc_quad_kernel_nopk<R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfcc_quad_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if constexpr (std::is_same<R, float>::value) hipLaunchKernelGGL((mfcc_quad_kernel_nopk<R>), dim3(fb), dim3(64 * W), quad_lds(t), s, a, t, q, fb);
+    else hipLaunchKernelGGL((mfcc_quad_kernel<R>), dim3(fb), dim3(64 * W), quad_lds(t), s, a, t, q, fb);
+    return hipGetLastError();
+}
+hipError_t launch_mfcc_quad_f64(const MfccStreamArgs<double>& a, const WaveTables<double>& t, const void* qtab, int n_cus, hipStream_t s) { return launch_mfcc_quad<double>(a, t, qtab, n_cus, s); }
+hipError_t launch_mfcc_quad_f32(const MfccStreamArgs<float>& a, const WaveTables<float>& t, const void* qtab, int n_cus, hipStream_t s) { return launch_mfcc_quad<float>(a, t, qtab, n_cus, s); }
+#endif
 hipError_t launch_mfcc_f64(const MfccStreamArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s) { return launch_mfcc<double>(a, t, n_cus, s); }
 hipError_t launch_mfcc_f32(const MfccStreamArgs<float>& a, const WaveTables<float>& t, int n_cus, hipStream_t s) { return launch_mfcc<float>(a, t, n_cus, s); }
 

@@ -249,6 +249,10 @@ hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const WaveTables<do
 hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const WaveTables<float>& t, const GruArgs& g, int n_cus, hipStream_t s);
 // tuning aid (-DPE_TUNING builds only; 0 in the product): an integer knob read from the environment
 int tuning_env_int(const char* name, int dflt);
+#ifdef PE_TUNING
+hipError_t launch_mfcc_quad_f64(const MfccStreamArgs<double>& a, const WaveTables<double>& t, const void* qtab, int n_cus, hipStream_t s);
+hipError_t launch_mfcc_quad_f32(const MfccStreamArgs<float>& a, const WaveTables<float>& t, const void* qtab, int n_cus, hipStream_t s);
+#endif
 hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s);
 hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, const WaveTables<float>& t, int n_cus, hipStream_t s);
 hipError_t launch_gru_small(const GruArgs& a, int input_mode, hipStream_t s);   // units <= 32; 0 feats, 1 ring, 2 rows
