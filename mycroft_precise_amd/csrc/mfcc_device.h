@@ -126,6 +126,37 @@ __device__ __forceinline__ void mfcc_book_tile(const MfccStreamArgs<R>& a, const
             else if (n < qn) carw[n] = (int16_t)(left[c] & 0xffff);
         }
     };
+    // Single updates whose leftovers lie inside the chunk (every update of 1024-sample chunks: a completed frame puts the next
+    // one's start, >= hop samples on, past anything the carry held): eight samples per load.  Lane r of the group moves samples
+    // 8 r + 128 c .. + 8 with one 16-byte load (source 4-byte aligned: q and hop are even) and one aligned 16-byte store, and
+    // the group's lanes 0 .. 2 the up to three sample pairs behind the last full eight: 5 loads where the dword form below
+    // issues 16, and a quarter of its address arithmetic (round 5: the role was 55 of ~500 vector instructions per stream and
+    // update of the launch, profiles/round5/r5h_mfcc_quad.log).
+    const int vb1 = nnew * hop;
+    if (U == 1 && C >= 8 && __all(!fast ? 0 : (qn <= 0 || vb1 >= q))) {
+        struct __attribute__((packed, aligned(4))) Pcm8 { int d[4]; };
+        const int16_t* src = base + (vb1 - q);                   // sample 0 of the leftover
+        const int full8 = qn > 0 ? (qn & ~7) : 0;                // samples covered by whole eights
+        const int rest = qn > 0 ? ((qn & 7) >> 1) : 0;           // sample pairs behind them (0 .. 3)
+        const int nhalf = __any(qn > 256) ? 2 : 1;
+        for (int half = 0; half < nhalf; ++half) {
+            Pcm8 v[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int n = 128 * (2 * half + c) + 8 * r;
+                v[c] = *reinterpret_cast<const Pcm8*>(n < full8 ? src + n : base);      // (unconditional, from a clamped position)
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int n = 128 * (2 * half + c) + 8 * r;
+                if (n < full8) *reinterpret_cast<int4*>(carw + n) = int4{v[c].d[0], v[c].d[1], v[c].d[2], v[c].d[3]};
+            }
+        }
+        if (__any(rest > 0)) {
+            const int val = *reinterpret_cast<const int*>(r < rest ? src + full8 + 2 * r : base);
+            if (r < rest) *reinterpret_cast<int*>(carw + full8 + 2 * r) = val;
+        }
+    } else
     // the leftover of a stream is up to 511 samples = 16 dwords per lane of its group, but in most updates it is shorter than
     // 256 samples or empty (q < 0: the next frame starts inside the next chunk): the two halves are wave-uniform branches
     if (__any(qn > 0)) {
