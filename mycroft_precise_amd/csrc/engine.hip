@@ -769,7 +769,7 @@ int launch_mfcc(pe_engine* e, const int16_t* pcm_dev, int chunk, hipStream_t s) 
         if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_general_stream_f64(general_args<double>(e, pcm_dev, chunk), s));
         else PE_HIP(e, launch_general_stream_f32(general_args<float>(e, pcm_dev, chunk), s));
 #ifdef PE_TUNING
-    } else if (e->quad && e->table_layout.mel_pad == 10 && e->prm.n_filt <= 31 && !e->proj_on && ((chunk | e->prm.hop_samples | frame_len_of(e->prm)) & 1) == 0 &&
+    } else if (e->quad && e->table_layout.mel_pad == 10 && e->prm.n_filt <= 31 && !e->proj_on && chunk >= frame_len_of(e->prm) && ((chunk | e->prm.hop_samples | frame_len_of(e->prm)) & 1) == 0 &&
                (reinterpret_cast<uintptr_t>(pcm_dev) & 3u) == 0) {
         if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_mfcc_quad_f64(mfcc_args<double>(e, pcm_dev, chunk), tables<double>(e), e->quad_tab, e->n_cus, s));
         else PE_HIP(e, launch_mfcc_quad_f32(mfcc_args<float>(e, pcm_dev, chunk), tables<float>(e), e->quad_tab, e->n_cus, s));

@@ -300,12 +300,16 @@ __device__ __forceinline__ void mfcc_quad_tasks(const MfccStreamArgs<R>& a, cons
     int base = s_begin - 64, kb = 0, vq = 0, vkc = 0, nnew = 0, v_first = 0;
     bool in_batch = false;
     unsigned long long due = 0ull;
+    // (fetch and copy_issue issue the SAME number of loads on every call, from clamped positions once their generator has run dry:
+    //  the compiler's s_waitcnt counts are the minimum over all paths to a use, and one path that skips the loads -- "no next
+    //  pass" -- makes every pass wait for the prefetch it has just issued)
     auto fetch = [&](int (&raw)[16], long long& cell) -> bool {
+        bool any = true;
         while (!due) {
             if (in_batch) ++kb;
             else {
                 base += 64;
-                if (base >= s_end) return false;
+                if (base >= s_end) { base = s_end; any = false; break; }
                 const int s = base + lane;
                 const int sc = s < s_end ? s : 0;
                 vq = a.st_q[sc];
@@ -313,6 +317,18 @@ __device__ __forceinline__ void mfcc_quad_tasks(const MfccStreamArgs<R>& a, cons
                 const int avail = vq + C;
                 nnew = (s < s_end && avail >= flen) ? 1 + (int)a.div_hop.div((uint32_t)(avail - flen)) : 0;
                 v_first = nnew > slots ? nnew - slots : 0;
+                if (s < s_end) {                    // the counters of the batch, one stream per lane, as mfcc_book_tile advances them for one update
+                    uint32_t ke = a.st_ke[s];
+                    const int qu = avail - nnew * hop;
+                    const uint32_t kcu = (uint32_t)vkc + (uint32_t)nnew;
+                    const int m = qu + hop * (int)(kcu - ke);
+                    if (m >= geo.window) ke += 1u + a.div_hop.div((uint32_t)(m - geo.window));
+                    if (a.ke_hist) a.ke_hist[s] = ke;
+                    a.st_q_next[s] = qu;
+                    a.st_kc_next[s] = kcu;
+                    a.st_ke_next[s] = ke;
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0) HERE, on the rare path: otherwise every call waits for "maybe just loaded" counters
                 kb = 0;
                 in_batch = true;
             }
@@ -326,11 +342,11 @@ __device__ __forceinline__ void mfcc_quad_tasks(const MfccStreamArgs<R>& a, cons
             if (due) due &= due - 1;
         }
         const int mine = G == 0 ? pick[0] : G == 1 ? pick[1] : G == 2 ? pick[2] : pick[3];
-        const bool live = mine >= 0;
+        const bool live = any && mine >= 0;
         const int src = live ? mine : 0;
         const int q = __builtin_amdgcn_ds_bpermute(src * 4, vq);
         const uint32_t kc = (uint32_t)__builtin_amdgcn_ds_bpermute(src * 4, vkc);
-        const int st = base + src;
+        const int st = live ? base + src : 0;
         // sample m of the frame (0 <= m < flen): m < qa from the carry (its sample vb + m), else from the chunk (off0 + m)
         const int vb = kb * hop, qa = q - vb, off0 = vb - q;
         const int16_t* car = a.carry + (size_t)st * kCarryCap + vb;
@@ -339,13 +355,13 @@ __device__ __forceinline__ void mfcc_quad_tasks(const MfccStreamArgs<R>& a, cons
         for (int n1 = 0; n1 < 16; ++n1) {
             const int m = 2 * (16 * n1 + j);
             const int mm = m < flen ? m : 0;
-            const int16_t* p = (mm < qa ? car : row) + mm;
+            const int16_t* p = (live ? (mm < qa ? car : row) : a.pcm) + mm;
             raw[n1] = *reinterpret_cast<const int*>(p);           // (unconditional, from a clamped position, masked when consumed: the load stays in flight)
         }
         const int tile = st >> 4, js = st & 15;
         const int slot = (int)((kc + (uint32_t)kb) & (uint32_t)(slots - 1));
         cell = live ? (long long)(((size_t)tile * slots + slot) * kTileStreams + js) : -1ll;
-        return true;
+        return any;
     };
     auto work = [&](const int (&raw)[16], const long long cell) {
         PE_T(2);
@@ -357,95 +373,89 @@ __device__ __forceinline__ void mfcc_quad_tasks(const MfccStreamArgs<R>& a, cons
         }
         PE_T(11);
     };
-    // bookkeeping of the wave's own streams, four per unit (lane group = stream, its lane r moves sample pairs 16 c + r): leftover
-    // samples -> the other carry buffer, counters -> the other counter set, exactly as mfcc_book_tile does for one update with
-    // dword pairs.  A unit's loads are issued BEFORE a pass and stored AFTER it: workgroups of their own for this role would each
-    // reserve this kernel's LDS and run one per CU behind the frames (a separate launch: 15.8 us at 65536 streams,
-    // profiles/round5/r5h_mfcc_quad.log).
-    int bbase = s_begin - 64, bround = 16, bhalf = 0, bq = 0, bkc = 0, bke = 0;      // (batch of 64 streams, round of four, half of the leftover)
-    int b_left[8], b_qn = 0, b_nnew = 0;
-    long long b_s = -1;
-    bool b_second = false;
-    auto book_issue = [&]() -> bool {
-        if (!(bhalf == 0 && b_second)) {            // next round (a second half follows only when some leftover of the round exceeds 256 samples)
-            bhalf = 0;
-            if (++bround >= 16 || bbase + 4 * bround >= s_end) {
-                bbase += 64;
-                if (bbase >= s_end) return false;
-                const int s = bbase + lane;
-                const int sc = s < s_end ? s : 0;
-                bq = a.st_q[sc];
-                bkc = (int)a.st_kc[sc];
-                bke = (int)a.st_ke[sc];
-                bround = 0;
+    // leftover samples of the wave's own streams -> the other carry buffer, four streams per round (lane group = stream), eight
+    // samples per lane and load as in mfcc_book_tile's 16-byte form: the launch requires chunk >= frame length, which puts every
+    // leftover inside the chunk (nnew hop > q + chunk - frame length >= q; no frame completed: q < frame length - chunk <= 0).
+    // A round's loads are issued BEFORE a pass and stored AFTER it.  Bookkeeping workgroups of their own would each reserve this
+    // kernel's LDS and run behind the frames instead of beside them (profiles/round5/r5h_mfcc_quad.log).
+    struct __attribute__((packed, aligned(4))) Pcm8 { int d[4]; };
+    int cbase = s_begin - 64, cround = 16, cq = 0;
+    Pcm8 c_v[4];
+    int c_tail = 0, c_full8 = 0, c_rest = 0;
+    long long c_s = -1;
+    bool c_high = false;
+    auto copy_issue = [&]() -> bool {
+#if defined(PE_QUAD_ABL) && (PE_QUAD_ABL & 1)      // (timing only: no leftover role at all)
+        return false;
+#endif
+        bool any = true;
+        if (++cround >= 16 || cbase + 4 * cround >= s_end) {
+            cbase += 64;
+            if (cbase >= s_end) { cbase = s_end; any = false; }
+            else {
+                const int s = cbase + lane;
+                cq = a.st_q[s < s_end ? s : 0];
+                __builtin_amdgcn_s_waitcnt(0x0F70);     // (as in fetch)
             }
-        } else bhalf = 1;
-        const int src = 4 * bround + G;
-        const int st = bbase + src;
-        const bool valid = st < s_end;
-        const int q = __builtin_amdgcn_ds_bpermute(src * 4, bq);
+            cround = 0;
+        }
+        const int src = 4 * cround + G;
+        const int st = cbase + src;
+        const bool valid = any && st < s_end;
+        const int q = __builtin_amdgcn_ds_bpermute(src * 4, cq);
         const int avail = q + C;
         const int nnew_s = avail >= flen ? 1 + (int)a.div_hop.div((uint32_t)(avail - flen)) : 0;
         const int qn = valid ? avail - nnew_s * hop : 0;
-        b_s = valid ? (long long)st : -1ll;
-        b_qn = qn;
-        b_nnew = nnew_s;
-        if (bhalf == 0) b_second = __any(qn > 256);
-        else b_second = false;
-        const int vb = qn > 0 ? nnew_s * hop : q;          // (streams with nothing to move read their chunk's first samples and store nothing)
-        const int16_t* car = a.carry + (size_t)(valid ? st : 0) * kCarryCap;
-        const int16_t* row = a.pcm + (size_t)(valid ? st : 0) * C - q;
+        c_s = valid && qn > 0 ? (long long)st : -1ll;
+        c_full8 = qn > 0 ? (qn & ~7) : 0;
+        c_rest = qn > 0 ? ((qn & 7) >> 1) : 0;
+        const int16_t* row0 = a.pcm + (size_t)(valid ? st : 0) * C;
+        const int16_t* srcp = row0 + (nnew_s * hop - q);               // sample 0 of the leftover (dereferenced only where qn > 0)
+        c_high = __any(c_full8 > 256);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int n = 32 * (8 * bhalf + c) + 2 * j;
-            const int v = vb + (n < qn ? n : 0);
-            b_left[c] = *reinterpret_cast<const int*>((v < q ? car : row) + v);
+        for (int c = 0; c < 4; ++c) {
+            const int n = 128 * c + 8 * j;
+            c_v[c] = *reinterpret_cast<const Pcm8*>(n < c_full8 ? srcp + n : row0);          // (unconditional, from a clamped position)
         }
-        return true;
+        c_tail = *reinterpret_cast<const int*>(j < c_rest ? srcp + c_full8 + 2 * j : row0);
+        return any;
     };
-    auto book_finish = [&]() {
-        if (b_s >= 0) {
-            int16_t* const carw = a.carry_next + (size_t)b_s * kCarryCap;
+    auto copy_finish = [&]() {
+#if defined(PE_QUAD_ABL) && (PE_QUAD_ABL & 2)      // (timing only: no stores of the leftover)
+        if (c_tail == 0x7fffffff) a.ring[0] = 0.0f;
+        return;
+#endif
+        if (c_s < 0) return;
+        int16_t* const carw = a.carry_next + (size_t)c_s * kCarryCap;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int n = 32 * (8 * bhalf + c) + 2 * j;
-                if (n + 1 < b_qn) *reinterpret_cast<int*>(carw + n) = b_left[c];
-                else if (n < b_qn) carw[n] = (int16_t)(b_left[c] & 0xffff);
+        for (int c = 0; c < 2; ++c) {
+            const int n = 128 * c + 8 * j;
+            if (n < c_full8) *reinterpret_cast<int4*>(carw + n) = int4{c_v[c].d[0], c_v[c].d[1], c_v[c].d[2], c_v[c].d[3]};
+        }
+        if (c_high) {
+#pragma unroll
+            for (int c = 2; c < 4; ++c) {
+                const int n = 128 * c + 8 * j;
+                if (n < c_full8) *reinterpret_cast<int4*>(carw + n) = int4{c_v[c].d[0], c_v[c].d[1], c_v[c].d[2], c_v[c].d[3]};
             }
         }
-        const int src = 4 * bround + G;
-        const uint32_t kc = (uint32_t)__builtin_amdgcn_ds_bpermute(src * 4, bkc);
-        uint32_t ke = (uint32_t)__builtin_amdgcn_ds_bpermute(src * 4, bke);
-        if (b_s >= 0 && bhalf == 0 && j == 0) {
-            const uint32_t kcu = kc + (uint32_t)b_nnew;
-            const int m = b_qn + hop * (int)(kcu - ke);
-            if (m >= geo.window) ke += 1u + a.div_hop.div((uint32_t)(m - geo.window));
-            if (a.ke_hist) a.ke_hist[b_s] = ke;
-            a.st_q_next[b_s] = b_qn;
-            a.st_kc_next[b_s] = kcu;
-            a.st_ke_next[b_s] = ke;
-        }
+        if (j < c_rest) *reinterpret_cast<int*>(carw + c_full8 + 2 * j) = c_tail;
     };
-    int cur[16], nxt[16];
-    long long ccell = -1, ncell = -1;
-    bool have = fetch(cur, ccell);
-    bool bk = book_issue();
+    // two sample buffers in turn (no register copies), every generator call on every path
+    int rawA[16], rawB[16];
+    long long cellA = -1, cellB = -1;
+    bool have = fetch(rawA, cellA);
+    bool bk = copy_issue();
     while (have || bk) {
-        bool more = false;
-        if (have) {
-            more = fetch(nxt, ncell);
-            work(cur, ccell);
-        }
-        if (bk) {
-            book_finish();
-            bk = book_issue();
-        }
-        if (have) {
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) cur[n1] = nxt[n1];
-            ccell = ncell;
-            have = more;
-        }
+        const bool more = fetch(rawB, cellB);
+        if (have) work(rawA, cellA);
+        copy_finish();
+        const bool bk2 = copy_issue();
+        have = fetch(rawA, cellA);
+        if (more) work(rawB, cellB);
+        copy_finish();
+        bk = copy_issue();
+        (void)bk2;
     }
 }
 

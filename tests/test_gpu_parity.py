@@ -409,6 +409,26 @@ def test_other_chunk_sizes_including_odd_sample_counts(stock_weights, chunk):
         assert np.abs(raw - want).max() <= GUARD_RAW, (chunk, u)
 
 
+@pytest.mark.parametrize('chunk', [1090, 1026, 802, 518, 8, 6])
+def test_leftover_moves_of_every_shape(stock_weights, chunk):
+    """The bookkeeping role moves a single update's leftover samples 16 bytes per lane when they lie inside the chunk (mfcc_device.h):
+    even chunk lengths that are no multiple of eight leave 1-3 sample pairs behind the last full eight, short chunks leave fewer than
+    eight samples or start in the carry (the dword form), 7 streams leave a lane group of the last wave without a stream.  Features
+    and probabilities against the oracle, update by update (network_runner.py:125-146)."""
+    from mycroft_precise_amd.network_runner import BatchedListener
+    n, total = 7, 24000 if chunk >= 500 else 2800
+    n_up = total // chunk
+    pcm = _stream_batch(['tone_noise', 'quiet', 'square', 'tone_noise', 'zeros', 'tone_noise', 'quiet'], n_up, chunk)
+    hip = BatchedListener(stock_weights, n)
+    ref = ol.BatchedOracle(stock_weights, n)
+    for u in range(n_up):
+        raw = hip.update_raw(pcm[u])
+        want = ref.update_raw(pcm[u])
+        assert np.abs(raw - want).max() <= GUARD_RAW, (chunk, u)
+        if u % 7 == 0 or u == n_up - 1:
+            assert np.abs(hip.engine.get_vectors().astype(np.float64) - ref.mfccs).max() <= 2e-6, (chunk, u)
+
+
 def test_runner_predict_matches_oracle_ragged_and_empty(stock_weights):
     from mycroft_precise_amd.network_runner import HipRunner
     runner = HipRunner(weights=stock_weights)
