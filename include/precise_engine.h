@@ -54,7 +54,7 @@ typedef struct pe_params {
                                 launch; EVERY OTHER shape in the ranges above runs on the general front end (same
                                 results contract, two launches per update, pe_update_many = the same updates one after
                                 the other).  17..32 coefficients feed the float32 network of <= 32 units without
-                                use_delta only; the bf16 configuration exists for the stock shape only.  An n_fft that is
+                                use_delta only; bf16 operands / rows take <= 16 coefficients on either front end.  An n_fft that is
                                 not a power of two >= 64 (16 and 32 included) runs as Bluestein's chirp-z transform over
                                 the next power of two >= max(128, 2 n_fft - 1) (one wave's LDS holds it up to n_fft =
                                 1024).  Outside the ranges (n_fft > 2048, not a power of two and > 1024, < 16, ...):

@@ -751,6 +751,7 @@ GeneralStreamArgs<R> general_args(const pe_engine* e, const int16_t* pcm_dev, in
     a.st_q = e->st_q[c]; a.st_kc = e->st_kc[c]; a.st_ke = e->st_ke[c];
     a.st_q_next = e->st_q[n]; a.st_kc_next = e->st_kc[n]; a.st_ke_next = e->st_ke[n];
     a.ring = e->ring; a.row_floats = e->row_floats;
+    a.ring_bf16 = e->prm.ring_precision == 1;
     return a;
 }
 
@@ -1046,8 +1047,8 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
     }
     if (p->n_mfcc > kRowFloats && (wide || p->use_delta || p->gru_precision != 0))
         return fail(nullptr, PE_ERR_UNSUPPORTED, "more than 16 coefficients per frame feed the float32 network of <= 32 units without delta features only");
-    if (general && (p->gru_precision != 0 || p->ring_precision != 0))
-        return fail(nullptr, PE_ERR_UNSUPPORTED, "the bf16 configuration exists for the stock front-end shape (n_fft = 512, <= 64 filters, <= 16 coefficients)");
+    // (bf16 operands / bf16 rows behind the general front end: the same network kernels, fed from rows of <= 16 coefficients --
+    //  more than 16 were refused above)
 
     pe_engine* e = new pe_engine();
     e->prm = *p;
@@ -1058,10 +1059,7 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         pe_wave::Layout lprobe{};
         const std::string perr = p->mfcc_precision == 0 ? pe_wave::build<double>(mel_filters, p->n_filt, p->n_mfcc, probe, lprobe)
                                                         : pe_wave::build<float>(mel_filters, p->n_filt, p->n_mfcc, probe, lprobe);
-        if (!perr.empty()) {
-            if (p->gru_precision != 0 || p->ring_precision != 0) { delete e; return fail(nullptr, PE_ERR_UNSUPPORTED, "%s", perr.c_str()); }
-            general = true;
-        }
+        if (!perr.empty()) general = true;
     }
     e->general = general;
     e->row_floats = p->n_mfcc > kRowFloats ? 2 * kRowFloats : kRowFloats;

@@ -393,8 +393,9 @@ struct GeneralStreamArgs {
     int carry_cap;
     const int32_t* st_q; const uint32_t* st_kc; const uint32_t* st_ke;
     int32_t* st_q_next; uint32_t* st_kc_next; uint32_t* st_ke_next;
-    float* ring;                // [tiles][slots][16 streams][row_floats]
+    float* ring;                // [tiles][slots][16 streams][row_floats] -- or, ring_bf16, 16 bf16 per row (row_floats == 16 only)
     int row_floats;
+    int ring_bf16;
 };
 
 // Two waves per stream: wave `par` takes the due frames kb = first + par, first + par + 2, ... (1024-sample chunks complete one
@@ -441,8 +442,11 @@ __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R*
             }, coeff);
         }
         const int slot = (int)((kc + (uint32_t)kb) & (uint32_t)(slots - 1));
-        float* out = a.ring + (((size_t)tile * slots + slot) * kTileStreams + j) * a.row_floats;
-        if (lane < a.row_floats) out[lane] = lane < geo.n_mfcc ? (float)coeff[0] : 0.0f;
+        const size_t cell = ((size_t)tile * slots + slot) * kTileStreams + j;
+        const float xf = lane < geo.n_mfcc ? (float)coeff[0] : 0.0f;
+        if (a.ring_bf16) {          // (rounded where it is stored, to nearest even: what the bf16 network does to a float32 row at the load)
+            if (lane < kRowFloats) reinterpret_cast<__bf16*>(a.ring)[cell * kRowFloats + lane] = (__bf16)xf;
+        } else if (lane < a.row_floats) a.ring[cell * a.row_floats + lane] = xf;
     }
     if (par != 0) return;
     // leftover samples, counters (the arithmetic of mfcc_book_tile)

@@ -614,6 +614,45 @@ def test_general_listener_params_streaming(kw, chunk):
     eng.close(); many.close(); one.close()
 
 
+@pytest.mark.parametrize('kw', [GENERAL_PARAMS[1], GENERAL_PARAMS[4], GENERAL_PARAMS[5], GENERAL_PARAMS[6]],
+                         ids=lambda kw: 'fft%d_filt%d_mfcc%d' % (kw['n_fft'], kw['n_filt'], kw['n_mfcc']))
+def test_general_front_end_feeds_the_bf16_network(kw):
+    """BASELINE configs[4]'s arithmetic (bf16 operands, optionally bf16 feature rows) behind the GENERAL front end (round 5: it was
+    refused): the same network kernels read the general kernel's rows of <= 16 coefficients.  Probabilities within the bf16
+    tolerance of the float32 oracle, update by update; bf16 rows == float32 rows rounded at the load, bit for bit; the features
+    themselves stay at the front end's own bar; pe_update_many == the updates one after the other."""
+    import warnings
+    from mycroft_precise_amd._lib import HipEngine
+    opr = ol.Params(**kw)
+    hpr = P.pr.copy()
+    hpr.__dict__.update(kw)
+    w = synth.make_weights(n_in=kw['n_mfcc'], units=(20,), seed=7)
+    n, n_up, chunk = 21, 48, 1024
+    pcm = _stream_batch(['tone_noise'] * (n - 3) + ['zeros', 'square', 'quiet'], n_up, chunk)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        a = HipEngine(hpr, w, n_streams=n, gru_precision='bf16')
+        b = HipEngine(hpr, w, n_streams=n, gru_precision='bf16', ring_precision='bf16')
+        many = HipEngine(hpr, w, n_streams=n, gru_precision='bf16', ring_precision='bf16')
+    refs = [ol.OracleListener(w, opr) for _ in range(n)]
+    many.reserve_updates(4, chunk)
+    worst = 0.0
+    for u in range(n_up):
+        ra, rb = a.update(pcm[u]), b.update(pcm[u])
+        assert np.array_equal(ra, rb), u                   # the row format does not change a bit of the output
+        want = np.array([r.update_raw(pcm[u, j].tobytes()) for j, r in enumerate(refs)])
+        worst = max(worst, float(np.abs(ra - want).max()))
+        if u % 4 == 3:
+            assert np.array_equal(many.update_many(pcm[u - 3:u + 1])[-1], rb), u
+    assert worst <= 1e-2, worst                            # BASELINE.json: bf16 tolerance
+    want_feats = np.stack([r.mfccs for r in refs])
+    assert np.abs(a.get_vectors() - want_feats).max() <= TOL_FEAT32
+    got_b = b.get_vectors().astype(np.float32)
+    assert np.abs(got_b - want_feats).max() <= np.abs(want_feats).max() * 2.0 ** -8          # bf16 rows: 8 bits of mantissa
+    assert np.abs(np.asarray(a.predict(want_feats)).reshape(-1) - keras_gru.predict(want_feats, w)[:, 0]).max() <= 1e-2
+    a.close(); b.close(); many.close()
+
+
 def test_device_threshold_decoder_and_trigger(stock_weights):
     """ThresholdDecoder.decode and TriggerDetector.update for every stream on the device vs the
     reference-pinned fixtures / host classes (decode is a step function: one LUT bin of tolerance;
