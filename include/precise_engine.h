@@ -52,8 +52,8 @@ typedef struct pe_params {
                                 Front-end kernels: the stock shape (n_fft = 512, <= 64 filters whose runs fit the 64
                                 lanes of a wave, <= 16 coefficients) runs on the one-frame-per-wave kernel and the fused
                                 launch; EVERY OTHER shape in the ranges above runs on the general front end (same
-                                results contract, two launches per update, pe_update_many = the same updates one after
-                                the other).  17..32 coefficients feed the float32 network of <= 32 units without
+                                results contract, two launches per update and per pe_update_many call -- one network
+                                launch per update of the call for rows of 17..32 coefficients).  17..32 coefficients feed the float32 network of <= 32 units without
                                 use_delta only; bf16 operands / rows take <= 16 coefficients on either front end.  An n_fft that is
                                 not a power of two >= 64 (16 and 32 included) runs as Bluestein's chirp-z transform over
                                 the next power of two >= max(128, 2 n_fft - 1) (one wave's LDS holds it up to n_fft =
@@ -151,8 +151,8 @@ int pe_wait(pe_engine* e);
  * replay, latency-tolerant servers) this fills the machine where a single update of a few thousand
  * streams cannot.  pe_reserve_updates sizes the feature ring, the second leftover buffer and the
  * per-update counters for it (and restarts all streams); n_updates * chunk_samples < 2^30.
- * Engines on the general front end (see pe_params) run the same n updates one after the other inside the call (two launches
- * each, same bits).  The enlarged ring stays: later single pe_update calls on a reserved engine are unchanged in their
+ * Engines on the general front end (see pe_params) take one front-end launch per call as well, then the batched network
+ * launch (rows of 17..32 coefficients: one network launch per update of the call); same bits.  The enlarged ring stays: later single pe_update calls on a reserved engine are unchanged in their
  * results but, up to 8192 streams, use the one-wave network shape (the critical-wave shape stages exactly 32 ring slots in
  * LDS) -- reserve only on engines that use pe_update_many. */
 int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samples);

@@ -752,6 +752,7 @@ GeneralStreamArgs<R> general_args(const pe_engine* e, const int16_t* pcm_dev, in
     a.st_q_next = e->st_q[n]; a.st_kc_next = e->st_kc[n]; a.st_ke_next = e->st_ke[n];
     a.ring = e->ring; a.row_floats = e->row_floats;
     a.ring_bf16 = e->prm.ring_precision == 1;
+    a.n_updates = 1; a.div_chunk = FastDiv::make((uint32_t)chunk); a.ke_hist = nullptr; a.n_padded = e->n_padded;
     return a;
 }
 
@@ -1581,11 +1582,34 @@ int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, i
     if ((long long)n_updates * chunk >= (1ll << 30)) return fail(e, PE_ERR_INVALID, "n_updates * chunk_samples must stay below 2^30");
     if (e->prm.n_features + pending + frames > e->ring_slots) return fail(e, PE_ERR_INVALID, "reserved ring too small for %d updates of %d samples", n_updates, chunk);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (e->general) {           // the general front end has no multi-update launch: the same updates, one after the other
-        for (int u = 0; u < n_updates; ++u) {
-            int urc = do_update(e, pcm_dev + (size_t)u * e->n_streams * chunk, chunk, raw_out_dev + (size_t)u * e->n_streams, nullptr, s);
-            if (urc) return urc;
+    if (e->general) {
+        // the general front end: every frame the call completes in ONE launch (mfcc_general_device.h: general_stream with n_updates),
+        // then the batched network launch over 16-float rows, or one network launch per update over 32-float rows
+        if (e->prm.mfcc_precision == 0) {
+            GeneralStreamArgs<double> a = general_args<double>(e, pcm_dev, chunk);
+            a.n_updates = n_updates; a.ke_hist = e->ke_hist;
+            PE_HIP(e, launch_general_stream_f64(a, s));
+        } else {
+            GeneralStreamArgs<float> a = general_args<float>(e, pcm_dev, chunk);
+            a.n_updates = n_updates; a.ke_hist = e->ke_hist;
+            PE_HIP(e, launch_general_stream_f32(a, s));
         }
+        flip_state(e);
+        GruArgs g = gru_args(e);
+        g.st_ke = e->ke_hist;
+        g.out = raw_out_dev;
+        if (e->wide || e->row_floats != kRowFloats) {
+            for (int u = 0; u < n_updates; ++u) {
+                GruArgs gu = g;
+                gu.st_ke = e->ke_hist + (size_t)u * e->n_padded;
+                gu.out = raw_out_dev + (size_t)u * e->n_streams;
+                int nrc = launch_network(e, gu, 1, s);
+                if (nrc) return nrc;
+            }
+            return PE_OK;
+        }
+        if (g.waves_per_tile != 16) g.waves_per_tile = 1;
+        PE_HIP(e, launch_gru_many(g, n_updates, e->n_padded, s));
         return PE_OK;
     }
     // frames one stream can complete in this call: one task row per frame, at most kMaxFrameRows rows

@@ -396,11 +396,18 @@ struct GeneralStreamArgs {
     float* ring;                // [tiles][slots][16 streams][row_floats] -- or, ring_bf16, 16 bf16 per row (row_floats == 16 only)
     int row_floats;
     int ring_bf16;
+    // several updates per launch (pe_update_many): chunk u of stream s at pcm + (u * n_streams + s) * chunk
+    int n_updates;
+    FastDiv div_chunk;          // division by the chunk length
+    uint32_t* ke_hist;          // [n_updates][n_padded] emitted-frame counter after every update, or null
+    int n_padded;
 };
 
 // Two waves per stream: wave `par` takes the due frames kb = first + par, first + par + 2, ... (1024-sample chunks complete one
 // or two frames per update: the second frame of a stream no longer waits for its first), wave 0 also moves the leftover
 // samples and the counters.  Both read the state before the update; only wave 0 writes the state after it.
+// n_updates > 1 (pe_update_many): the frames of the virtual stream carry ++ chunk 0 ++ ... ++ chunk n-1 in ONE launch, the
+// emitted-frame counter after every update recorded for the network launch that follows (round 5; it was one launch per update).
 template <class R, int BITS, bool BLUE = false>
 __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R* S, const int s, const int par, const int lane, const int n_par = 2) {
     const StreamGeom& geo = a.geo;
@@ -408,11 +415,19 @@ __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R*
     const int q = a.st_q[s];
     const uint32_t kc = a.st_kc[s];
     uint32_t ke = a.st_ke[s];
-    const int avail = q + C;
+    const int U = a.n_updates;
+    const int avail = q + U * C;
     const int nnew = avail >= flen ? 1 + (avail - flen) / hop : 0;
     const int16_t* car = a.carry + (size_t)s * a.carry_cap;
-    const int16_t* row = a.pcm + (size_t)s * C;
-    auto vsample = [&](int v) -> int { return v < q ? (int)car[v] : (int)row[v - q]; };      // (q < 0: all of it in the chunk)
+    const int16_t* row0 = a.pcm + (size_t)s * C;
+    const size_t update_stride = (size_t)geo.n_streams * C;
+    // sample w >= 0 of the call's chunks of this stream, one after the other (pe_update_many: chunk u = w / C, a row of its own)
+    auto row = [&](int w) -> const int16_t* {
+        if (U == 1) return row0 + w;
+        const int u = (int)a.div_chunk.div((uint32_t)w);
+        return row0 + (size_t)u * update_stride + (w - u * C);
+    };
+    auto vsample = [&](int v) -> int { return v < q ? (int)car[v] : (int)*row(v - q); };      // (q < 0: all of it in the chunks)
     // (even, odd) sample pairs as one dword: every quantity that shifts a pair boundary must be even (then a pair never
     // straddles the carry / chunk seam, and every pair address is 4-byte aligned: carry rows are 128-byte aligned)
     const bool pairs = a.pcm_pairs_ok && ((q | hop | flen) & 1) == 0;
@@ -430,7 +445,7 @@ __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R*
         } else if (pairs) {
             general_frame<R, BITS>(a.tab, S, lane_k, [&](int n) -> cplx<R> {
                 const int m = 2 * n < flen ? 2 * n : 0, v = vb + m;           // (beyond the frame: a valid pair, zeroed below)
-                const int16_t* p = v < q ? car + v : row + (v - q);
+                const int16_t* p = v < q ? car + v : row(v - q);
                 const int w2 = *reinterpret_cast<const int*>(p);
                 const bool in = 2 * n < flen;
                 return cplx<R>{in ? (R)(int)(short)(w2 & 0xffff) * RealK<R>::INV_I16 : R(0), in ? (R)(w2 >> 16) * RealK<R>::INV_I16 : R(0)};
@@ -461,7 +476,7 @@ __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R*
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int d = d0 + 64 * i + lane, dc = d < nd ? d : 0, v = vb + 2 * dc;
-                    w2[i] = *reinterpret_cast<const int*>(v < q ? car + v : row + (v - q));
+                    w2[i] = *reinterpret_cast<const int*>(v < q ? car + v : row(v - q));
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -474,10 +489,18 @@ __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R*
         }
     }
     if (lane == 0) {
-        const uint32_t kcn = kc + (uint32_t)nnew;
-        const int mm = qn + hop * (int)(kcn - ke);
-        if (mm >= geo.window) ke += 1u + (uint32_t)((mm - geo.window) / hop);
-        a.st_q_next[s] = qn; a.st_kc_next[s] = kcn; a.st_ke_next[s] = ke;
+        int qu = q;
+        uint32_t kcu = kc;
+        for (int u = 0; u < U; ++u) {                   // the counters update by update, as single updates move them (mfcc_book_tile)
+            const int av = qu + C;
+            const int nn = av >= flen ? 1 + (av - flen) / hop : 0;
+            qu = av - nn * hop;
+            kcu += (uint32_t)nn;
+            const int mm = qu + hop * (int)(kcu - ke);
+            if (mm >= geo.window) ke += 1u + (uint32_t)((mm - geo.window) / hop);
+            if (a.ke_hist) a.ke_hist[(size_t)u * a.n_padded + s] = ke;
+        }
+        a.st_q_next[s] = qu; a.st_kc_next[s] = kcu; a.st_ke_next[s] = ke;
     }
 }
 

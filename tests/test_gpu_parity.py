@@ -653,6 +653,38 @@ def test_general_front_end_feeds_the_bf16_network(kw):
     a.close(); b.close(); many.close()
 
 
+@pytest.mark.parametrize('kw', [GENERAL_PARAMS[1], GENERAL_PARAMS[3], GENERAL_PARAMS[6]],
+                         ids=lambda kw: 'fft%d_filt%d_mfcc%d' % (kw['n_fft'], kw['n_filt'], kw['n_mfcc']))
+def test_general_update_many_is_one_front_end_launch_with_the_same_bits(kw):
+    """pe_update_many behind the general front end (round 5: one MFCC launch over carry ++ chunk 0 ++ ... ++ chunk n-1 instead of
+    one launch per update): bit for bit the updates one after the other, for short chunks that complete a frame only every few
+    updates, long ones that complete several per update, an odd length (sample-by-sample loads) -- 16-float rows through the
+    batched network launch, 32-float rows through one network launch per update."""
+    import warnings
+    from mycroft_precise_amd._lib import HipEngine
+    hpr = P.pr.copy()
+    hpr.__dict__.update(kw)
+    w = synth.make_weights(n_in=kw['n_mfcc'], units=(20,), seed=11)
+    n = 9
+    for chunk, depth in ((160, 16), (2400, 3), (801, 5)):
+        n_up = (36000 // chunk) // depth * depth
+        pcm = _stream_batch(['tone_noise'] * (n - 2) + ['square', 'quiet'], n_up, chunk)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            one = HipEngine(hpr, w, n_streams=n)
+            many = HipEngine(hpr, w, n_streams=n)
+        many.reserve_updates(depth, chunk)
+        for u0 in range(0, n_up, depth):
+            want = np.stack([one.update(pcm[u]) for u in range(u0, u0 + depth)])
+            got = many.update_many(pcm[u0:u0 + depth])
+            assert np.array_equal(got, want), (chunk, depth, u0)
+        assert np.array_equal(one.get_vectors(), many.get_vectors()), (chunk, depth)
+        qa, ka, ea = one.stream_state()
+        qb, kb, eb = many.stream_state()
+        assert np.array_equal(qa, qb) and np.array_equal(ka, kb) and np.array_equal(ea, eb), (chunk, depth)
+        one.close(); many.close()
+
+
 def test_device_threshold_decoder_and_trigger(stock_weights):
     """ThresholdDecoder.decode and TriggerDetector.update for every stream on the device vs the
     reference-pinned fixtures / host classes (decode is a step function: one LUT bin of tolerance;
