@@ -61,8 +61,8 @@ for u in range(n_up):
             bad_windows += nb
             worst = max(worst, float(np.abs(feats[diff] - feats[0]).max()))
 torch.cuda.synchronize()
-print('%s B20=%s mfcc=%s gru=%s ring=%s: %d streams x %d fused updates = %.3g frames: output positions that ever disagreed %d, '
+print('%s network form %s mfcc=%s gru=%s ring=%s: %d streams x %d fused updates = %.3g frames: output positions that ever disagreed %d, '
       'feature windows that differed at a checkpoint %d (worst |delta| %.3g), %.1f s'
-      % (os.path.basename(os.environ.get('PE_LIB', 'in-tree')), os.environ.get('PE_B20', '0'), args.mfcc, args.gru, args.ring, B, n_up,
+      % (os.path.basename(os.environ.get('PE_LIB', 'in-tree')), eng.gru_tiling(), args.mfcc, args.gru, args.ring, B, n_up,
          B * n_up * 1.28, int(bad_dev.item()), bad_windows, worst, time.time() - t0), flush=True)
 eng.close()
