@@ -373,90 +373,72 @@ __device__ __forceinline__ void mfcc_quad_tasks(const MfccStreamArgs<R>& a, cons
         }
         PE_T(11);
     };
-    // leftover samples of the wave's own streams -> the other carry buffer, four streams per round (lane group = stream), eight
-    // samples per lane and load as in mfcc_book_tile's 16-byte form: the launch requires chunk >= frame length, which puts every
-    // leftover inside the chunk (nnew hop > q + chunk - frame length >= q; no frame completed: q < frame length - chunk <= 0).
-    // A round's loads are issued BEFORE a pass and stored AFTER it.  Bookkeeping workgroups of their own would each reserve this
-    // kernel's LDS and run behind the frames instead of beside them (profiles/round5/r5h_mfcc_quad.log).
-    struct __attribute__((packed, aligned(4))) Pcm8 { int d[4]; };
-    int cbase = s_begin - 64, cround = 16, cq = 0;
-    Pcm8 c_v[4];
-    int c_tail = 0, c_full8 = 0, c_rest = 0;
-    long long c_s = -1;
-    bool c_high = false;
-    auto copy_issue = [&]() -> bool {
-#if defined(PE_QUAD_ABL) && (PE_QUAD_ABL & 1)      // (timing only: no leftover role at all)
-        return false;
-#endif
-        bool any = true;
-        if (++cround >= 16 || cbase + 4 * cround >= s_end) {
-            cbase += 64;
-            if (cbase >= s_end) { cbase = s_end; any = false; }
-            else {
-                const int s = cbase + lane;
-                cq = a.st_q[s < s_end ? s : 0];
-                __builtin_amdgcn_s_waitcnt(0x0F70);     // (as in fetch)
-            }
-            cround = 0;
-        }
-        const int src = 4 * cround + G;
-        const int st = cbase + src;
-        const bool valid = any && st < s_end;
-        const int q = __builtin_amdgcn_ds_bpermute(src * 4, cq);
-        const int avail = q + C;
-        const int nnew_s = avail >= flen ? 1 + (int)a.div_hop.div((uint32_t)(avail - flen)) : 0;
-        const int qn = valid ? avail - nnew_s * hop : 0;
-        c_s = valid && qn > 0 ? (long long)st : -1ll;
-        c_full8 = qn > 0 ? (qn & ~7) : 0;
-        c_rest = qn > 0 ? ((qn & 7) >> 1) : 0;
-        const int16_t* row0 = a.pcm + (size_t)(valid ? st : 0) * C;
-        const int16_t* srcp = row0 + (nnew_s * hop - q);               // sample 0 of the leftover (dereferenced only where qn > 0)
-        c_high = __any(c_full8 > 256);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int n = 128 * c + 8 * j;
-            c_v[c] = *reinterpret_cast<const Pcm8*>(n < c_full8 ? srcp + n : row0);          // (unconditional, from a clamped position)
-        }
-        c_tail = *reinterpret_cast<const int*>(j < c_rest ? srcp + c_full8 + 2 * j : row0);
-        return any;
-    };
-    auto copy_finish = [&]() {
-#if defined(PE_QUAD_ABL) && (PE_QUAD_ABL & 2)      // (timing only: no stores of the leftover)
-        if (c_tail == 0x7fffffff) a.ring[0] = 0.0f;
-        return;
-#endif
-        if (c_s < 0) return;
-        int16_t* const carw = a.carry_next + (size_t)c_s * kCarryCap;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int n = 128 * c + 8 * j;
-            if (n < c_full8) *reinterpret_cast<int4*>(carw + n) = int4{c_v[c].d[0], c_v[c].d[1], c_v[c].d[2], c_v[c].d[3]};
-        }
-        if (c_high) {
-#pragma unroll
-            for (int c = 2; c < 4; ++c) {
-                const int n = 128 * c + 8 * j;
-                if (n < c_full8) *reinterpret_cast<int4*>(carw + n) = int4{c_v[c].d[0], c_v[c].d[1], c_v[c].d[2], c_v[c].d[3]};
-            }
-        }
-        if (j < c_rest) *reinterpret_cast<int*>(carw + c_full8 + 2 * j) = c_tail;
-    };
     // two sample buffers in turn (no register copies), every generator call on every path
-    int rawA[16], rawB[16];
-    long long cellA = -1, cellB = -1;
-    bool have = fetch(rawA, cellA);
-    bool bk = copy_issue();
-    while (have || bk) {
-        const bool more = fetch(rawB, cellB);
-        if (have) work(rawA, cellA);
-        copy_finish();
-        const bool bk2 = copy_issue();
-        have = fetch(rawA, cellA);
-        if (more) work(rawB, cellB);
-        copy_finish();
-        bk = copy_issue();
-        (void)bk2;
+    auto passes = [&]() {
+        int rawA[16], rawB[16];
+        long long cellA = -1, cellB = -1;
+        bool have = fetch(rawA, cellA);
+        while (have) {
+            const bool more = fetch(rawB, cellB);
+            work(rawA, cellA);
+            have = fetch(rawA, cellA);
+            if (more) work(rawB, cellB);
+        }
+    };
+    // (every other workgroup moves its leftovers BEFORE its passes: done by all waves at the same moment the role is a memory-bound
+    //  phase of the whole machine with the vector pipes idle)
+    const bool copy_first = (blockIdx.x & 1) != 0;
+    if (!copy_first) passes();
+    // leftover samples of the wave's own streams -> the other carry buffer, AFTER its passes: four streams per round (lane group =
+    // stream), eight samples per lane and load as in mfcc_book_tile's 16-byte form, eight rounds' loads in flight before the first
+    // store (the transform's registers are dead here).  The launch requires chunk >= frame length, which puts every leftover inside
+    // the chunk (nnew hop > q + chunk - frame length >= q; no frame completed: q < frame length - chunk <= 0).  Bookkeeping
+    // workgroups of their own would each reserve this kernel's LDS and run behind the frames instead of beside them; interleaved
+    // with the passes the role costs 9 us at 65536 streams (profiles/round5/r5h_mfcc_quad.log).
+    struct __attribute__((packed, aligned(4))) Pcm8 { int d[4]; };
+    constexpr int kRounds = 8;
+    for (int cb = s_begin; cb < s_end; cb += 64) {
+        const int sl = cb + lane;
+        const int cq = a.st_q[sl < s_end ? sl : 0];
+        for (int r0 = 0; r0 < 16 && cb + 4 * r0 < s_end; r0 += kRounds) {
+            Pcm8 v[kRounds][4];
+            int tail[kRounds], full8[kRounds], rest[kRounds], strm[kRounds];
+#pragma unroll
+            for (int k = 0; k < kRounds; ++k) {
+                const int src = 4 * (r0 + k) + G;
+                const int st = cb + src;
+                const bool valid = st < s_end;
+                const int q = __builtin_amdgcn_ds_bpermute(src * 4, cq);
+                const int avail = q + C;
+                const int nnew_s = avail >= flen ? 1 + (int)a.div_hop.div((uint32_t)(avail - flen)) : 0;
+                const int qn = valid ? avail - nnew_s * hop : 0;
+                strm[k] = valid && qn > 0 ? st : -1;
+                full8[k] = qn > 0 ? (qn & ~7) : 0;
+                rest[k] = qn > 0 ? ((qn & 7) >> 1) : 0;
+                const int16_t* row0 = a.pcm + (size_t)(valid ? st : 0) * C;
+                const int16_t* srcp = row0 + (nnew_s * hop - q);           // sample 0 of the leftover (dereferenced only where qn > 0)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int n = 128 * c + 8 * j;
+                    v[k][c] = *reinterpret_cast<const Pcm8*>(n < full8[k] ? srcp + n : row0);      // (unconditional, from a clamped position)
+                }
+                tail[k] = *reinterpret_cast<const int*>(j < rest[k] ? srcp + full8[k] + 2 * j : row0);
+            }
+#pragma unroll
+            for (int k = 0; k < kRounds; ++k) {
+                if (strm[k] >= 0) {
+                    int16_t* const carw = a.carry_next + (size_t)strm[k] * kCarryCap;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int n = 128 * c + 8 * j;
+                        if (n < full8[k]) *reinterpret_cast<int4*>(carw + n) = int4{v[k][c].d[0], v[k][c].d[1], v[k][c].d[2], v[k][c].d[3]};
+                    }
+                    if (j < rest[k]) *reinterpret_cast<int*>(carw + full8[k] + 2 * j) = tail[k];
+                }
+            }
+        }
     }
+    if (copy_first) passes();
 }
 
 }  // namespace pe
