@@ -6,7 +6,7 @@
 #include "mfcc_device.h"
 #include "mfcc_wave_device.h"
 #ifdef PE_TUNING
-#include "mfcc_quad_device.h"       // (round 5 experiment: four frames per wave)
+#include "../../tools/micro/mfcc_quad_device.h"       // (round 5 experiment: four frames per wave)
 #endif
 #include "gru_device.h"
 #include "gru_cw_device.h"

@@ -16,7 +16,7 @@
 //   * power spectrum to LDS in the slot order the filterbank run tables of mfcc_wave_tables.h expect (the SAME tables as the
 //     one-frame-per-wave kernel: four runs per lane instead of one), log on 16 lanes per round, DCT as one coefficient per lane.
 #pragma once
-#include "mfcc_wave_device.h"
+#include "../../mycroft_precise_amd/csrc/mfcc_wave_device.h"
 
 namespace pe {
 
