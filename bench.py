@@ -2,7 +2,7 @@
 """
 bench.py -- windows/sec of the MI355X wake-word hot path (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -490,6 +490,56 @@ def single_stream_latency_extra(n_calls=400):
             'config': {'workload': 'one stream, one 2048-byte chunk per call, synchronous', 'streams_per_gpu': 1}}
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): become
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same argv>`.
+    Refuses first, by name, when the node has fewer GPUs than ranks (PE_BENCH_SHARED_GPU=1: every rank on cuda:0, gloo)."""
+    import socket
+    shared = os.environ.get('PE_BENCH_SHARED_GPU') == '1'
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < (1 if shared else n_gpus):
+        sys.exit('bench.py --gpus %d: this node exposes %d GPU(s) (torch.cuda.device_count()); one rank per MI355X needs %d'
+                 '%s' % (n_gpus, have, n_gpus, '' if shared else ' (PE_BENCH_SHARED_GPU=1 runs every rank on cuda:0 over gloo: a plumbing test, not a measurement)'))
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def headline_parity(pcm, fed, n_timed, got, weights, tol, n_check=256):
+    """Parity object of the headline line: the oracle (the checker; never inside a timed region) replays the chunks the
+    first `n_check` streams were fed and every probability of the timed region is compared.  `fed` is the whole sequence of
+    resident-slab indices since the engine was created (roofline pass, warm-up, timed region); the replay starts late: at an
+    update index that is a multiple of 25 (25 x 1024 samples = 32 hops: a fresh stream frames the audio exactly as the
+    running one does from there) at least 30 updates before the timed region (the 29-frame window holds only frames from
+    the replayed part by then -- 1.28 frames per update)."""
+    from oracle import listener as oracle_listener
+    n_check = min(n_check, got.shape[1])
+    n_pre = len(fed) - n_timed
+    start = max(0, (n_pre - 30) // 25 * 25)
+    if CHUNK * 25 % pr.hop_samples != 0:
+        start = 0
+    slabs = sorted(set(fed[start:]))
+    host = {i: pcm[i, :n_check].cpu().numpy() for i in slabs}
+    oracle = oracle_listener.BatchedOracle(weights, n_check)
+    want = []
+    for k, i in enumerate(fed[start:]):
+        w = oracle.update_raw(host[i])
+        if start + k >= n_pre:
+            want.append(np.asarray(w, dtype=np.float64))
+    want = np.stack(want)
+    err = float(np.abs(want - got[:, :n_check].astype(np.float64)).max())
+    return {'max_abs_err': err, 'tol': tol, 'ok': bool(err <= tol), 'streams_checked': n_check, 'steps_checked': int(n_timed),
+            'oracle_lead_in_updates': int(n_pre - start),
+            'against': "oracle.listener.BatchedOracle replaying the timed region's own chunks (checker, outside the timed region); "
+                       "every probability of the timed region's probs[steps][0:%d]" % n_check}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -512,22 +562,30 @@ def main():
                     help='back-to-back launches of the roofline pass that precedes the warm-up (HIP events around the run)')
     ap.add_argument('--resident-updates', type=int, default=256,
                     help='distinct PCM chunks kept in HBM per stream (reused cyclically beyond that)')
+    ap.add_argument('--gather-every-step', choices=['rccl', 'host'], default=None,
+                    help="after the headline's timed region, a second one in which step u's probabilities leave the GPU while update "
+                         "u + 1 runs: 'rccl' = one asynchronous gather to rank 0 per step (gloo on host copies with PE_BENCH_SHARED_GPU=1), "
+                         "'host' = every rank copies its own [B] floats into its own pinned host ring on a side stream (no collective per step)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args.gpus)                       # does not return
     rank, local_rank, world = env_world()
     # host-core baseline first, before this process owns a GPU context (it forks workers)
     cpu = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None
     cpu_b1 = cpu_baseline_single_stream() if (world == 1 and not args.no_cpu_baseline) else None
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
-                     % (args.gpus, args.gpus))
+        sys.exit('bench.py --gpus %d was started as one of %d rank(s) (WORLD_SIZE): launch it bare -- it starts its own ranks -- or '
+                 'with torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X (torch.cuda.is_available() is False)')
     # PE_BENCH_SHARED_GPU=1 (test aid for 1-GPU boxes): every rank uses cuda:0 and the collectives run over gloo
     # on host copies, so the N > 1 control flow can be exercised where RCCL (one device per rank) cannot run.
     shared_gpu = os.environ.get('PE_BENCH_SHARED_GPU') == '1'
     dev_index = 0 if shared_gpu else local_rank
+    if dev_index >= torch.cuda.device_count():
+        sys.exit('bench.py rank %d: local rank %d has no GPU (this node exposes %d); one rank per MI355X'
+                 % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     comm_device = torch.device('cpu') if shared_gpu else device
@@ -564,7 +622,13 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if shared_gpu:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[dev_index])      # (RCCL: names the device, no guess from the rank)
+
+    # which slab of the resident PCM every update since the engine's creation was fed (headline_parity replays its tail)
+    fed = []
 
     def run(first_step, n, out_rows):
         for i in range(n):
@@ -585,13 +649,29 @@ def main():
         ev1.synchronize()
         return ev0.elapsed_time(ev1) / n
 
-    if world > 1:                                # warm the communicator (same shape as the timed gather)
-        gather_probabilities(probs.to(comm_device), n_global, dst=0)
+    collective = {'collective': None, 'fallback_reason': None}
+    if world > 1:
+        # Warm the communicator with the timed gather's own shape -- and settle HERE, before anything is timed, which
+        # collective the job uses: a gather to rank 0 (one send per peer over its own xGMI link), or, should this RCCL build
+        # refuse it, an all-gather.  Every rank must take the same one: the outcome is agreed with an all-reduce (MIN).
+        ok = 1
+        try:
+            gather_probabilities(probs.to(comm_device), n_global, dst=0)
+        except Exception as ex:                               # noqa: BLE001
+            ok = 0
+            collective['fallback_reason'] = repr(ex)[:200]
+        flag = torch.tensor([ok], dtype=torch.int32, device=comm_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        collective['collective'] = 'gather' if int(flag.item()) == 1 else 'all_gather'
+        if collective['collective'] == 'all_gather':
+            gather_probabilities(probs.to(comm_device), n_global, dst=None)
+    gather_dst = 0 if collective['collective'] != 'all_gather' else None
     # ---- roofline pass FIRST, on every rank: `roofline.achieved` comes from here.  It also is what takes the GPU out of
     # idle: a 25-launch region entered from an idle GPU runs 8 % slower than the same region after >= 20 ms of
     # back-to-back launches (19.9 vs 18.3 us/step, tools/gpu_cold_start*.py), and the metric is sustained throughput.
     roofline_launches = args.roofline_launches
     fused_ms = bracket_pass(roofline_launches)          # wide networks: MFCC launch + network launch per update
+    fed += [(warmup + steps + i) % n_res for i in range(roofline_launches)]
 
     # ---- warm-up: `warmup` untimed steps --------------------------------------------------------
     run(0, warmup, False)
@@ -602,10 +682,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(warmup, steps, True)
-    gathered = gather_probabilities(probs.to(comm_device), n_global, dst=0) if world > 1 else probs      # rank 0 only
+    gathered = gather_probabilities(probs.to(comm_device), n_global, dst=gather_dst) if world > 1 else probs      # rank 0 (all ranks after a fallback)
     wait_for_gpu()
     barrier()
     elapsed = time.perf_counter() - t0
+    fed += [i % n_res for i in range(warmup)] + [(warmup + i) % n_res for i in range(steps)]
     rank_ms = [1e3 * elapsed / steps]
     ranks_seen = 1
     if world > 1:
@@ -621,6 +702,69 @@ def main():
     finite = bool(torch.isfinite(gathered if rank == 0 else probs).all().item())
     if rank == 0 and os.environ.get('PE_BENCH_DUMP'):        # test aid: the timed region's probabilities, rank-ordered
         np.save(os.environ['PE_BENCH_DUMP'], gathered.cpu().numpy())
+    # parity of the headline itself (rank 0's own shard: global streams 0 .. 255), from the timed region's own probabilities
+    parity = None
+    if rank == 0:
+        try:
+            parity = headline_parity(pcm, fed, steps, probs.cpu().numpy(), weights, 1e-2 if args.gru_precision == 'bf16' else 1e-4,
+                                     n_check=256 if stock else 16)
+        except Exception as ex:                                  # noqa: BLE001  (the checker must not cost the bench its line)
+            parity = {'error': repr(ex)}
+
+    # ---- --gather-every-step: a second region, same K steps, step u's probabilities leaving while update u + 1 runs ----------
+    per_step = None
+    if args.gather_every_step:
+        mode = args.gather_every_step
+        side = torch.cuda.Stream(device=device)
+        host_ring = torch.empty((steps, B), dtype=torch.float32).pin_memory()
+        recv = None
+        if mode == 'rccl' and world > 1 and rank == 0:
+            recv = torch.empty((world, steps, B), dtype=torch.float32, device=comm_device)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        works, evs = [], []
+        for i in range(steps):
+            u = (warmup + i) % n_res
+            engine.update_device(pcm_base + u * chunk_bytes, CHUNK, probs_base + i * B * 4, stream)
+            if mode == 'host' or (mode == 'rccl' and shared_gpu) or world == 1:
+                ev = torch.cuda.Event()
+                ev.record()                                       # behind update i on the launch stream
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    host_ring[i].copy_(probs[i], non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record()
+                evs.append(done)
+                if mode == 'rccl' and world > 1:                  # shared-GPU test path: gloo needs host tensors, so the host waits per step
+                    done.synchronize()
+                    dist.gather(host_ring[i], [recv[r][i] for r in range(world)] if rank == 0 else None, dst=0)
+            else:
+                # RCCL: torch's collective stream waits for the launch stream's work so far (update i) and runs the gather beside
+                # update i + 1; async_op keeps the launch stream itself from waiting for it
+                works.append(dist.gather(probs[i], [recv[r][i] for r in range(world)] if rank == 0 else None, dst=0, async_op=True))
+        for w in works:
+            w.wait()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t1
+        fed += [(warmup + i) % n_res for i in range(steps)]
+        if world > 1:
+            mine = torch.tensor([dt], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+            dt = float(mine.item())
+        delivered_ok = None
+        if rank == 0:
+            if recv is not None:
+                delivered_ok = bool(torch.equal(recv[0].to(device), probs))
+            else:
+                delivered_ok = bool(torch.equal(host_ring.to(device), probs))
+        per_step = {'mode': mode if world > 1 or mode == 'host' else 'host (one rank: nothing to gather)',
+                    'transport': ('gloo on host copies (PE_BENCH_SHARED_GPU=1: plumbing only, the host waits for every step)' if (mode == 'rccl' and shared_gpu and world > 1)
+                                  else 'RCCL gather to rank 0 per step, asynchronous beside the next update' if (mode == 'rccl' and world > 1)
+                                  else "each rank's own pinned host ring, one 4 B x %d copy per step on a side stream" % B),
+                    'ms_per_step': 1e3 * dt / steps, 'value': n_global * steps / dt, 'unit': 'windows/s',
+                    'final_gather_ms_per_step': 1e3 * elapsed / steps, 'delivered_equals_device': delivered_ok}
 
     # ---- instrumented passes: HIP-event time per launch, on the launch stream --------------------
     def timed_pass(fused):
@@ -647,25 +791,52 @@ def main():
     time_batched = None
     depth = 8
     if world == 1 and not args.no_batched and (stock or args.gru_precision == 'bf16') and n_res >= 2 * depth:      # N = 1 only: no collectives outside the timed region
+        def batched_run(tiling):
+            """8 updates per call on a fresh engine reserved for it (the engine picks ONE network form for all of its launches when it
+            is reserved: engine.hip gru_args); tiling -1 = that automatic choice, otherwise forced."""
+            eng = HipEngine(pr, weights, n_streams=B, device=dev_index, mfcc_precision=args.mfcc_precision,
+                            gru_precision=args.gru_precision, ring_precision=args.ring_precision)
+            try:
+                eng.reserve_updates(depth, CHUNK)
+                if tiling >= 0:
+                    eng.set_gru_tiling(tiling)
+                form = eng.gru_tiling()
+                many_out = torch.zeros((depth, B), dtype=torch.float32, device=device)
+                rounds = max(4, min(steps, 200) // depth)
+                for i in range(4):
+                    eng.update_many_device(pcm_base + ((i * depth) % max(1, n_res - depth)) * chunk_bytes, CHUNK, depth, many_out.data_ptr(), stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(rounds):
+                    eng.update_many_device(pcm_base + ((i * depth) % max(1, n_res - depth)) * chunk_bytes, CHUNK, depth, many_out.data_ptr(), stream)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                # parity: the same 4 + rounds calls replayed by the oracle on 256 streams, last call's 8 x 256 probabilities
+                from oracle import listener as oracle_listener
+                n_chk = min(256, B)
+                oracle = oracle_listener.BatchedOracle(weights, n_chk)
+                host = pcm[:, :n_chk].cpu().numpy()
+                want = None
+                for i in list(range(4)) + list(range(rounds)):
+                    first = (i * depth) % max(1, n_res - depth)
+                    want = np.stack([oracle.update_raw(host[first + k]) for k in range(depth)])
+                err = float(np.abs(want.astype(np.float64) - many_out[:, :n_chk].cpu().numpy().astype(np.float64)).max())
+                tol_b = 1e-2 if args.gru_precision == 'bf16' else 1e-4
+                return {'gru_form': form, 'value': n_global * rounds * depth / dt, 'unit': 'windows/s', 'ms_per_update': 1e3 * dt / (rounds * depth),
+                        'parity': {'max_abs_err': err, 'tol': tol_b, 'ok': bool(err <= tol_b), 'streams_checked': n_chk}}
+            finally:
+                eng.close()
         try:
-            engine.reserve_updates(depth, CHUNK)
-            many_out = torch.zeros((depth, B), dtype=torch.float32, device=device)
-            rounds = max(4, min(steps, 200) // depth)
-            for i in range(4):
-                engine.update_many_device(pcm_base + ((i * depth) % max(1, n_res - depth)) * chunk_bytes, CHUNK, depth,
-                                          many_out.data_ptr(), stream)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(rounds):
-                engine.update_many_device(pcm_base + ((i * depth) % max(1, n_res - depth)) * chunk_bytes, CHUNK, depth,
-                                          many_out.data_ptr(), stream)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            time_batched = {'updates_per_call': depth, 'value': n_global * rounds * depth / dt, 'unit': 'windows/s',
-                            'ms_per_update': 1e3 * dt / (rounds * depth),
-                            'note': 'pe_update_many_device: same results, 3 launches per %d updates; not the headline' % depth}
-        except (ValueError, NotImplementedError):
-            time_batched = None
+            auto = batched_run(-1)
+            time_batched = dict(auto, updates_per_call=depth,
+                                note='pe_update_many_device on an engine reserved for %d updates per call: same results as single updates, 2 launches per %d '
+                                     'updates; the reserved engine picks its network form for the batched launch (gru_form: 1 = re-tiled f32-input MFMAs, '
+                                     '2 = float32 products on the bf16 pipe); not the headline' % (depth, depth))
+            if args.gru_precision == 'f32' and stock:
+                other = 1 if auto['gru_form'] == 2 else 2
+                time_batched['other_form'] = batched_run(other)
+        except (ValueError, NotImplementedError) as ex:
+            time_batched = {'error': repr(ex)}
 
     # ---- the other BASELINE.json configurations that fit one GPU (N = 1 only; each a few seconds) -------------------
     extras = []
@@ -775,6 +946,7 @@ def main():
                        'parallelism': 'streams sharded over %d rank(s), final RCCL gather of probabilities to rank 0' % world},
             'realtime_streams': value / REALTIME_WINDOWS_PER_S,
             'outputs_finite': finite,
+            'parity': parity,
             # what the communicator reported and every rank's own clock around the timed region (value uses the max)
             'sequence': 'roofline pass (%d back-to-back launches, HIP events) -> %d warm-up steps -> %d timed steps; a region entered '
                         'from an idle GPU measures ~8 %% slower (DESIGN 5)' % (roofline_launches, warmup, steps),
@@ -783,6 +955,8 @@ def main():
                              'note': 'distinct [B][1024] int16 slabs cycled by every pass; independent of --steps'},
             'ranks_seen': ranks_seen, 'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms)},
             'collective_backend': (dist.get_backend() if world > 1 else None),      # 'nccl' = RCCL over xGMI (one device per rank)
+            'collective': collective['collective'], 'collective_fallback_reason': collective['fallback_reason'],
+            'streams_per_rank': [B] * world,
             # dominant kernel of the timed region: the fused launch (GRU role is its long pole)
             'roofline': ({'kernel': fused_name, 'bound': 'hbm', 'achieved': gbs_w(fused_ms), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                           'frac': gbs_w(fused_ms) / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': fused_ms,
@@ -818,6 +992,8 @@ def main():
             line['extra_configs'] = extras
         if time_batched is not None:
             line['time_batched'] = time_batched
+        if per_step is not None:
+            line['per_step_delivery'] = per_step
         if cpu is not None:
             line['cpu_baseline'] = cpu
         if cpu_b1 is not None:

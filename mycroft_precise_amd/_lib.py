@@ -6,6 +6,7 @@ There is NO CPU fallback: if the HIP library is missing or a call fails this mod
 import ctypes as C
 import importlib.util
 import os
+import weakref
 
 import numpy as np
 
@@ -155,7 +156,9 @@ class HipEngine:
         from .params import Vectorizer
         self._lib = load()
         self._h = C.c_void_p()
-        self._pinned, self._async_keep = [], []
+        self._async_keep = []
+        self._views = 0                # host_array() buffers still referenced by numpy arrays (their memory dies with the engine)
+        self._close_pending = False
         self.n_streams = int(n_streams)
         self.n_features = int(params.n_features)
         self.n_mfcc = int(params.n_mfcc)
@@ -235,21 +238,32 @@ class HipEngine:
     # -- host-fed pipeline (pe_update_async / pe_wait): scripts/engine.py:60-63 hands over host bytes per chunk ----------
     def host_array(self, shape, dtype) -> np.ndarray:
         """A numpy array over pinned, device-visible host memory of this engine (pe_host_alloc): ``update_async`` reads PCM
-        from / writes probabilities to such arrays without a staging copy.  Freed with the engine."""
+        from / writes probabilities to such arrays without a staging copy.  The memory belongs to the engine (pe_destroy frees
+        it), so the array keeps the engine alive: ``close()`` -- explicit or by garbage collection -- takes effect only once
+        the last such array (and every view of it) is gone."""
         dtype = np.dtype(dtype)
         n = int(np.prod(shape)) * dtype.itemsize
         p = C.c_void_p()
         self._check(self._lib.pe_host_alloc(self._h, max(n, 1), C.byref(p)))
         buf = (C.c_char * max(n, 1)).from_address(p.value)
         arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-        self._pinned.append((p.value, buf))
+        # `buf` is the base object of `arr` and of every view of it; the finalizer holds the engine (a bound method) until buf dies
+        self._views += 1
+        weakref.finalize(buf, self._view_released).atexit = False      # (at interpreter exit the HIP runtime may already be gone)
         return arr
+
+    def _view_released(self):
+        self._views -= 1
+        if self._views == 0 and self._close_pending:
+            self.close()
 
     def update_async(self, pcm: np.ndarray, out: np.ndarray = None) -> np.ndarray:
         """Enqueue one update ([n_streams, chunk] int16) and return the float32 [n_streams] array its probabilities will be
         in after ``wait()`` (or once 3 more updates have been enqueued).  Up to 3 updates are in flight: the next chunk
-        crosses PCIe while this one runs.  ``pcm`` from ``host_array`` is read in place (keep it untouched until then);
-        any other array is copied at the call."""
+        crosses PCIe while this one runs.  ``pcm`` is handed to ``hipMemcpyAsync`` as it is: PAGEABLE memory is staged by the
+        HIP runtime before the call returns (the array is free again at once); memory the runtime knows as PINNED --
+        ``host_array``, but also ``torch.Tensor.pin_memory()`` / hipHostRegister'ed buffers -- is read by the DMA engine after
+        the call returns and must stay untouched until ``wait()`` or until 3 more updates have been enqueued."""
         pcm = self._pcm(pcm)
         if out is None:
             out = np.empty(self.n_streams, dtype=np.float32)
@@ -414,7 +428,9 @@ class HipEngine:
         self._check(self._lib.pe_set_gru_tiling(self._h, int(tiling)))
 
     def gru_tiling(self) -> int:
-        """The form this engine's network launches take now: 0 / 1 / 2 as above, -1 for wide networks."""
+        """The form this engine's network launches take now (pe_get_gru_tiling): float32 networks of <= 32 units 0 / 1 / 2 as
+        above; wide / stacked networks 0 (f32-input MFMAs) or 2 (float32 products on the bf16 pipe); bf16-operand networks
+        1 (five gate values per lane) or 0 (eight)."""
         return int(self._lib.pe_get_gru_tiling(self._h))
 
     def set_timing(self, enabled: bool):
@@ -426,7 +442,16 @@ class HipEngine:
         return a.value, b.value
 
     def close(self):
+        """pe_destroy.  While arrays from ``host_array`` are still referenced the destruction is deferred until the last one
+        is gone (their memory is the engine's): nothing can read freed pinned memory through a stale array."""
         if getattr(self, '_h', None) and self._h.value:
+            if getattr(self, '_views', 0) > 0:
+                self._close_pending = True
+                try:
+                    self._lib.pe_wait(self._h)       # nothing of this engine stays in flight behind a "closed" handle
+                except Exception:
+                    pass
+                return
             self._lib.pe_destroy(self._h)
             self._h = C.c_void_p()
 

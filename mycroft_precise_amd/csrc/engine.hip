@@ -106,14 +106,19 @@ struct pe_engine {
     // buffers and pinned staging; the chunk of update u + 1 crosses PCIe (copy stream) while update u runs (compute stream)
     static constexpr int kAsyncDepth = 3;
     struct AsyncSlot {
-        void* pin_in = nullptr; size_t pin_in_bytes = 0;        // pinned staging for callers that hand over pageable memory
-        float* pin_out = nullptr; size_t pin_out_bytes = 0;
+        float* pin_out = nullptr; size_t pin_out_bytes = 0;     // pinned landing zone for callers whose output array is pageable
         DeviceBuf dev_in, dev_out;
         hipEvent_t copied = nullptr, done = nullptr;
         float* user_out = nullptr; size_t out_bytes = 0;
         bool direct_out = false, busy = false;
     } aslot[kAsyncDepth];
     hipStream_t s_copy = nullptr, s_compute = nullptr;
+    // the stream of the last *_device call that moved the streams' state: pe_update_async runs on the engine's own
+    // (non-blocking) streams, which nothing orders behind that work -- not even the NULL stream -- so it waits for it
+    // by event, lazily (recorded only when the caller switches styles: the *_device loop itself pays nothing)
+    hipStream_t last_user_stream = nullptr;
+    bool user_dirty = false;
+    hipEvent_t ev_user = nullptr;
     unsigned async_next = 0;
     int async_inflight = 0;
     std::vector<std::pair<char*, size_t>> pinned;               // pe_host_alloc'ed ranges (zero-copy sources / destinations)
@@ -821,7 +826,13 @@ GruArgs gru_args(const pe_engine* e) {
     // 24 576, 69 vs 79 at 32 768, 128 vs 154 us at 65 536 -- and 48 vs 43 us at 16 384 (one tile per SIMD: the classic network
     // still runs in one round of waves, and the missing fused launch costs more than the cheaper network saves).
     const bool x3_ok = e->x3_blob && !a.bf16 && !e->wide && !a.proj_ring && e->row_floats == kRowFloats && e->gru_waves != 16;
-    a.x3 = x3_ok && (e->gru_tiling == 2 || (e->gru_tiling < 0 && e->n_tiles > 4 * e->n_cus)) ? e->x3_blob : nullptr;
+    // ... and so do engines reserved for several updates per call (pe_reserve_updates) whose batched network launch has more
+    // (update, tile) windows than the machine has SIMDs: ONE form per engine (every launch of a form agrees bit for bit), chosen
+    // for the launch the engine was reserved for -- its single updates then run the one-wave XDL kernel in two launches.
+    // Measured at 4096 streams x 8 updates per call: 61.6 us for the batched network on the re-tiled f32-input form against
+    // the XDL form's rate of ~26 us for the same 32 768 windows (profiles/round5/r5zz_kernel_stats.csv; round 6: profiles/round6).
+    const bool many_windows = e->max_updates > 1 && (long long)e->max_updates * e->n_tiles > 4LL * e->n_cus;
+    a.x3 = x3_ok && (e->gru_tiling == 2 || (e->gru_tiling < 0 && (e->n_tiles > 4 * e->n_cus || many_windows))) ? e->x3_blob : nullptr;
     a.x3w = e->x3_blob;
     const bool cw_ok = e->cw_blob && e->row_floats == kRowFloats && !a.proj_ring && !a.bf16 && !a.x3 && !e->wide && e->gru_waves != 16;
     const bool retile = cw_ok && (e->gru_tiling == 1 || (e->gru_tiling < 0 && e->n_tiles <= 2 * e->n_cus));
@@ -895,6 +906,7 @@ int async_init(pe_engine* e) {
         PE_HIP(e, hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
         PE_HIP(e, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
+    PE_HIP(e, hipEventCreateWithFlags(&e->ev_user, hipEventDisableTiming));
     return PE_OK;
 }
 
@@ -910,20 +922,28 @@ int ensure_pinned(pe_engine* e, void** p, size_t* have, size_t bytes) {
 // the update in this slot has finished: hand its probabilities to the caller
 int finish_slot(pe_engine* e, pe_engine::AsyncSlot& sl) {
     if (!sl.busy) return PE_OK;
-    PE_HIP(e, hipEventSynchronize(sl.done));
-    if (!sl.direct_out) std::memcpy(sl.user_out, sl.pin_out, sl.out_bytes);
-    sl.busy = false;
+    const hipError_t err = hipEventSynchronize(sl.done);
+    sl.busy = false;                                  // (also when the wait failed: a slot that stays busy would fail every later drain)
     --e->async_inflight;
+    if (err != hipSuccess) return fail(e, PE_ERR_HIP, "hipEventSynchronize(update in flight) failed: %s", hipGetErrorString(err));
+    if (!sl.direct_out) std::memcpy(sl.user_out, sl.pin_out, sl.out_bytes);
     return PE_OK;
 }
 
 int drain_async(pe_engine* e) {
     if (!e || e->async_inflight == 0) return PE_OK;
-    for (int i = 0; i < pe_engine::kAsyncDepth; ++i) {                 // oldest first
-        int rc = finish_slot(e, e->aslot[(e->async_next + i) % pe_engine::kAsyncDepth]);
-        if (rc) return rc;
+    int first_rc = PE_OK;
+    for (int i = 0; i < pe_engine::kAsyncDepth; ++i) {                 // oldest first; a failed slot does not keep the others in flight
+        const int rc = finish_slot(e, e->aslot[(e->async_next + i) % pe_engine::kAsyncDepth]);
+        if (rc && !first_rc) first_rc = rc;
     }
-    return PE_OK;
+    return first_rc;
+}
+
+// a *_device entry point is about to enqueue state-moving work on the caller's stream (see pe_engine::last_user_stream)
+void note_user_stream(pe_engine* e, void* stream) {
+    e->last_user_stream = static_cast<hipStream_t>(stream);
+    e->user_dirty = true;
 }
 
 int check_chunk(pe_engine* e, const void* pcm, int chunk) {
@@ -1166,13 +1186,13 @@ int pe_destroy(pe_engine* e) {
     if (e->s_compute) (void)hipStreamSynchronize(e->s_compute);
     if (e->s_copy) (void)hipStreamSynchronize(e->s_copy);
     for (auto& sl : e->aslot) {
-        if (sl.pin_in) (void)hipHostFree(sl.pin_in);
         if (sl.pin_out) (void)hipHostFree(sl.pin_out);
         if (sl.dev_in.p) (void)hipFree(sl.dev_in.p);
         if (sl.dev_out.p) (void)hipFree(sl.dev_out.p);
         if (sl.copied) (void)hipEventDestroy(sl.copied);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    if (e->ev_user) (void)hipEventDestroy(e->ev_user);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
     for (auto& r : e->pinned) (void)hipHostFree(r.first);
@@ -1206,6 +1226,7 @@ int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, float*
     PE_HIP(e, hipSetDevice(e->device));
     PE_DRAIN(e);
     if (!raw_out_dev) return fail(e, PE_ERR_INVALID, "raw_out_dev is null");
+    note_user_stream(e, stream);
     return do_update(e, pcm_dev, chunk, raw_out_dev, nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -1214,6 +1235,7 @@ int pe_update_vectors_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk
     if (rc) return rc;
     PE_HIP(e, hipSetDevice(e->device));
     PE_DRAIN(e);
+    note_user_stream(e, stream);
     return do_update(e, pcm_dev, chunk, nullptr, feats_out_dev, static_cast<hipStream_t>(stream));
 }
 
@@ -1221,6 +1243,7 @@ int pe_run_device(pe_engine* e, float* raw_out_dev, void* stream) {
     if (!e || !raw_out_dev) return fail(e, PE_ERR_INVALID, "null argument to pe_run_device");
     PE_HIP(e, hipSetDevice(e->device));
     PE_DRAIN(e);
+    note_user_stream(e, stream);
     return launch_gru_ring(e, raw_out_dev, static_cast<hipStream_t>(stream));
 }
 
@@ -1275,21 +1298,41 @@ int pe_update_async(pe_engine* e, const int16_t* pcm_host, int32_t chunk, float*
     if ((rc = ensure(e, sl.dev_in, pcm_bytes))) return rc;
     if ((rc = ensure(e, sl.dev_out, out_bytes))) return rc;
     // (pageable memory: hipMemcpyAsync stages it through the runtime's own pinned buffers and returns once the last piece is
-    //  staged -- the caller gets its buffer back at the return of this call either way; measured: 207 us per 8.4 MB update that
-    //  way against 295 us with a memcpy into a pinned ring of the engine's own, 165 us zero-copy from pe_host_alloc'ed memory)
-    const void* src = pcm_host;
+    //  staged -- the caller gets its buffer back at the return of this call; measured: 207 us per 8.4 MB update that
+    //  way against 295 us with a memcpy into a pinned ring of the engine's own, 165 us zero-copy from pe_host_alloc'ed memory.
+    //  Memory the runtime knows as pinned -- pe_host_alloc, but also hipHostRegister / torch pin_memory -- is read by the DMA
+    //  AFTER this call returns: such a buffer must stay untouched until the update is delivered)
     sl.direct_out = is_pinned(e, raw_out_host, out_bytes);
     if (!sl.direct_out) {
         void* po = sl.pin_out;
         if ((rc = ensure_pinned(e, &po, &sl.pin_out_bytes, out_bytes))) return rc;
         sl.pin_out = static_cast<float*>(po);
     }
-    PE_HIP(e, hipMemcpyAsync(sl.dev_in.p, src, pcm_bytes, hipMemcpyHostToDevice, e->s_copy));
-    PE_HIP(e, hipEventRecord(sl.copied, e->s_copy));
-    PE_HIP(e, hipStreamWaitEvent(e->s_compute, sl.copied, 0));
-    if ((rc = do_update(e, static_cast<const int16_t*>(sl.dev_in.p), chunk, static_cast<float*>(sl.dev_out.p), nullptr, e->s_compute))) return rc;
-    PE_HIP(e, hipMemcpyAsync(sl.direct_out ? raw_out_host : sl.pin_out, sl.dev_out.p, out_bytes, hipMemcpyDeviceToHost, e->s_compute));
-    PE_HIP(e, hipEventRecord(sl.done, e->s_compute));
+    // state-moving work the caller queued through a *_device entry point (on the NULL stream or its own) comes first
+    if (e->user_dirty) {
+        PE_HIP(e, hipEventRecord(e->ev_user, e->last_user_stream));
+        PE_HIP(e, hipStreamWaitEvent(e->s_compute, e->ev_user, 0));
+        e->user_dirty = false;
+    }
+    // From the first enqueue on, a failure must not leave half an update behind: both streams are drained, the slot stays
+    // free, and the error goes to the caller (the streams' state may then be one update ahead of what was delivered --
+    // the message says so; pe_clear restarts the streams).
+    auto enqueue = [&]() -> int {
+        PE_HIP(e, hipMemcpyAsync(sl.dev_in.p, pcm_host, pcm_bytes, hipMemcpyHostToDevice, e->s_copy));
+        PE_HIP(e, hipEventRecord(sl.copied, e->s_copy));
+        PE_HIP(e, hipStreamWaitEvent(e->s_compute, sl.copied, 0));
+        int urc = do_update(e, static_cast<const int16_t*>(sl.dev_in.p), chunk, static_cast<float*>(sl.dev_out.p), nullptr, e->s_compute);
+        if (urc) return urc;
+        PE_HIP(e, hipMemcpyAsync(sl.direct_out ? raw_out_host : sl.pin_out, sl.dev_out.p, out_bytes, hipMemcpyDeviceToHost, e->s_compute));
+        PE_HIP(e, hipEventRecord(sl.done, e->s_compute));
+        return PE_OK;
+    };
+    if ((rc = enqueue())) {
+        const std::string why = e->err;
+        (void)hipStreamSynchronize(e->s_copy);
+        (void)hipStreamSynchronize(e->s_compute);
+        return fail(e, rc, "pe_update_async: %s (this update was not delivered; the engine's streams were drained)", why.c_str());
+    }
     sl.user_out = raw_out_host; sl.out_bytes = out_bytes; sl.busy = true;
     ++e->async_inflight;
     ++e->async_next;
@@ -1582,6 +1625,7 @@ int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, i
     if ((long long)n_updates * chunk >= (1ll << 30)) return fail(e, PE_ERR_INVALID, "n_updates * chunk_samples must stay below 2^30");
     if (e->prm.n_features + pending + frames > e->ring_slots) return fail(e, PE_ERR_INVALID, "reserved ring too small for %d updates of %d samples", n_updates, chunk);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    note_user_stream(e, stream);
     if (e->general) {
         // the general front end: every frame the call completes in ONE launch (mfcc_general_device.h: general_stream with n_updates),
         // then the batched network launch over 16-float rows, or one network launch per update over 32-float rows

@@ -917,13 +917,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BITS >= 10 ?
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     general_offline<R, BITS, BLUE>(a, reinterpret_cast<R*>(smem), blockIdx.x, gridDim.x, threadIdx.x);
 }
+// float32 butterflies without packed float32 here too (round 6, advisor r5): the general front end may run beside the
+// five-values bf16 network of ANOTHER engine on the same compute unit, the combination whose stock-shape twin went wrong
+// with packed instructions (see PE_NO_PK_F32 above); tests/test_gpu_parity.py soaks it
+template <class R, int BITS, bool BLUE = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BITS >= 10 ? 2 : 4))) PE_NO_PK_F32 void mfcc_general_stream_kernel_nopk(const GeneralStreamArgs<R> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = PE_GEN_TWO_WAVES ? blockIdx.x >> 1 : blockIdx.x;
+    if (s < a.geo.n_streams) general_stream<R, BITS, BLUE>(a, reinterpret_cast<R*>(smem), s, PE_GEN_TWO_WAVES ? blockIdx.x & 1 : 0, threadIdx.x, PE_GEN_TWO_WAVES ? 2 : 1);
+}
+template <class R, int BITS, bool BLUE = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BITS >= 10 ? 2 : 4))) PE_NO_PK_F32 void mfcc_general_offline_kernel_nopk(const GeneralOfflineArgs<R> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    general_offline<R, BITS, BLUE>(a, reinterpret_cast<R*>(smem), blockIdx.x, gridDim.x, threadIdx.x);
+}
 template <class R, int BITS, bool BLUE = false>
 static void launch_general_stream_b(const GeneralStreamArgs<R>& a, hipStream_t s) {
-    hipLaunchKernelGGL((mfcc_general_stream_kernel<R, BITS, BLUE>), dim3((PE_GEN_TWO_WAVES ? 2 : 1) * (unsigned)a.geo.n_streams), dim3(64), general_lds_bytes(sizeof(R), a.tab.n_fft, a.tab.n_filt, a.tab.n_rounds), s, a);
+    PE_LAUNCH_R(R, mfcc_general_stream_kernel, (BITS, BLUE), dim3((PE_GEN_TWO_WAVES ? 2 : 1) * (unsigned)a.geo.n_streams), dim3(64), general_lds_bytes(sizeof(R), a.tab.n_fft, a.tab.n_filt, a.tab.n_rounds), s, a);
 }
 template <class R, int BITS, bool BLUE = false>
 static void launch_general_offline_b(const GeneralOfflineArgs<R>& a, unsigned blocks, hipStream_t s) {
-    hipLaunchKernelGGL((mfcc_general_offline_kernel<R, BITS, BLUE>), dim3(blocks), dim3(64), general_lds_bytes(sizeof(R), a.tab.n_fft, a.tab.n_filt, a.tab.n_rounds), s, a);
+    PE_LAUNCH_R(R, mfcc_general_offline_kernel, (BITS, BLUE), dim3(blocks), dim3(64), general_lds_bytes(sizeof(R), a.tab.n_fft, a.tab.n_filt, a.tab.n_rounds), s, a);
 }
 template <class R>
 static hipError_t launch_general_stream_t(const GeneralStreamArgs<R>& a, hipStream_t s) {

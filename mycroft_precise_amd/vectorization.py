@@ -18,32 +18,51 @@ class UnverifiedFilterbank(UserWarning):
     be checked on (see ``mel_filterbank``)."""
 
 
-def mel_filterbank(sample_rate: int, num_filt: int, n_bins: int) -> np.ndarray:
+# How repeated mel grid points are treated when a filterbank is built and the caller does not say: 'push' (what sonopy
+# 0.1.2's ``correct_grid`` is written to do) or 'keep' (what it does if the correction never fires, see ``mel_filterbank``).
+# A maintainer who can run the real package sets this once (or passes ``duplicates=`` / ``mel_filters=`` explicitly).
+sonopy_duplicates = 'push'
+
+
+def mel_filterbank(sample_rate: int, num_filt: int, n_bins: int, duplicates: str = None) -> np.ndarray:
     """
     Triangular mel filters [num_filt, n_bins] (float64), the constant table handed to
     ``pe_create``.  Construction follows the filterbank of the vectorizer the reference calls
     (vectorization.py:36-39 -> sonopy 0.1.2): num_filt+2 points equally spaced on the mel scale
     m(f) = 1127 ln(1 + f/700) between 0 Hz and ``sample_rate`` Hz (sic), mapped to bins with
-    int(hz * n_bins / sample_rate), repeated points pushed forward, each filter rising over
-    [left, mid) and falling over [mid, right) with endpoint-free linspaces.
+    int(hz * n_bins / sample_rate), each filter rising over [left, mid) and falling over [mid, right)
+    with endpoint-free linspaces.
+
+    duplicates: what happens to REPEATED grid points (they exist only for non-stock settings, e.g. 40 filters at
+    n_fft = 512; the stock 20 filters have none, and both choices then build the same table):
+      'push' -- repeated points are pushed forward until the grid is strictly increasing: what sonopy's
+                ``correct_grid`` is written to do;
+      'keep' -- the grid is used as computed: what sonopy does if ``correct_grid`` receives an ndarray, for which its
+                ``[x[0] - 1] + x`` broadcasts and the correction never fires.  A filter whose three points coincide is
+                empty (its energy is 0, its log-mel value log(eps)).
+    None = the module default ``sonopy_duplicates`` ('push').  Which of the two the real package does could not be
+    checked offline (requirements.txt:35 pins sonopy==0.1.2; it is not installed here), hence the warning.
     """
+    mode = sonopy_duplicates if duplicates is None else duplicates
+    if mode not in ('push', 'keep'):
+        raise ValueError("duplicates must be 'push' or 'keep', got %r" % (mode,))
     top = 1127.0 * np.log(1.0 + float(sample_rate) / 700.0)
     mels = np.linspace(0.0, top, num_filt + 2, True)
     hz = 700.0 * (np.exp(mels / 1127.0) - 1.0)
     raw = (hz * n_bins / sample_rate).astype(int).tolist()
     if len(set(raw)) != len(raw):
-        # Colliding grid points (e.g. n_filt = 40 at n_fft = 512) are where the two recollections of sonopy 0.1.2
-        # differ: its ``correct_grid`` is written to push duplicates forward -- what is built below -- but it may
-        # receive an ndarray, for which ``[x[0] - 1] + x`` broadcasts and the correction never fires.  The stock
-        # 20 filters have no collision and are unaffected; anything else is served but flagged.
-        warnings.warn('mel grid of %d filters over %d bins has repeated points: the filterbank for this '
-                      'setting is UNVERIFIED against sonopy 0.1.2 (its duplicate handling could not be '
-                      'checked)' % (num_filt, n_bins), UnverifiedFilterbank, stacklevel=2)
-    pts, shift, last = [], 0, raw[0] - 1
-    for v in raw:
-        shift = max(0, shift + last + 1 - v)
-        pts.append(v + shift)
-        last = v
+        warnings.warn("mel grid of %d filters over %d bins has repeated points: built with duplicates=%r; the filterbank for "
+                      "this setting is UNVERIFIED against sonopy 0.1.2 (whether its correct_grid fires could not be checked) -- "
+                      "switch with mel_filterbank(..., duplicates='push'|'keep') or vectorization.sonopy_duplicates"
+                      % (num_filt, n_bins, mode), UnverifiedFilterbank, stacklevel=2)
+    if mode == 'keep':
+        pts = raw
+    else:
+        pts, shift, last = [], 0, raw[0] - 1
+        for v in raw:
+            shift = max(0, shift + last + 1 - v)
+            pts.append(v + shift)
+            last = v
     bank = np.zeros((num_filt, n_bins), dtype=np.float64)
     for f in range(num_filt):
         lo, mid, hi = pts[f], pts[f + 1], pts[f + 2]

@@ -17,7 +17,9 @@ Named quirks (all float64, numpy):
   Q3  power = (re^2 + im^2) / fft_size           (fft_size//2 + 1 = 257 bins)
   Q4  mel filterbank: num_filt+2 grid points equally spaced in mels between
       mel(0) and mel(sample_rate) (sample_rate, NOT Nyquist), mel(f)=1127 ln(1+f/700),
-      mapped to bin indices ``int(hz * n_bins / sample_rate)``, duplicates pushed forward;
+      mapped to bin indices ``int(hz * n_bins / sample_rate)``, duplicates pushed forward
+      (``DUPLICATES = 'push'``; ``'keep'`` = left alone, the other possible behaviour of the real
+      package's ``correct_grid`` -- the two differ only for non-stock settings with colliding points);
       filter i rises linearly 0->1 over [left, mid) and falls 1->0 over [mid, right)
       (``linspace(..., endpoint=False)``, so the peak 1.0 sits at bin ``mid`` and bin
       ``left`` has weight 0).
@@ -72,12 +74,22 @@ def _push_duplicates(idx):
     return out
 
 
-def filterbanks(sample_rate, num_filt, fft_len):
+# Q4 fork (see the header): 'push' = correct_grid fires and repeated grid points move forward, 'keep' = it never fires
+# (ndarray argument: ``[x[0] - 1] + x`` broadcasts).  Identical for the stock 20 filters.  Module default, like the product's
+# mycroft_precise_amd.vectorization.sonopy_duplicates.
+DUPLICATES = 'push'
+
+
+def filterbanks(sample_rate, num_filt, fft_len, duplicates=None):
     """Q4.  -> [num_filt, fft_len] float64 triangular filters."""
+    mode = DUPLICATES if duplicates is None else duplicates
+    if mode not in ('push', 'keep'):
+        raise ValueError("duplicates must be 'push' or 'keep'")
     grid_mels = np.linspace(_hz_to_mel(0.0), _hz_to_mel(float(sample_rate)), num_filt + 2, True)
     grid_hz = _mel_to_hz(grid_mels)
     grid_idx = [int(v) for v in (grid_hz * fft_len / sample_rate).astype(int)]
-    grid_idx = _push_duplicates(grid_idx)
+    if mode == 'push':
+        grid_idx = _push_duplicates(grid_idx)
     banks = np.zeros((num_filt, fft_len))
     for i in range(num_filt):
         left, mid, right = grid_idx[i], grid_idx[i + 1], grid_idx[i + 2]

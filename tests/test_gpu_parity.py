@@ -260,22 +260,36 @@ def test_update_many_equals_consecutive_updates(stock_weights, gru):
     eng.close()
 
 
-def test_update_many_large_launch_uses_one_wave_kernel(stock_weights):
+@pytest.mark.parametrize('form', [-1, 1])
+def test_update_many_large_launch_uses_one_wave_kernel(stock_weights, form):
     """More than 1536 (update, tile) pairs per call switch the network launch of pe_update_many to one wave
-    per pair (fewer are served by the four-wave kernel): both must reproduce consecutive updates bit for bit."""
+    per pair (fewer are served by the four-wave kernel): both must reproduce consecutive updates bit for bit.
+    form -1: an engine reserved for more (update, tile) windows per call than the machine has SIMDs (> 4 per compute unit)
+    picks the float32 network on the bf16 pipe (form 2) for ALL of its launches by itself (engine.hip: gru_args) -- the
+    unreserved engine beside it is put on the same form (forms agree to float32 summation order, shapes of a form bit for
+    bit); form 1: both forced onto the re-tiled f32-input MFMAs."""
     from mycroft_precise_amd._lib import HipEngine
     n, depth, chunk = 1616, 16, 1024                       # 101 tiles x 16 updates = 1616 workgroups
-    rng = np.random.default_rng(5)
     base = _stream_batch(['tone_noise'] * 16, 2 * depth, chunk)            # [32, 16, chunk]
     pcm = np.ascontiguousarray(np.tile(base, (1, n // 16, 1)))
     pcm[:, ::7] = np.roll(pcm[:, ::7], 3, axis=2)                       # not all tiles alike
     a = HipEngine(P.pr, stock_weights, n_streams=n)
     b = HipEngine(P.pr, stock_weights, n_streams=n)
+    assert a.gru_tiling() == 1
     b.reserve_updates(depth, chunk)
+    if form >= 0:
+        b.set_gru_tiling(form)
+    assert b.gru_tiling() == (2 if form < 0 else form)
+    a.set_gru_tiling(b.gru_tiling())
+    ref = ol.BatchedOracle(stock_weights, 32)
     for u in range(0, 2 * depth, depth):
         want = np.stack([a.update(pcm[u + i]) for i in range(depth)])
         got = b.update_many(pcm[u:u + depth])
         assert np.array_equal(got, want), u
+        orc = np.stack([ref.update_raw(pcm[u + i, :32]) for i in range(depth)])
+        assert np.abs(got[:, :32].astype(np.float64) - orc).max() <= GUARD_RAW
+    # single updates on the reserved engine: same form, same bits as the unreserved engine's
+    assert np.array_equal(b.update(pcm[0]), a.update(pcm[0]))
     for x, y in zip(a.stream_state(), b.stream_state()):
         assert np.array_equal(x, y)
     a.close(); b.close()
@@ -1582,6 +1596,10 @@ def test_full_batch_update_many_4096_streams_x8(stock_weights):
     a = HipEngine(P.pr, stock_weights, n_streams=B)
     b = HipEngine(P.pr, stock_weights, n_streams=B)
     b.reserve_updates(depth, 1024)
+    # 256 tiles x 8 updates = 2048 windows per call > 4 per compute unit: the reserved engine takes the float32 network on the
+    # bf16 pipe for all of its launches (round 6); bit identity holds within a form, so the single-update engine is put on it too
+    assert b.gru_tiling() == 2 and a.gru_tiling() == 1
+    a.set_gru_tiling(2)
     ref = ol.BatchedOracle(stock_weights, n_check)
     for r in range(5):
         pcm = np.ascontiguousarray(base[r * depth:(r + 1) * depth][:, owner])
@@ -1620,6 +1638,172 @@ def test_bench_two_ranks_on_one_gpu_shards_streams_correctly():
     solo = np.load(env1['PE_BENCH_DUMP'])
     assert solo.shape == (6, 512) and np.array_equal(both[:, 512:], solo)
     assert not np.array_equal(both[:, :512], both[:, 512:])          # the two shards really are different streams
+
+
+def test_bench_starts_its_own_ranks_and_delivers_per_step():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's N = 1 command): bench.py re-executes itself
+    under torch.distributed.run on 127.0.0.1 with a free port.  Both ranks on cuda:0 over gloo (PE_BENCH_SHARED_GPU=1: this
+    pool has one GPU per box).  One JSON line: two ranks seen, which collective carried the final gather, the headline's own
+    parity object, global stream order (rank 1's shard == a solo run over streams 512..1023), and the second region of
+    --gather-every-step delivering every step's probabilities unchanged."""
+    import json
+    dump = os.path.join(REPO, 'gpurun_out', 'bench2s_probs.npy')
+    env = dict(os.environ, PE_BENCH_SHARED_GPU='1', PE_BENCH_DUMP=dump, PYTHONPATH=REPO + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
+    common = ['--steps', '20', '--warmup', '5', '--streams', '512', '--no-cpu-baseline']
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--gather-every-step', 'rccl'] + common,
+                         env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['config']['global_streams'] == 1024
+    assert line['collective_backend'] == 'gloo' and line['collective'] in ('gather', 'all_gather')
+    assert line['streams_per_rank'] == [512, 512]
+    assert line['parity']['ok'] and line['parity']['streams_checked'] == 256 and line['parity']['steps_checked'] == 20
+    assert line['parity']['max_abs_err'] <= GUARD_RAW
+    ps = line['per_step_delivery']
+    assert ps['delivered_equals_device'] is True and ps['ms_per_step'] > 0
+    both = np.load(dump)
+    assert both.shape == (20, 1024)
+    env1 = dict(env, PE_BENCH_DUMP=os.path.join(REPO, 'gpurun_out', 'bench1s_probs.npy'), PE_BENCH_FIRST_STREAM='512')
+    one = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--gather-every-step', 'host'] + common, env=env1, cwd=REPO,
+                         capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    solo_line = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
+    assert solo_line['parity']['ok'] and solo_line['per_step_delivery']['delivered_equals_device'] is True
+    solo = np.load(env1['PE_BENCH_DUMP'])
+    assert solo.shape == (20, 512) and np.array_equal(both[:, 512:], solo)
+    # a rank count the node cannot serve is refused by name before anything is launched (no PE_BENCH_SHARED_GPU)
+    env2 = {k: v for k, v in env.items() if k != 'PE_BENCH_SHARED_GPU'}
+    import torch
+    bad = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', str(torch.cuda.device_count() + 1)] + common, env=env2, cwd=REPO,
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and 'exposes' in bad.stderr and 'Traceback' not in bad.stderr
+
+
+# ---- the float32 frame role beside the bf16 matrix pipe: a gate, not a tool (VERDICT r5 #6) ----------------------------------------
+def _position_soak(eng, n_updates, every=16):
+    """Every stream gets the SAME audio, so every position must produce the same bits: raw outputs compared with stream 0
+    on the device after every update, whole feature windows every `every` updates (a frame stays in the window for ~22)."""
+    import torch
+    dev = torch.device('cuda', 0)
+    B = eng.n_streams
+    n_res = 8
+    base = synth.batch_pcm(1, n_res)
+    pcm = torch.from_numpy(np.ascontiguousarray(base[:, 0, :])).to(dev)[:, None, :].expand(n_res, B, 1024).contiguous()
+    out = torch.zeros(B, device=dev)
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    bad_windows = 0
+    for u in range(n_updates):
+        eng.update_device(pcm[u % n_res].data_ptr(), 1024, out.data_ptr(), st)
+        bad += (out != out[0]).sum()
+        if (u + 1) % every == 0 or u == n_updates - 1:
+            torch.cuda.synchronize()
+            feats = eng.get_vectors()
+            bad_windows += int(np.any(feats != feats[0], axis=(1, 2)).sum())
+    torch.cuda.synchronize()
+    assert np.isfinite(out.cpu().numpy()).all() and float(out[0]) > 0.0
+    return int(bad.item()), bad_windows
+
+
+@pytest.mark.parametrize('streams,updates', [(8192, 100), (65536, 16)])
+def test_float32_frames_position_soak_beside_b20_network(stock_weights, streams, updates):
+    """Round 4 found ~0.7 % of the float32 frames of a fused launch wrong beside the five-values bf16 network role when the
+    frame role used packed float32 instructions; the cure (kernels.hip: PE_NO_PK_F32 on every kernel that hosts float32
+    butterflies) has no isolated cause, so a compiler upgrade could bring it back silently.  This is tools/gpu_frame_soak.py
+    as a gate: >= 2e6 float32 frames over the two sizes, five-values role on, bf16 rows, every position compared."""
+    from mycroft_precise_amd._lib import HipEngine
+    eng = HipEngine(P.pr, stock_weights, n_streams=streams, mfcc_precision='f32', gru_precision='bf16', ring_precision='bf16')
+    assert eng.gru_tiling() == 1                        # five gate values per lane (gru_b20_device.h)
+    bad_out, bad_win = _position_soak(eng, updates)
+    eng.close()
+    assert (bad_out, bad_win) == (0, 0), 'float32 frames disagree between positions: %d outputs, %d feature windows' % (bad_out, bad_win)
+
+
+def test_general_float32_front_end_soak_beside_b20_network():
+    """The general front end hosts float32 butterflies too (mfcc_general_stream_kernel<float>: compiled without packed float32
+    since round 6) and may feed the five-values bf16 network; a SECOND engine's fused float32 + b20 launches run on another
+    stream at the same time, so packed-free frame waves and b20 MFMA waves of different engines share compute units."""
+    import threading
+    import torch
+    from mycroft_precise_amd._lib import HipEngine
+    kw = dict(n_fft=256, n_filt=20, n_mfcc=13)
+    hpr = P.pr.copy()
+    hpr.__dict__.update(kw)
+    w = synth.make_weights(n_in=13, units=(20,), seed=7)
+    gen = HipEngine(hpr, w, n_streams=8192, mfcc_precision='f32', gru_precision='bf16', ring_precision='bf16')
+    assert gen.gru_tiling() == 1
+    other = HipEngine(P.pr, w, n_streams=8192, mfcc_precision='f32', gru_precision='bf16', ring_precision='bf16')
+    dev = torch.device('cuda', 0)
+    side = torch.cuda.Stream(device=dev)
+    opcm = torch.from_numpy(synth.batch_pcm(1, 1)[0, 0]).to(dev)[None, :].expand(8192, 1024).contiguous()
+    oout = torch.zeros(8192, device=dev)
+    stop = threading.Event()
+    launched = [0]
+
+    def background():
+        while not stop.is_set():
+            for _ in range(20):
+                other.update_device(opcm.data_ptr(), 1024, oout.data_ptr(), side.cuda_stream)
+            launched[0] += 20
+            side.synchronize()
+
+    th = threading.Thread(target=background)
+    th.start()
+    try:
+        bad_out, bad_win = _position_soak(gen, 120)
+    finally:
+        stop.set()
+        th.join()
+    side.synchronize()
+    same_other = bool((oout == oout[0]).all().item())
+    gen.close(); other.close()
+    assert launched[0] >= 20 and same_other
+    assert (bad_out, bad_win) == (0, 0), 'general float32 frames disagree between positions: %d outputs, %d windows' % (bad_out, bad_win)
+
+
+@pytest.mark.parametrize('dup', ['push', 'keep'])
+def test_colliding_mel_grid_either_duplicate_rule(dup):
+    """40 filters over the 257 bins of n_fft = 512: the mel grid starts 0, 0, 1, 2 ... -- the one setting family where the two
+    possible behaviours of sonopy 0.1.2's correct_grid differ.  `mel_filterbank(..., duplicates=)` builds either table; the
+    kernels serve both, offline and streaming, against the oracle switched the same way (sonopy_restated.DUPLICATES)."""
+    import warnings
+    from mycroft_precise_amd import vectorization as V
+    from mycroft_precise_amd._lib import HipEngine
+    from oracle import sonopy_restated as sr
+    kw = dict(n_filt=40)
+    hpr = P.pr.copy()
+    hpr.__dict__.update(kw)
+    opr = ol.Params(**kw)
+    w = synth.make_weights(seed=11)
+    n, n_up = 19, 40
+    pcm = _stream_batch(['tone_noise'] * (n - 3) + ['zeros', 'square', 'quiet'], n_up)
+    prev_o, prev_p = sr.DUPLICATES, V.sonopy_duplicates
+    try:
+        sr.DUPLICATES = dup
+        V.sonopy_duplicates = dup
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', V.UnverifiedFilterbank)
+            bank = V.mel_filterbank(16000, 40, 257)
+            assert np.array_equal(bank, sr.filterbanks(16000, 40, 257))
+            eng = HipEngine(hpr, w, n_streams=n)                 # (the module default reaches pe_create through HipEngine)
+            explicit = HipEngine(hpr, w, n_streams=n, mel_filters=V.mel_filterbank(16000, 40, 257, duplicates=dup))
+        audio = synth.stream_pcm(2, 20000).astype(np.float64) / 32768.0
+        want = sr.mfcc_spec(audio, 16000, (opr.window_samples, opr.hop_samples), 512, 40, 13)
+        assert np.abs(eng.vectorize_raw(audio) - want).max() <= 1e-9
+        ref = ol.BatchedOracle(w, n, opr)
+        for u in range(n_up):
+            got = eng.update(pcm[u])
+            assert np.array_equal(got, explicit.update(pcm[u]))
+            assert np.abs(got.astype(np.float64) - ref.update_raw(pcm[u])).max() <= GUARD_RAW, u
+        assert np.abs(eng.get_vectors().astype(np.float64) - ref.mfccs).max() <= TOL_FEAT32
+        eng.close(); explicit.close()
+    finally:
+        sr.DUPLICATES, V.sonopy_duplicates = prev_o, prev_p
 
 
 def test_random_chunk_sizes_streams_and_call_shapes(stock_weights):

@@ -116,6 +116,25 @@ def test_mel_filterbank_table_equals_oracle():
         assert np.array_equal(V.mel_filterbank(16000, 20, 257), so.filterbanks(16000, 20, 257))
     with pytest.warns(V.UnverifiedFilterbank):               # 40 filters over 257 bins: low grid points collide
         assert np.array_equal(V.mel_filterbank(16000, 40, 257), so.filterbanks(16000, 40, 257))
+    # the two candidate behaviours of sonopy's correct_grid as a switch: equal to the oracle's in either setting, different
+    # from each other where points collide, identical on the stock grid; the module default is what an unqualified call takes
+    with pytest.warns(V.UnverifiedFilterbank, match="duplicates='keep'"):
+        keep = V.mel_filterbank(16000, 40, 257, duplicates='keep')
+    with pytest.warns(V.UnverifiedFilterbank, match="duplicates='push'"):
+        push = V.mel_filterbank(16000, 40, 257, duplicates='push')
+    assert np.array_equal(keep, so.filterbanks(16000, 40, 257, duplicates='keep'))
+    assert np.array_equal(push, so.filterbanks(16000, 40, 257, duplicates='push'))
+    assert not np.array_equal(keep, push)                   # grid 0, 0, 1, 2, 4 ... : filter 0 has no rising edge under 'keep'
+    assert np.array_equal(V.mel_filterbank(16000, 20, 257, duplicates='keep'), V.mel_filterbank(16000, 20, 257, duplicates='push'))
+    prev = V.sonopy_duplicates
+    try:
+        V.sonopy_duplicates = 'keep'
+        with pytest.warns(V.UnverifiedFilterbank):
+            assert np.array_equal(V.mel_filterbank(16000, 40, 257), keep)
+    finally:
+        V.sonopy_duplicates = prev
+    with pytest.raises(ValueError):
+        V.mel_filterbank(16000, 20, 257, duplicates='drop')
 
 
 def test_vectorize_raw_rejects_empty_audio_and_serves_every_vectorizer():
