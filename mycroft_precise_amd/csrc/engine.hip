@@ -70,10 +70,6 @@ struct pe_engine {
     uint32_t* ke_hist = nullptr;
     // constant tables of the MFCC frame kernel, laid out as they sit in LDS (mfcc_wave_tables.h)
     unsigned char* table_blob = nullptr;
-#ifdef PE_TUNING
-    void* quad_tab = nullptr;       // mfcc_quad_device.h: W256^(k1 j) [16][16], W512^p [128] as complex R
-    bool quad = false;              // four frames per wave for single updates of stock-shape engines (round-5 experiment: PE_QUAD=1)
-#endif
     pe_wave::Layout table_layout{};
     // packed network
     float* wxd = nullptr;
@@ -197,26 +193,6 @@ size_t ring_floats(const pe_engine* e) {
 }
 
 
-#ifdef PE_TUNING
-template <class R>
-int build_quad_tables(pe_engine* e) {
-    const long double PI = 3.14159265358979323846264338327950288L;
-    std::vector<R> tw((size_t)(16 * 16 + 128) * 2);
-    for (int k1 = 0; k1 < 16; ++k1)
-        for (int j = 0; j < 16; ++j) {
-            tw[(size_t)(k1 * 16 + j) * 2] = (R)cosl(-2.0L * PI * (k1 * j) / 256.0L);
-            tw[(size_t)(k1 * 16 + j) * 2 + 1] = (R)sinl(-2.0L * PI * (k1 * j) / 256.0L);
-        }
-    for (int p = 0; p < 128; ++p) {
-        tw[(size_t)(256 + p) * 2] = (R)cosl(-2.0L * PI * p / 512.0L);
-        tw[(size_t)(256 + p) * 2 + 1] = (R)sinl(-2.0L * PI * p / 512.0L);
-    }
-    R* d = nullptr;
-    int rc = dev_upload(e, &d, tw);
-    e->quad_tab = d;
-    return rc;
-}
-#endif
 
 template <class R>
 int build_tables(pe_engine* e, const double* mel_filters) {
@@ -775,12 +751,6 @@ int launch_mfcc(pe_engine* e, const int16_t* pcm_dev, int chunk, hipStream_t s) 
     if (e->general) {
         if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_general_stream_f64(general_args<double>(e, pcm_dev, chunk), s));
         else PE_HIP(e, launch_general_stream_f32(general_args<float>(e, pcm_dev, chunk), s));
-#ifdef PE_TUNING
-    } else if (e->quad && e->table_layout.mel_pad == 10 && e->prm.n_filt <= 31 && !e->proj_on && chunk >= frame_len_of(e->prm) && ((chunk | e->prm.hop_samples | frame_len_of(e->prm)) & 1) == 0 &&
-               (reinterpret_cast<uintptr_t>(pcm_dev) & 3u) == 0) {
-        if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_mfcc_quad_f64(mfcc_args<double>(e, pcm_dev, chunk), tables<double>(e), e->quad_tab, e->n_cus, s));
-        else PE_HIP(e, launch_mfcc_quad_f32(mfcc_args<float>(e, pcm_dev, chunk), tables<float>(e), e->quad_tab, e->n_cus, s));
-#endif
     } else if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_mfcc_f64(mfcc_args<double>(e, pcm_dev, chunk), tables<double>(e), e->n_cus, s));
     else PE_HIP(e, launch_mfcc_f32(mfcc_args<float>(e, pcm_dev, chunk), tables<float>(e), e->n_cus, s));
     flip_state(e);
@@ -1151,10 +1121,6 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
         if (e->general) rc = (p->mfcc_precision == 0) ? build_general_tables<double>(e, mel_filters) : build_general_tables<float>(e, mel_filters);
         else rc = (p->mfcc_precision == 0) ? build_tables<double>(e, mel_filters) : build_tables<float>(e, mel_filters);
         if (rc) break;
-#ifdef PE_TUNING
-        e->quad = !e->general && tuning_env_int("PE_QUAD", 0) != 0;
-        if (e->quad && (rc = (p->mfcc_precision == 0) ? build_quad_tables<double>(e) : build_quad_tables<float>(e))) break;
-#endif
         if (e->proj_on && (rc = dev_alloc(e, &e->proj_ring, (size_t)e->n_tiles * e->ring_slots * kTileStreams * kProjRow))) break;
         for (auto& ev : e->ev)
             if (hipEventCreate(&ev) != hipSuccess) { rc = fail(e, PE_ERR_HIP, "hipEventCreate failed"); break; }

@@ -5,15 +5,8 @@
 #include <type_traits>
 #include "mfcc_device.h"
 #include "mfcc_wave_device.h"
-#ifdef PE_TUNING
-#include "../../tools/micro/mfcc_quad_device.h"       // (round 5 experiment: four frames per wave)
-#endif
 #include "gru_device.h"
 #include "gru_cw_device.h"
-#ifdef PE_TUNING      // measured and rejected: tuning builds only (tools/build_variants.sh)
-#include "../../tools/micro/gru_dpp_device.h"
-#include "../../tools/micro/gru_pair_device.h"
-#endif
 #include "gru_bf16_device.h"
 #include "gru_b20_device.h"
 #include "gru_x3_device.h"
@@ -81,53 +74,6 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
     mfcc_kernel_body<R, SH, SINGLE>(a, t, n_frame_blocks);
 }
 
-#ifdef PE_TUNING
-// ---- MFCC, four frames per wave (mfcc_quad_device.h): the frame role of one update with dword sample pairs ----------------------------
-// ONE workgroup per CU, as many waves as the register file and the LDS take (float64: 12 waves of <= 168 registers and 11 KB of
-// scratch; float32: 16 waves of <= 128 registers); LDS: [scratch of wave 0 .. W-1][table image of the one-frame kernel from its log
-// table on][quad twiddles].  The frame waves keep the books of their own streams between passes (mfcc_quad_tasks): as trailing
-// workgroups of this launch the bookkeeping role would reserve its 60-150 KB per workgroup and run behind the frames, not beside.
-#ifndef PE_QUAD_WAVES
-template <class R> constexpr int kQuadWaves = sizeof(R) == 8 ? 12 : 16;
-#else
-template <class R> constexpr int kQuadWaves = PE_QUAD_WAVES;
-#endif
-template <class R>
-__device__ __forceinline__ void mfcc_quad_body(const MfccStreamArgs<R>& a, const WaveTables<R>& t, const pe_wave::cx<R>* qtab, const int n_frame_blocks) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int W = kQuadWaves<R>;
-    PE_T(0);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int skip = t.L.logtab;
-    const int n16 = (t.L.total - skip) >> 4;
-    unsigned char* const image = smem + W * kQuadScratchBytes<R>;
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(t.blob) + skip);
-        uint4* dst = reinterpret_cast<uint4*>(image);
-        for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
-        const uint4* qs = reinterpret_cast<const uint4*>(qtab);
-        uint4* qd = reinterpret_cast<uint4*>(image + (size_t)n16 * 16);
-        constexpr int nq = kQuadTwElems * 2 * (int)sizeof(R) / 16;
-        for (int i = threadIdx.x; i < nq; i += blockDim.x) qd[i] = qs[i];
-    }
-    __syncthreads();
-    const pe_wave::Tab<R> tab = pe_wave::bind<R>(image, t.L, skip);
-    const pe_wave::cx<R>* qtw = reinterpret_cast<const pe_wave::cx<R>*>(image + (size_t)n16 * 16);
-    PE_T(1);
-    mfcc_quad_tasks<R, ShapeStock>(a, tab, qtw, qtw + 256, smem + (size_t)wave * kQuadScratchBytes<R>, (int)blockIdx.x * W, n_frame_blocks * W);
-    PE_T(15);
-}
-template <class R>
-__global__ __launch_bounds__(64 * kQuadWaves<R>) void mfcc_quad_kernel(const MfccStreamArgs<R> a, const WaveTables<R> t, const pe_wave::cx<R>* qtab, const int n_frame_blocks) {
-    mfcc_quad_body<R>(a, t, qtab, n_frame_blocks);
-}
-template <class R>
-__global__ __launch_bounds__(64 * kQuadWaves<R>) PE_NO_PK_F32 void mfcc_quad_kernel_nopk(const MfccStreamArgs<R> a, const WaveTables<R> t, const pe_wave::cx<R>* qtab, const int n_frame_blocks) {
-    mfcc_quad_body<R>(a, t, qtab, n_frame_blocks);
-}
-template <class R>
-static size_t quad_lds(const WaveTables<R>& t) { return (size_t)kQuadWaves<R> * kQuadScratchBytes<R> + (size_t)(t.L.total - t.L.logtab) + (size_t)kQuadTwElems * 2 * sizeof(R); }
-#endif  // PE_TUNING
 
 // network for a whole batch of updates: workgroup (one wave) b serves update b / n_tiles, tile b % n_tiles
 template <int R, bool PROJ>
@@ -368,41 +314,6 @@ __global__ __launch_bounds__(256) void gru_mw_kernel(const GruArgs a) {
     gru_tile_mw_any<R, PROJ, KX>(a, blockIdx.x, wave, threadIdx.x & 63, S);
 }
 
-#ifdef PE_TUNING
-// ---- GRU: sixteen lanes per stream, no hand-offs (few tiles: the window's dependent chain is what counts) ----------
-__global__ __launch_bounds__(256) void gru_dpp_kernel(const GruArgs a) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    gru_tile_dpp(a, blockIdx.x, wave, threadIdx.x & 63);
-}
-
-// the same for a whole batch of updates: workgroup b serves update b / n_tiles, tile b % n_tiles
-__global__ __launch_bounds__(256) void gru_many_dpp_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
-    const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
-    GruArgs b = a;
-    b.st_ke = a.st_ke + (size_t)u * n_padded;
-    b.out = a.out + (size_t)u * a.n_streams;
-    b.predict_ke = 0;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    gru_tile_dpp(b, tile, wave, threadIdx.x & 63);
-}
-
-// the fused update with that network role (its ~150 registers per lane leave three waves per SIMD)
-template <class R, class SH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void fused_update_dpp_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
-                                                               const int n_gru_blocks, const int n_frame_blocks, const int n_tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x;
-    if (b < n_gru_blocks) {
-        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        gru_tile_dpp(g, b, wave, threadIdx.x & 63);
-    } else if (b < n_gru_blocks + n_frame_blocks) {
-        mfcc_frame_tasks<R, SH, true>(m, t, smem, (b - n_gru_blocks) * kFrameWaves, n_frame_blocks * kFrameWaves);
-    } else {
-        mfcc_book_tile<R>(m, b - n_gru_blocks - n_frame_blocks);
-    }
-}
-
-#endif      // PE_TUNING
 
 // ---- fused update: GRU role || MFCC frame role || bookkeeping role in ONE launch -------------------------------
 // Workgroups [0, n_gru_blocks) run the network on the feature windows as they will stand after this update (they
@@ -467,71 +378,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
     fused_update_body<R, SH, RG, MW, PROJ, CW>(m, t, g, n_gru_blocks, n_frame_blocks, n_tiles, frames_first);
 }
 
-#ifdef PE_TUNING
-// ---- GRU, stock width, classic tiling: two tiles per wave (gru_pair_device.h) -------------------------------------
-// four waves per workgroup = eight tiles; the accumulator inits (biases) come from 256 bytes of LDS (no register cap
-// here: the input kernel stays in registers, three waves = six tile chains per SIMD)
-__global__ __launch_bounds__(256) void gru_pair_kernel(const GruArgs a, const int n_tiles) {
-    touch_kernel_arguments<(int)sizeof(GruArgs) + 4>();
-    __shared__ __attribute__((aligned(16))) float B[kPairBiasFloats];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (wave == 0) pair_bias_to_lds(a, B, lane);
-    __syncthreads();
-    const int t0 = (blockIdx.x * 4 + wave) * 2;
-    if (t0 < n_tiles) gru_tile_pair<true>(a, t0, t0 + 1, n_tiles, lane, B);
-}
-
-// ---- fused update, throughput regime: MIXED workgroups ---------------------------------------------------------------
-// Eight waves per workgroup, two per SIMD: waves 0..3 run the MFCC frame role, waves 4..7 the network role with two tiles
-// per wave -- so EVERY SIMD holds, by construction and whatever the dispatcher does, one frame wave and one network wave
-// of each resident workgroup (two workgroups per compute unit under the 128-register budget: 2 + 2 per SIMD, the four
-// tile chains a SIMD used to need four network waves for).  The roles use different pipes (VALU + LDS vs MFMA) and now
-// share every SIMD for the whole launch instead of taking turns at its four wave slots.
-// The workgroups are persistent: frame waves own a contiguous run of (stream, row parity) slots (mfcc_frame_tasks),
-// network waves walk the tile pairs with the stride of the launch.  The last workgroups keep the books, two tiles each.
-constexpr int kMixWaves = 8;
-__device__ __forceinline__ void set_wave_prio(const int p) {       // (s_setprio takes an immediate)
-    if (p == 1) __builtin_amdgcn_s_setprio(1);
-    else if (p == 2) __builtin_amdgcn_s_setprio(2);
-    else if (p == 3) __builtin_amdgcn_s_setprio(3);
-}
-template <class R, class SH>
-__global__ __launch_bounds__(64 * kMixWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_update_mix_kernel(const MfccStreamArgs<R> m, const WaveTables<R> t, const GruArgs g,
-                                                                const int n_mix, const int n_tiles, const int bias_off, const int flags) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    touch_kernel_arguments<(int)(sizeof(MfccStreamArgs<R>) + sizeof(WaveTables<R>) + sizeof(GruArgs) + 16)>();
-    const int b = blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (b < n_mix) {
-        float* const B = reinterpret_cast<float*>(smem + bias_off);
-        if (wave < kFrameWaves) {
-            if (flags & 1) {            // (tuning: launch without the frame role -- the barrier of the table commit still has to be met)
-                const TabRegs tr = wave_tables_issue<R>(t);
-                wave_tables_commit<R>(smem, t, tr);
-                return;
-            }
-            set_wave_prio((flags >> 6) & 3);
-            mfcc_frame_tasks<R, SH, true, true>(m, t, smem, b * kFrameWaves, n_mix * kFrameWaves);
-        } else {
-            // the network waves take part in the workgroup's one barrier (the table image's commit: all eight waves carry
-            // pieces of it) and publish the accumulator inits before it
-            const TabRegs tr = wave_tables_issue<R>(t);
-            if (wave == kFrameWaves) pair_bias_to_lds(g, B, lane);
-            if (wave == kFrameWaves + 1) pair_wx_to_lds(g, B + kPairBiasFloats, lane);
-            wave_tables_commit<R>(smem, t, tr);
-            if (flags & 2) return;      // (tuning: launch without the network role)
-            set_wave_prio((flags >> 4) & 3);
-            const int n_pairs = (n_tiles + 1) >> 1;
-            for (int pi = b * 4 + (wave - kFrameWaves); pi < n_pairs; pi += n_mix * 4) gru_tile_pair<true, true>(g, 2 * pi, 2 * pi + 1, n_tiles, lane, B);
-        }
-    } else {
-        if (flags & 1) return;
-        const int tile = (b - n_mix) * 2 + (wave >> 2);
-        if (tile < n_tiles) mfcc_book_tile<R>(m, tile, wave & 3);
-    }
-}
-
-#endif      // PE_TUNING
 
 // Workgroups of the frame role: one wave per task while that fits the machine (4 workgroups of 4 waves per compute
 // unit are resident: LDS and a 128-register budget), more tasks per wave beyond.
@@ -594,30 +440,6 @@ static hipError_t launch_mfcc(const MfccStreamArgs<R>& a, const WaveTables<R>& t
     return hipGetLastError();
 }
 // four frames per wave: the frame role of ONE update of a stock-shape engine whose geometry allows dword sample pairs
-#ifdef PE_TUNING
-template <class R>
-static hipError_t launch_mfcc_quad(const MfccStreamArgs<R>& a, const WaveTables<R>& t, const void* qtab, int n_cus, hipStream_t s) {
-    constexpr int W = kQuadWaves<R>;
-    const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
-    if (!blob_matches_shape(t) || t.L.mel_pad != ShapeStock::MEL) return hipErrorInvalidValue;
-    static const int per_cu = env_int("PE_QUAD_WG_PER_CU", 1);
-    const long long need = ((long long)a.geo.n_streams + 4 * W - 1) / (4 * W);        // at least four streams per wave
-    const long long cap = (long long)n_cus * per_cu;
-    const int fb = (int)(need < cap ? (need < 1 ? 1 : need) : cap);
-    const pe_wave::cx<R>* q = reinterpret_cast<const pe_wave::cx<R>*>(qtab);
-    static bool once = false;
-    if (!once) {
-        once = true;
-        if constexpr (std::is_same<R, float>::value) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfcc_quad_kernel_nopk<R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfcc_quad_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-    if constexpr (std::is_same<R, float>::value) hipLaunchKernelGGL((mfcc_quad_kernel_nopk<R>), dim3(fb), dim3(64 * W), quad_lds(t), s, a, t, q, fb);
-    else hipLaunchKernelGGL((mfcc_quad_kernel<R>), dim3(fb), dim3(64 * W), quad_lds(t), s, a, t, q, fb);
-    return hipGetLastError();
-}
-hipError_t launch_mfcc_quad_f64(const MfccStreamArgs<double>& a, const WaveTables<double>& t, const void* qtab, int n_cus, hipStream_t s) { return launch_mfcc_quad<double>(a, t, qtab, n_cus, s); }
-hipError_t launch_mfcc_quad_f32(const MfccStreamArgs<float>& a, const WaveTables<float>& t, const void* qtab, int n_cus, hipStream_t s) { return launch_mfcc_quad<float>(a, t, qtab, n_cus, s); }
-#endif
 hipError_t launch_mfcc_f64(const MfccStreamArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s) { return launch_mfcc<double>(a, t, n_cus, s); }
 hipError_t launch_mfcc_f32(const MfccStreamArgs<float>& a, const WaveTables<float>& t, int n_cus, hipStream_t s) { return launch_mfcc<float>(a, t, n_cus, s); }
 
@@ -652,12 +474,6 @@ static hipError_t launch_r(const GruArgs& a, int mode, hipStream_t s) {
         return hipGetLastError();
     }
     if constexpr (R == 5) {
-#ifdef PE_TUNING
-        if (a.pair && mode == kRing && !a.cw && !a.proj_ring && !a.use_delta && a.waves_per_tile == 1) {
-            hipLaunchKernelGGL(gru_pair_kernel, dim3((tiles + 7) / 8), dim3(256), 0, s, a, tiles);
-            return hipGetLastError();
-        }
-#endif
         if (a.cw) {
             if (mode == kRing && a.waves_per_tile == 4 && cw_four_waves_ok(a)) hipLaunchKernelGGL(gru_cw_kernel, dim3(tiles), dim3(256), kCwLdsBytes, s, a);
             else if (a.use_delta) {
@@ -670,12 +486,6 @@ static hipError_t launch_r(const GruArgs& a, int mode, hipStream_t s) {
             else hipLaunchKernelGGL((gru_v_kernel<kFeats, false>), dim3(tiles), dim3(64), 0, s, a);
             return hipGetLastError();
         }
-#ifdef PE_TUNING
-        if (mode == kRing && a.proj_ring && a.waves_per_tile == 16) {
-            hipLaunchKernelGGL(gru_dpp_kernel, dim3(tiles), dim3(256), 0, s, a);
-            return hipGetLastError();
-        }
-#endif
         if (mode == kRing && a.proj_ring) {
             if (a.waves_per_tile == 4) hipLaunchKernelGGL((gru_mw_kernel<R, true>), dim3(tiles), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((gru_small_kernel<R, kRing, true>), dim3(tiles), dim3(64), 0, s, a);
@@ -741,12 +551,6 @@ static hipError_t launch_many_r(const GruArgs& a, int n_updates, int n_padded, h
             else hipLaunchKernelGGL(gru_many_v_kernel<false>, dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
             return hipGetLastError();
         }
-#ifdef PE_TUNING
-        if (a.proj_ring && a.waves_per_tile == 16) {       // the engine's single updates use the DPP kernel: so does the batch
-            hipLaunchKernelGGL(gru_many_dpp_kernel, dim3(tiles * n_updates), dim3(256), 0, s, a, tiles, n_padded);
-            return hipGetLastError();
-        }
-#endif
         if (a.proj_ring) {
             if (mw) hipLaunchKernelGGL((gru_many_mw_kernel<R, true>), dim3(tiles * n_updates), dim3(256), 0, s, a, tiles, n_padded);
             else hipLaunchKernelGGL((gru_many_kernel<R, true>), dim3(tiles * n_updates), dim3(64), 0, s, a, tiles, n_padded);
@@ -811,24 +615,6 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
     if (skip == 3) book = 0;
     const dim3 grid(gru_blocks + fb_ + book);
     if constexpr (RG == 5) {
-#ifdef PE_TUNING
-        if (g.pair && !g.cw && !g.proj_ring && !g.use_delta && g.waves_per_tile == 1) {
-            // throughput regime: mixed workgroups (frame waves + two-tiles-per-wave network waves on every SIMD), two resident
-            // per compute unit; persistent -- fewer only when there are not enough tile pairs to give every network wave one
-            static const int per_cu_env = env_int("PE_MIX_WG_PER_CU", 0);
-            const int n_pairs = (tiles + 1) / 2;
-            const int cap = n_cus * (per_cu_env ? per_cu_env : 2);
-            const int need = (n_pairs + 3) / 4;
-            const int n_mix = need < cap ? need : cap;
-            const int bias_off = (int)((lds + 15) & ~(size_t)15);
-            // wave priorities of the two roles (bits 4-5: network, 6-7: frames)
-            static const int prio_net = env_int("PE_MIX_PRIO_NET", 3), prio_frame = env_int("PE_MIX_PRIO_FRAME", 0);
-            const int flags = (skip == 1 ? 1 : 0) | (skip == 2 ? 2 : 0) | ((prio_net & 3) << 4) | ((prio_frame & 3) << 6);
-            hipLaunchKernelGGL((fused_update_mix_kernel<R, ShapeStock>), dim3(n_mix + (tiles + 1) / 2), dim3(64 * kMixWaves), (size_t)bias_off + kPairLdsFloats * sizeof(float), s,
-                               m, t, g, n_mix, tiles, bias_off, flags);
-            return hipGetLastError();
-        }
-#endif
         if (g.cw) {                          // stock width, re-tiled: the four-wave shape wants its LDS (mailboxes + staged ring)
             if (g.waves_per_tile == 4 && cw_four_waves_ok(g)) {
                 PE_LAUNCH_R(R, fused_update_kernel, (ShapeStock, RG, true, false, true), grid, dim3(256), lds > kCwLdsBytes ? lds : kCwLdsBytes, s, m, t, g, gru_blocks, fb_, tiles, frames_first);
@@ -840,12 +626,6 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
         }
     }
     if constexpr (RG == 5) {                 // (projection rows exist for the stock width only)
-#ifdef PE_TUNING
-        if (g.proj_ring && g.waves_per_tile == 16) {
-            hipLaunchKernelGGL((fused_update_dpp_kernel<R, ShapeStock>), dim3(tiles + fb_ + book), dim3(256), lds, s, m, t, g, tiles, fb_, tiles);
-            return hipGetLastError();
-        }
-#endif
         if (g.proj_ring) {
             if (g.waves_per_tile == 4) PE_LAUNCH_R(R, fused_update_kernel, (ShapeStock, RG, true, true), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb_, tiles, frames_first);
             else PE_LAUNCH_R(R, fused_update_kernel, (ShapeStock, RG, false, true), grid, dim3(256), lds, s, m, t, g, gru_blocks, fb_, tiles, frames_first);

@@ -8,7 +8,8 @@
 //     calls are carried in HBM ("carry", int16), and the 36 % of every window that numpy's rfft crop makes dead is
 //     never read;
 //   * per stream: q = samples held toward the next frame to compute (negative inside the dead zone between
-//     windows), kc = frames computed, ke = frames emitted (visible to the network); counters wrap mod 2^32.
+//     windows), kc = frames computed, ke = frames emitted (visible to the network); counters wrap mod 2^32 --
+//     one 16-byte record per stream and side (pe_common.h: StreamRec).
 #pragma once
 #include "pe_common.h"
 
@@ -53,11 +54,12 @@ __device__ __forceinline__ void group_sync() {
     asm volatile("" ::: "memory");
 }
 
-// One 16-lane group per stream (one workgroup of 256 threads = one tile of 16 streams): after a call that appended
-// n_updates chunks of C samples, move the leftover samples to carry_next (the frame tasks of the same launch
-// still read the old carry: the two buffers must differ), advance the counters update by update exactly as
-// single updates would, and record the emitted-frame counter after EVERY update (ke_hist, when given) -- that is
-// what tells a batched network launch which window each update saw.
+// One 16-lane group per stream (one workgroup of 256 threads = one tile of 16 streams of this launch): after a call that
+// appended n_updates chunks of C samples, move the leftover samples to the stream's OTHER side (the frame tasks of the
+// same launch still read the current one), advance the counters update by update exactly as single updates would, publish
+// them as the other side's record (stamped with this call's number: current from the next call on), and record the
+// emitted-frame counter after EVERY update (ke_hist, when given) -- that is what tells a batched network launch which window
+// each update saw.  Streams that are not in this launch (pe_update_subset) are not touched.
 template <class R>
 __device__ __forceinline__ void mfcc_book_tile(const MfccStreamArgs<R>& a, const int tile, const int wave_in_tile = -1) {
     const StreamGeom& geo = a.geo;
@@ -65,19 +67,24 @@ __device__ __forceinline__ void mfcc_book_tile(const MfccStreamArgs<R>& a, const
     const int lane = threadIdx.x & 63, wave = wave_in_tile >= 0 ? wave_in_tile : (int)(threadIdx.x >> 6);
     const int grp = lane >> 4, r = lane & 15;
     const int j = wave * 4 + grp;
-    const long long s = (long long)tile * kTileStreams + j;
+    const long long s = (long long)tile * kTileStreams + j;       // position in this launch: PCM row
     if (s >= geo.n_streams) return;
+    const long long sid = a.ids ? (long long)a.ids[s] : s;        // the stream: state, leftover PCM
     const int C = a.chunk, hop = geo.hop, flen = geo.frame_len, U = a.n_updates;
     const size_t update_stride = (size_t)geo.n_streams * C;
-    const int q = a.st_q[s];
-    const uint32_t kc = a.st_kc[s];
+    const RecPair both = rec_request(a.st.rec, a.st.n_padded, sid);
+    const int side = rec_side(both, a.st.call);
+    const StreamRec now = rec_pick(both, side);
+    const int q = now.q;
+    const uint32_t kc = now.kc;
     const int avail = q + U * C;
     // (divisions by the hop and the chunk length through the host-made reciprocals: a runtime integer division is ~40
     //  instructions, and this role had six of them per stream)
     auto by_hop = [&](int x) -> int { return (int)a.div_hop.div((uint32_t)x); };
     auto by_chunk = [&](int x) -> int { return (int)a.div_chunk.div((uint32_t)x); };
     const int nnew = avail >= flen ? 1 + by_hop(avail - flen) : 0;
-    const int16_t* car = a.carry + (size_t)s * kCarryCap;
+    const size_t carry_side = (size_t)a.st.n_padded * kCarryCap;
+    const int16_t* car = a.st.carry + (size_t)side * carry_side + (size_t)sid * kCarryCap;
     const int16_t* base = a.pcm + (size_t)s * C;
     // virtual sample v (0 <= v < avail): carry below q, chunk (v - q) / C above
     auto vsample = [&](int v) -> int {
@@ -117,7 +124,7 @@ __device__ __forceinline__ void mfcc_book_tile(const MfccStreamArgs<R>& a, const
         }
     };
     const int qn = avail - nnew * hop;
-    int16_t* const carw = a.carry_next + (size_t)s * kCarryCap;
+    int16_t* const carw = a.st.carry + (size_t)(side ^ 1) * carry_side + (size_t)sid * kCarryCap;
     auto put = [&](const int c0, const int (&left)[8]) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -171,7 +178,7 @@ __device__ __forceinline__ void mfcc_book_tile(const MfccStreamArgs<R>& a, const
     }
     if (r == 0) {
         int qu = q;
-        uint32_t kcu = kc, ke = a.st_ke[s];
+        uint32_t kcu = kc, ke = now.ke;
         for (int u = 0; u < U; ++u) {                          // the counters update by update, as pe_update moves them
             const int av = qu + C;
             const int nn = av >= flen ? 1 + by_hop(av - flen) : 0;
@@ -179,11 +186,9 @@ __device__ __forceinline__ void mfcc_book_tile(const MfccStreamArgs<R>& a, const
             kcu += (uint32_t)nn;
             const int m = qu + hop * (int)(kcu - ke);
             if (m >= geo.window) ke += 1u + (uint32_t)by_hop(m - geo.window);
-            if (a.ke_hist) a.ke_hist[(size_t)u * a.n_padded + s] = ke;
+            if (a.ke_hist) a.ke_hist[(size_t)u * a.n_padded + sid] = ke;
         }
-        a.st_q_next[s] = qu;
-        a.st_kc_next[s] = kcu;
-        a.st_ke_next[s] = ke;
+        a.st.rec[(size_t)(side ^ 1) * a.st.n_padded + sid] = StreamRec{qu, kcu, ke, a.st.call};      // one 16-byte store
     }
 }
 

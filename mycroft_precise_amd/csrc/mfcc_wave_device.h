@@ -529,12 +529,18 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
     const int s_end = sg_end > sg_begin ? (int)((sg_end + 1) >> 1) : s_begin;
     int base = s_begin, kb_next = -1;
     int vq = 0, vkc = 0, v_first = 0, v_nnew = 0;           // per lane: counters, first frame row worth computing, frames completed
+    int vss = 0;                                            // per lane: (stream << 1) | current side of its state
     unsigned long long due = 0;
+    // lane i <-> position base + i of this launch; its stream is ids[base + i] (pe_update_subset) or the position itself
     auto load_counters = [&]() {
         const int s = base + lane;
         const int sc = s < s_end ? s : 0;                       // (unconditional loads: see wave_tables_issue)
-        vq = a.st_q[sc]; vkc = (int)a.st_kc[sc];
+        const int sid = a.ids ? a.ids[sc] : sc;
+        const RecPair both = rec_request(a.st.rec, a.st.n_padded, sid);
+        const int side = rec_side(both, a.st.call);
+        vq = side ? both.r1.q : both.r0.q; vkc = (int)(side ? both.r1.kc : both.r0.kc);
         vq = s < s_end ? vq : 0; vkc = s < s_end ? vkc : 0;
+        vss = (sid << 1) | side;
     };
     auto lane_frames = [&]() {                                // (after the counters arrived)
         const int avail = vq + U * C;
@@ -553,11 +559,13 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
         }
         const int i = __builtin_ctzll(due);
         due &= due - 1;
-        const int kb = kb_next, s = base + i;
+        const int kb = kb_next, s = base + i;                 // s: position in this launch (PCM row)
         const int q = __builtin_amdgcn_readlane(vq, i);
         const uint32_t kc = (uint32_t)__builtin_amdgcn_readlane(vkc, i);
-        const int tile = s >> 4, j = s & 15;
-        f.car = a.carry + (size_t)s * kCarryCap;
+        const int ss = __builtin_amdgcn_readlane(vss, i);
+        const int sid = ss >> 1;                              // the stream: leftover PCM, ring rows
+        const int tile = sid >> 4, j = sid & 15;
+        f.car = a.st.carry + ((size_t)(ss & 1) * a.st.n_padded + (size_t)sid) * kCarryCap;
         f.vb = kb * hop; f.q = q;
         const int w0 = f.vb - q;
         int u0 = 0;
@@ -674,7 +682,7 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
             pe_wave::Regs<R> v;
             convert(pcm, v);                                            // the wait for this frame's samples
 #ifdef PE_DBG_CAPTURE
-            const long long dbg_s = (cur.car - a.carry) / kCarryCap;
+            const long long dbg_s = ((cur.car - a.st.carry) / kCarryCap) % a.st.n_padded;
             const int dbg_kb = cur.vb / hop;
             unsigned* const dbg = dbg_s < kDbgStreams ? pe_dbg_capture + ((size_t)(dbg_s * 2 + (dbg_kb & 1)) * 64 + lane) * kDbgWords : nullptr;
             if (dbg) { dbg[0] = (unsigned)pcm.a0; dbg[1] = (unsigned)pcm.a1; dbg[2] = (unsigned)pcm.a2; dbg[3] = (unsigned)pcm.a3; }

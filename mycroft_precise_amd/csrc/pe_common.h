@@ -50,6 +50,42 @@ struct FastDiv {
     }
 };
 
+// ---- per-stream streaming state ------------------------------------------------------------------------------------
+// One 16-byte record per stream and SIDE: q = samples held toward the next frame to compute (negative inside the dead zone
+// between windows), kc = frames computed, ke = frames emitted (visible to the network; both mod 2^32), wcall = the number
+// of the engine call that wrote the record.  Every stream has two sides (records AND leftover-PCM buffers): a call that
+// advances a stream reads its CURRENT side and writes the other one, so the roles of one launch that read the state before
+// the update (frame tasks, the network role of a fused launch) never see a half-written record -- and a stream that takes no
+// part in a call keeps its current side untouched (pe_update_subset: streams advance independently, Listener.update per
+// client, network_runner.py:125-146).  Current side = the one written most recently BEFORE this call: records stamped with
+// this call's own number are being written right now and are ignored by its readers.  (Call numbers wrap after 2^32 calls;
+// the host renumbers all records long before: engine.hip renormalize.)
+struct __attribute__((aligned(16))) StreamRec { int32_t q; uint32_t kc, ke, wcall; };
+
+struct StreamState {
+    StreamRec* rec;         // [2][n_padded]
+    int16_t* carry;         // [2][n_padded][carry_cap] leftover PCM of the one frame that straddles two calls
+    uint32_t n_padded;      // records per side
+    uint32_t call;          // number of this engine call (readers: records with wcall == call are not yet valid)
+};
+
+struct RecPair { StreamRec r0, r1; };
+__device__ __forceinline__ RecPair rec_request(const StreamRec* rec, const uint32_t n_padded, const long long s) {
+    RecPair p;              // two independent 16-byte loads: one round trip
+    p.r0 = rec[s];
+    p.r1 = rec[(size_t)n_padded + s];
+    return p;
+}
+// side whose record is current for a reader of call `call`: smallest non-zero distance call - wcall
+__device__ __forceinline__ int rec_side(const RecPair& p, const uint32_t call) {
+    return (call - p.r1.wcall) - 1u < (call - p.r0.wcall) - 1u ? 1 : 0;
+}
+__device__ __forceinline__ StreamRec rec_pick(const RecPair& p, const int side) {
+    StreamRec r;
+    r.q = side ? p.r1.q : p.r0.q; r.kc = side ? p.r1.kc : p.r0.kc; r.ke = side ? p.r1.ke : p.r0.ke; r.wcall = side ? p.r1.wcall : p.r0.wcall;
+    return r;
+}
+
 struct StreamGeom {
     int n_streams;
     int window;       // samples past a frame's start that make it visible: window_samples (+ hop for speechpy)
@@ -68,16 +104,10 @@ struct MfccStreamArgs {
     const int16_t* pcm;     // [n_streams][chunk]
     int chunk;
     int pcm_pairs_ok;       // chunk even and pcm 4-byte aligned: int16 pairs may be loaded as one dword
-    int16_t* carry;         // [n_streams_padded][kCarryCap]
-    // stream state BEFORE this update (read) ...
-    const int32_t* st_q;    // samples held toward the next frame to compute (may be < 0)
-    const uint32_t* st_kc;  // frames computed so far (mod 2^32)
-    const uint32_t* st_ke;  // frames emitted so far, i.e. visible to the network (mod 2^32)
-    // ... and AFTER it (written).  Ping-pong buffers: the GRU role of a fused launch reads the
-    // old state while MFCC workgroups are already publishing the new one.
-    int32_t* st_q_next;
-    uint32_t* st_kc_next;
-    uint32_t* st_ke_next;
+    // geo.n_streams counts the streams of THIS launch; row v of pcm belongs to stream ids[v] (pe_update_subset) or, ids == null,
+    // to stream v.  State, leftover PCM and ring rows are addressed by the stream, PCM rows and outputs by v.
+    const int32_t* ids;
+    StreamState st;         // read: each stream's current side; written: its other side (see StreamRec)
     float* ring;            // [n_tiles][ring_slots][16 streams][16 floats] -- or, ring_bf16, 16 bf16 per row (32 bytes)
     int ring_bf16;
     float* proj_ring;       // [n_tiles][ring_slots][16 streams][64 floats] x.W + b of every frame, or null
@@ -85,7 +115,6 @@ struct MfccStreamArgs {
     int n_updates;
     int n_frame_rows;       // frame tasks per stream: the most frames one stream can complete in this call
     FastDiv div_hop, div_chunk;   // division by hop_samples / by the chunk length
-    int16_t* carry_next;    // leftover after the call; must not alias carry
     uint32_t* ke_hist;      // [n_updates][n_padded] emitted-frame counter after every update
     int n_padded;
 };
@@ -139,9 +168,6 @@ struct GruArgs {
     // CwPack): non-null = the launchers take the re-tiled shapes (gru_tile_cw / gru_tile_v), which agree with each
     // other bit for bit and with the classic tiling to float32 summation order
     const float* cw;
-    // the same matrices as Keras stores them, for the DPP kernel (gru_dpp_device.h), which picks its own order
-    const float* rk;        // [H][3H] recurrent kernel, gate order z | r | h
-    const float* wd_plain;  // [H]     dense kernel
     // bf16-operand variant (gru_bf16_device.h): unit 8 g + i, tiles z0 z1 r0 r1 c0 c1
     int bf16;               // != 0: run the bf16 kernel
     const void* wx_bf16;    // [6][64] x 8 bf16    input kernel, k = 8 g + e <-> feature; k = 30, 31: bias hi, lo
@@ -153,20 +179,24 @@ struct GruArgs {
     // non-null = the launchers take gru_tile_x3 for every input mode
     const void* x3;         // [4 tiles][4][64] + [4 tiles][3][64] uint4 of 8 bf16, then float wd[5][64]
     const void* x3w;        // the same blob whatever form the launches take (PE_CW_VAR bit 6, the timing experiment of gru_cw_device.h), may be null
-    // input: either the feature ring (+ per-stream emitted-frame counters) ...
+    // input: either the feature ring (+ each stream's record: its emitted-frame counter) ...
+    // n_streams counts the windows of THIS launch; window v belongs to stream ids[v] (pe_update_subset) or, ids == null, to
+    // stream v: records and ring rows are addressed by the stream, out[] by v
+    const int32_t* ids;
+    const StreamRec* rec;   // [2][n_padded]
+    uint32_t n_padded, call;
+    const uint32_t* ke_plain;   // non-null: the emitted-frame counter of stream s is ke_plain[s] (pe_update_many: one row of the
+                                // per-update history) and the records are not read
     const float* ring;
     int ring_bf16;          // rows hold 16 bf16 (32 bytes) instead of 16 floats: bf16-operand kernel only
     // ... with, when the MFCC stage wrote it, the input projection x.W + b of every frame beside it, in MFMA slot
     // order [tile][slot][stream][g][output tile][q]: the network then starts every timestep from that accumulator
     // instead of recomputing the projection in each of the n_features windows the frame appears in
     const float* proj_ring;
-    const uint32_t* st_ke;
     int ring_slots;
-    // predict_ke != 0: st_q/st_kc/st_ke hold the state BEFORE the update whose chunk is `chunk`
+    // predict_ke != 0: the records hold the state BEFORE the update whose chunk is `chunk`
     // samples; the wave derives the post-update emitted count itself (fused MFCC || GRU launch)
     int predict_ke;
-    const int32_t* st_q;
-    const uint32_t* st_kc;
     int chunk, window, hop, frame_len;
     // ... or an explicit [n][T][F] float32 batch (Runner.predict), or -- row_stride > 0 -- one
     // [n_frames][16] float32 row sequence from which window w takes rows [w*row_stride, +T)
@@ -174,10 +204,42 @@ struct GruArgs {
     int row_stride;
     float* out;             // [n_streams]
     int row_floats;         // floats per feature row: 16, or 32 for 17..32 coefficients per frame (one-wave kernel, KX = 2)
-    int pair;               // tuning builds only (tools/micro/gru_pair_device.h, PE_PAIR=1): two tiles per network wave
-    int waves_per_tile;     // 1: one wave per tile (gru_tile);  4: four waves share a tile (gru_tile_mw);
-                            // 16: four waves per tile, sixteen LANES per stream (gru_tile_dpp)
+    int waves_per_tile;     // 1: one wave per tile (gru_tile);  4: four waves share a tile (gru_tile_mw)
 };
+
+// ---- which stream a lane of a network tile serves, and where its window ends ------------------------------------------
+// v = position in this launch (tile * 16 + j); padded lanes shadow position 0's stream (their results are never stored)
+__device__ __forceinline__ long long gru_stream_of(const GruArgs& a, const long long v, const bool valid) {
+    return a.ids ? (long long)a.ids[valid ? v : 0] : v;
+}
+// first ring cell (in rows) of a stream: [tile][slot][16 streams] rows, slot 0
+__device__ __forceinline__ size_t gru_ring_cell(const GruArgs& a, const long long sid) {
+    return (size_t)(sid >> 4) * a.ring_slots * kTileStreams + (size_t)(sid & 15);
+}
+// the loads behind a window's end (issued early, consumed by gru_ke_resolve: nothing here waits)
+struct KeRequest { RecPair p; uint32_t plain; };
+__device__ __forceinline__ KeRequest gru_ke_request(const GruArgs& a, const long long sid) {
+    KeRequest r;
+    if (a.ke_plain) { r.plain = a.ke_plain[sid]; r.p.r0 = StreamRec{0, 0u, 0u, 0u}; r.p.r1 = r.p.r0; }
+    else { r.plain = 0u; r.p = rec_request(a.rec, a.n_padded, sid); }
+    return r;
+}
+// emitted-frame count the window of this launch ends at: the record's own, or -- predict_ke, the network role of a fused
+// launch -- what this update will make of it (same arithmetic as mfcc_book_tile)
+__device__ __forceinline__ uint32_t gru_ke_resolve(const GruArgs& a, const KeRequest& r) {
+    if (a.ke_plain) return r.plain;
+    const StreamRec c = rec_pick(r.p, rec_side(r.p, a.call));
+    uint32_t ke = c.ke;
+    if (a.predict_ke) {
+        const int avail = c.q + a.chunk;
+        const int nnew = avail >= a.frame_len ? 1 + (avail - a.frame_len) / a.hop : 0;
+        const int qn = avail - nnew * a.hop;
+        const int m = qn + a.hop * (int)(c.kc + (uint32_t)nnew - ke);
+        if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
+    }
+    return ke;
+}
+__device__ __forceinline__ uint32_t gru_window_end(const GruArgs& a, const long long sid) { return gru_ke_resolve(a, gru_ke_request(a, sid)); }
 
 struct WideLayerArgs {
     const float4* wx1;      // phase 1, input part     [wave][kx4][2 TPW][64] float4
@@ -200,7 +262,7 @@ struct WideArgs {
 struct GatherArgs {         // ring -> [n][T][F] time-ordered features (update_vectors result)
     int n_streams, n_features, n_mfcc, ring_slots, ring_bf16;
     const float* ring;
-    const uint32_t* st_ke;
+    StreamState st;         // gather: read (call = a number no record carries); scatter: both sides rewritten
     float* out;
     int row_floats = kRowFloats;    // floats per feature row (32 when a frame has 17..32 coefficients)
 };
@@ -208,7 +270,7 @@ struct GatherArgs {         // ring -> [n][T][F] time-ordered features (update_v
 struct ClearArgs {
     int n_streams, ring_slots;
     const uint8_t* mask;
-    int32_t* st_q; uint32_t* st_kc; uint32_t* st_ke;
+    StreamState st;         // both sides rewritten: side 0 current (wcall = call), side 1 older
     float* ring;
     int ring_bf16;
     int32_t* activation;    // per-stream trigger state, may be null
@@ -249,10 +311,6 @@ hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const WaveTables<do
 hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const WaveTables<float>& t, const GruArgs& g, int n_cus, hipStream_t s);
 // tuning aid (-DPE_TUNING builds only; 0 in the product): an integer knob read from the environment
 int tuning_env_int(const char* name, int dflt);
-#ifdef PE_TUNING
-hipError_t launch_mfcc_quad_f64(const MfccStreamArgs<double>& a, const WaveTables<double>& t, const void* qtab, int n_cus, hipStream_t s);
-hipError_t launch_mfcc_quad_f32(const MfccStreamArgs<float>& a, const WaveTables<float>& t, const void* qtab, int n_cus, hipStream_t s);
-#endif
 hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s);
 hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, const WaveTables<float>& t, int n_cus, hipStream_t s);
 hipError_t launch_gru_small(const GruArgs& a, int input_mode, hipStream_t s);   // units <= 32; 0 feats, 1 ring, 2 rows
@@ -262,7 +320,9 @@ int gru_small_tiles(int units);                 // NT = ceil(3R/4)
 hipError_t launch_gru_wide(const WideArgs& a, int input_mode, hipStream_t s);      // units 64..256, 1-2 layers
 hipError_t launch_gru_wide_x3(const WideArgs& a, int input_mode, hipStream_t s);   // the same, float32 products on the bf16 pipe (its own weight packing)
 hipError_t launch_gather(const GatherArgs& a, hipStream_t s);
-hipError_t launch_scatter(const GatherArgs& a, int32_t* st_q, uint32_t* st_kc, hipStream_t s);   // a.out is read
+hipError_t launch_scatter(const GatherArgs& a, hipStream_t s);   // a.out is read
+// every record's wcall rewritten to 2 (current side) / 1 (other side): the host then continues counting calls from 3
+hipError_t launch_renumber(const StreamState& st, int n_padded, hipStream_t s);
 hipError_t launch_clear(const ClearArgs& a, hipStream_t s);
 // proj[row][o] = b[o] + sum_c ring[row][c] w[c][o] for n_rows feature rows (after the ring was written from outside)
 hipError_t launch_project_rows(const float* ring, float* proj, const float* w, const float* b, int n_mfcc, long long n_rows, hipStream_t s);
