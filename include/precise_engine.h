@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PE_ABI_VERSION 5
+#define PE_ABI_VERSION 6
 
 typedef enum pe_status {
     PE_OK = 0,
@@ -124,6 +124,21 @@ int pe_update(pe_engine* e, const int16_t* pcm_host, int32_t chunk_samples, floa
 int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples,
                      float* raw_out_dev, void* hip_stream);
 
+/* Streams that advance independently.  Every reference Listener consumes chunks at its own pace (network_runner.py:125-146;
+ * one engine process per client, runner/precise_runner/runner.py:54-67, :232-243); a server that multiplexes many clients on
+ * one engine has audio for SOME of them at any moment.  pe_update_subset: stream stream_ids[i] (0 <= id < n_streams, each at
+ * most once) takes chunk i of pcm[n_active][chunk_samples] and gets raw_out[i]; every other stream keeps its leftover
+ * samples, counters and feature window untouched.  Same launches as pe_update (the fused one where pe_update fuses), sized by
+ * n_active: cost follows the active streams, not the engine.  Results are those of a private Listener per stream, bit-identical
+ * to pe_update whenever the same streams get the same chunks.  n_active == 0 is a no-op (PE_OK); chunk_samples == 0 with
+ * n_active > 0 -> PE_ERR_EOF.  Callers with several chunk lengths at once issue one call per length.
+ * The host entry point validates the ids (PE_ERR_INVALID: out of range / named twice); the device entry point cannot: ids
+ * out of range or repeated are undefined behaviour there. */
+int pe_update_subset(pe_engine* e, const int32_t* stream_ids_host, int32_t n_active, const int16_t* pcm_host,
+                     int32_t chunk_samples, float* raw_out_host);
+int pe_update_subset_device(pe_engine* e, const int32_t* stream_ids_dev, int32_t n_active, const int16_t* pcm_dev,
+                            int32_t chunk_samples, float* raw_out_dev, void* hip_stream);
+
 /* Host-fed pipeline: the reference's engine is handed HOST bytes per chunk (precise/scripts/engine.py:60-63,
  * runner/precise_runner/runner.py:62-67), and pe_update above is copy -> launch -> copy, one after the other.
  * pe_update_async enqueues the same update and returns: the chunk of update u + 1 crosses PCIe (a copy stream of the
@@ -154,7 +169,12 @@ int pe_wait(pe_engine* e);
  * Engines on the general front end (see pe_params) take one front-end launch per call as well, then the batched network
  * launch (rows of 17..32 coefficients: one network launch per update of the call); same bits.  The enlarged ring stays: later single pe_update calls on a reserved engine are unchanged in their
  * results but, up to 8192 streams, use the one-wave network shape (the critical-wave shape stages exactly 32 ring slots in
- * LDS) -- reserve only on engines that use pe_update_many. */
+ * LDS) -- reserve only on engines that use pe_update_many.
+ * Network form of a reserved engine (pe_set_gru_tiling -1, the default): when max_updates x stream tiles exceeds four per
+ * compute unit (e.g. 4096 streams x 8 updates), the float32 network takes form 2 (float32 products on the bf16 pipe) for ALL
+ * launches of the engine -- the batched launch is what the engine was reserved for (402 vs 296 M windows/s at that size), and
+ * one form per engine keeps pe_update == pe_update_many bit for bit.  Single updates on such an engine take two launches.  An
+ * unreserved engine of the same size runs form 1: the two agree to float32 summation order (<= 1e-6), not bit for bit. */
 int pe_reserve_updates(pe_engine* e, int32_t max_updates, int32_t max_chunk_samples);
 int pe_update_many(pe_engine* e, const int16_t* pcm_host, int32_t chunk_samples, int32_t n_updates, float* raw_out_host);
 int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples, int32_t n_updates,
@@ -235,6 +255,11 @@ int pe_get_info(const pe_engine* e, pe_info* out);
  * negative inside the dead zone between windows), frames computed / emitted so far (mod 2^32). */
 int pe_get_stream_state(pe_engine* e, int32_t* q_out, uint32_t* computed_out, uint32_t* emitted_out);
 
+/* Test aid.  Each stream's state is a pair of 16-byte records stamped with the number of the engine call that wrote them
+ * (csrc/pe_common.h: StreamRec); the 32-bit call count is renumbered in place long before it wraps (default: at 0x7fff0000
+ * calls).  This moves the threshold (8..0x7fff0000) so that a test can cross it. */
+int pe_set_renumber_at(pe_engine* e, uint32_t call_number);
+
 /* Kernel sequencing of pe_update*: 1 (default) = when chunk_samples <= window - min(window,
  * n_fft) -- no frame computed by an update can become visible in the same update -- the MFCC
  * and network roles run concurrently inside ONE launch (networks with a fused instantiation:
@@ -252,9 +277,7 @@ int pe_set_input_projection(pe_engine* e, int32_t enabled);
 /* Network kernel shape: 0 (default) = automatic -- four waves share each 16-stream tile while the engine has few
  * tiles (stock width 17..20 units, re-tiled: up to 2 tiles per compute unit = 8192 streams on MI355X, the
  * critical-wave kernel, use_delta included; other widths: up to 1 tile per compute unit, and use_delta on the
- * one-wave kernel), one wave per tile beyond -- 1 / 4 = forced: results are bit-identical.
- * 16 = sixteen lanes per stream without matrix cores (needs pe_set_input_projection(e, 1); its own summation order:
- * agrees to ~5e-6; slower, kept for measurement). */
+ * one-wave kernel), one wave per tile beyond -- 1 / 4 = forced: results are bit-identical. */
 int pe_set_gru_waves(pe_engine* e, int32_t waves_per_tile);
 
 /* Form of the float32 network (model.py:76-82), -1 (default) = automatic by engine size:

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PE_LIB') or os.path.join(HERE, 'libprecise_engine.so')
 
 PE_OK, PE_ERR_INVALID, PE_ERR_HIP, PE_ERR_UNSUPPORTED, PE_ERR_NOMEM, PE_ERR_EOF = range(6)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class PeParams(C.Structure):
@@ -52,6 +52,9 @@ EXPORTS = {
     'pe_clear': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pe_update': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     'pe_update_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'pe_update_subset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    'pe_update_subset_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'pe_set_renumber_at': (C.c_int, [C.c_void_p, C.c_uint32]),
     'pe_host_alloc': (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     'pe_host_free': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pe_update_async': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -234,6 +237,25 @@ class HipEngine:
         out = np.empty(self.n_streams, dtype=np.float32)
         self._check(self._lib.pe_update(self._h, pcm.ctypes.data, pcm.shape[1], out.ctypes.data))
         return out
+
+    def update_subset(self, stream_ids, pcm) -> np.ndarray:
+        """The streams named in ``stream_ids`` (unique, in range) take one chunk each -- pcm int16 [len(stream_ids), chunk] --
+        and every other stream stays as it is; -> raw outputs float32 [len(stream_ids)] in the order of ``stream_ids``."""
+        ids = np.ascontiguousarray(stream_ids, dtype=np.int32).reshape(-1)
+        pcm = np.ascontiguousarray(pcm, dtype='<i2')
+        if pcm.ndim == 1:
+            pcm = pcm.reshape(1, -1)
+        if pcm.ndim != 2 or pcm.shape[0] != ids.size:
+            raise ValueError('pcm must be int16 [%d active streams, chunk_samples], got %r' % (ids.size, pcm.shape))
+        out = np.empty(ids.size, dtype=np.float32)
+        self._check(self._lib.pe_update_subset(self._h, ids.ctypes.data, ids.size, pcm.ctypes.data, pcm.shape[1], out.ctypes.data))
+        return out
+
+    def update_subset_device(self, ids_ptr: int, n_active: int, pcm_ptr: int, chunk_samples: int, out_ptr: int, stream: int = 0):
+        self._check(self._lib.pe_update_subset_device(self._h, ids_ptr, n_active, pcm_ptr, chunk_samples, out_ptr, stream))
+
+    def set_renumber_at(self, call_number: int):
+        self._check(self._lib.pe_set_renumber_at(self._h, int(call_number)))
 
     # -- host-fed pipeline (pe_update_async / pe_wait): scripts/engine.py:60-63 hands over host bytes per chunk ----------
     def host_array(self, shape, dtype) -> np.ndarray:

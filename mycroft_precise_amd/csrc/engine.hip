@@ -40,15 +40,12 @@ struct pe_engine {
     std::string err;
     std::vector<void*> allocs;
     int64_t device_bytes = 0;
-    // streaming state
-    int16_t* carry = nullptr;
-    int16_t* carry_alt = nullptr;            // the bookkeeping role writes the leftover here (frame tasks of the same launch
-                                             // still read the old one), then the two swap
-    // per-stream counters, ping-pong: [cur] is the state now, [cur ^ 1] receives the next update's
-    int32_t* st_q[2] = {nullptr, nullptr};
-    uint32_t* st_kc[2] = {nullptr, nullptr};
-    uint32_t* st_ke[2] = {nullptr, nullptr};
-    int cur = 0;
+    // streaming state: per stream two sides of (16-byte record, leftover PCM); a call that advances a stream reads its
+    // current side and writes the other (pe_common.h: StreamRec) -- streams that take no part in a call are not touched
+    StreamRec* rec = nullptr;                // [2][n_padded]
+    int16_t* carry = nullptr;                // [2][n_padded][carry_cap]
+    uint32_t call_no = 1;                    // number of the last call that wrote records (readers of later launches pass call_no + 1)
+    uint32_t renumber_at = 0x7fff0000u;      // call number at which every record is renumbered and the count restarts (pe_set_renumber_at: tests)
     bool fused = true;      // MFCC || GRU in one launch when the chunk size allows it
     int gru_waves = 0;      // 0 = auto (4 waves per tile while tiles <= CUs, else 1), or forced 1 / 4
     // general front end (mfcc_general_device.h): any n_fft / n_filt / n_mfcc the stock-shape wave kernel has no tables for
@@ -74,7 +71,6 @@ struct pe_engine {
     // packed network
     float* wxd = nullptr;
     float* wx = nullptr; float* wr1 = nullptr; float* wr2 = nullptr; float* bias = nullptr; float* wd = nullptr;
-    float* rk_plain = nullptr; float* wd_plain = nullptr;     // Keras layout, for the DPP kernel
     // wide / stacked network (units 64..256, 1-2 layers): weight streams in MFMA A-operand order
     bool wide = false;
     float* wide_buf[2][6] = {{nullptr}};     // per layer: wx1, wr1, wx2, wr2, b1, b2
@@ -93,7 +89,8 @@ struct pe_engine {
     double* cd = nullptr; int cd_len = 0, dec_min_out = 0, dec_out_range = 0; double dec_center = 0.5;
     int32_t* activation = nullptr; double trig_threshold = 0.5; int trig_level = 3, trig_rearm = -8; bool trig_on = false;
     // staging for the host entry points (grown on demand)
-    DeviceBuf st_pcm, st_out, st_feats, st_mask, st_audio, st_mfcc, st_conf, st_fired;
+    DeviceBuf st_pcm, st_out, st_feats, st_mask, st_audio, st_mfcc, st_conf, st_fired, st_ids;
+    std::vector<uint8_t> seen_ids;          // pe_update_subset: duplicate check of the host entry point
     // timing
     bool timing = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -365,11 +362,6 @@ int pack_gru_weights(pe_engine* e, const pe_gru_layer& L, const float* dense_ker
         }
     }
     int rc;
-    {
-        std::vector<float> rk(L.recurrent_kernel, L.recurrent_kernel + (size_t)H * 3 * H), wdp(dense_kernel, dense_kernel + H);
-        if ((rc = dev_upload(e, &e->rk_plain, rk))) return rc;
-        if ((rc = dev_upload(e, &e->wd_plain, wdp))) return rc;
-    }
     if ((rc = dev_upload(e, &e->wx, wx))) return rc;
     if ((rc = dev_upload(e, &e->wxd, wxd))) return rc;
     if ((rc = dev_upload(e, &e->wr1, wr1))) return rc;
@@ -700,60 +692,70 @@ int max_frames_per_call(const pe_engine* e, long long new_samples) {
     return (int)(fmax < 1 ? 1 : fmax);
 }
 
+StreamState state_of(const pe_engine* e, uint32_t call) {
+    StreamState st;
+    st.rec = e->rec; st.carry = e->carry; st.n_padded = (uint32_t)e->n_padded; st.call = call;
+    return st;
+}
+
+// Number of a call that writes records.  Call numbers are 32 bits; only the order of a stream's two sides and "written by
+// this very call" are ever read from them, so long before the count wraps every record is renumbered (current side 2, other
+// side 1; on the stream this call launches on, in front of its launches) and the count restarts.
+int begin_state_call(pe_engine* e, hipStream_t s, uint32_t* call) {
+    if (e->call_no >= e->renumber_at) {
+        PE_HIP(e, launch_renumber(state_of(e, e->call_no + 1u), e->n_padded, s));
+        e->call_no = 2u;
+    }
+    *call = ++e->call_no;
+    return PE_OK;
+}
+
+// ids / n_active: the streams of this launch (pe_update_subset; device pointer), or null / 0 = all of them in order
 template <class R>
-MfccStreamArgs<R> mfcc_args(const pe_engine* e, const int16_t* pcm_dev, int chunk) {
+MfccStreamArgs<R> mfcc_args(const pe_engine* e, const int16_t* pcm_dev, int chunk, uint32_t call, const int32_t* ids = nullptr, int n_active = 0) {
     MfccStreamArgs<R> a;
     a.geo = geom(e);
+    if (ids) a.geo.n_streams = n_active;
     a.pcm = pcm_dev;
     a.chunk = chunk;
     a.pcm_pairs_ok = ((chunk & 1) == 0) && ((reinterpret_cast<uintptr_t>(pcm_dev) & 3u) == 0);
-    a.carry = e->carry;
-    const int c = e->cur, n = e->cur ^ 1;
-    a.st_q = e->st_q[c]; a.st_kc = e->st_kc[c]; a.st_ke = e->st_ke[c];
-    a.st_q_next = e->st_q[n]; a.st_kc_next = e->st_kc[n]; a.st_ke_next = e->st_ke[n];
+    a.ids = ids;
+    a.st = state_of(e, call);
     a.ring = e->ring; a.ring_bf16 = e->prm.ring_precision;
     a.proj_ring = e->proj_on ? e->proj_ring : nullptr;
     a.n_updates = 1; a.ke_hist = nullptr; a.n_padded = e->n_padded;
-    a.n_frame_rows = max_frames_per_call(e, chunk); a.carry_next = e->carry_alt;
+    a.n_frame_rows = max_frames_per_call(e, chunk);
     a.div_hop = FastDiv::make((uint32_t)e->prm.hop_samples);
     a.div_chunk = FastDiv::make((uint32_t)chunk);
     return a;
 }
 
 template <class R>
-GeneralStreamArgs<R> general_args(const pe_engine* e, const int16_t* pcm_dev, int chunk) {
+GeneralStreamArgs<R> general_args(const pe_engine* e, const int16_t* pcm_dev, int chunk, uint32_t call, const int32_t* ids = nullptr, int n_active = 0) {
     GeneralStreamArgs<R> a{};
     a.geo = geom(e);
+    if (ids) a.geo.n_streams = n_active;
     a.tab = e->gtab;
     a.pcm = pcm_dev; a.chunk = chunk;
     a.pcm_pairs_ok = ((chunk & 1) == 0) && ((reinterpret_cast<uintptr_t>(pcm_dev) & 3u) == 0);
-    a.carry = e->carry; a.carry_next = e->carry_alt; a.carry_cap = e->carry_cap;
-    const int c = e->cur, n = c ^ 1;
-    a.st_q = e->st_q[c]; a.st_kc = e->st_kc[c]; a.st_ke = e->st_ke[c];
-    a.st_q_next = e->st_q[n]; a.st_kc_next = e->st_kc[n]; a.st_ke_next = e->st_ke[n];
+    a.ids = ids;
+    a.st = state_of(e, call); a.carry_cap = e->carry_cap;
     a.ring = e->ring; a.row_floats = e->row_floats;
     a.ring_bf16 = e->prm.ring_precision == 1;
     a.n_updates = 1; a.div_chunk = FastDiv::make((uint32_t)chunk); a.ke_hist = nullptr; a.n_padded = e->n_padded;
     return a;
 }
 
-// after a call's MFCC launches: the other counter set and the other carry buffer are the current ones
-void flip_state(pe_engine* e) {
-    e->cur ^= 1;
-    std::swap(e->carry, e->carry_alt);
-}
-
-// MFCC alone: consumes state[cur], publishes state[cur ^ 1], then flips.
-int launch_mfcc(pe_engine* e, const int16_t* pcm_dev, int chunk, hipStream_t s) {
+// MFCC alone: every stream of the launch goes from its current side to the other one (records stamped `call`).
+int launch_mfcc(pe_engine* e, const int16_t* pcm_dev, int chunk, hipStream_t s, uint32_t call, const int32_t* ids = nullptr, int n_active = 0) {
     // (no cap on the frames ONE update may complete: Listener.update takes a chunk of any length,
     //  network_runner.py:125-146; the frame tasks skip every row that the ring would overwrite again -- v_first in
     //  mfcc_frame_tasks -- so a long chunk costs its last ring_slots frames plus a scalar walk over the row indices)
     if (e->general) {
-        if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_general_stream_f64(general_args<double>(e, pcm_dev, chunk), s));
-        else PE_HIP(e, launch_general_stream_f32(general_args<float>(e, pcm_dev, chunk), s));
-    } else if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_mfcc_f64(mfcc_args<double>(e, pcm_dev, chunk), tables<double>(e), e->n_cus, s));
-    else PE_HIP(e, launch_mfcc_f32(mfcc_args<float>(e, pcm_dev, chunk), tables<float>(e), e->n_cus, s));
-    flip_state(e);
+        if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_general_stream_f64(general_args<double>(e, pcm_dev, chunk, call, ids, n_active), s));
+        else PE_HIP(e, launch_general_stream_f32(general_args<float>(e, pcm_dev, chunk, call, ids, n_active), s));
+    } else if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_mfcc_f64(mfcc_args<double>(e, pcm_dev, chunk, call, ids, n_active), tables<double>(e), e->n_cus, s));
+    else PE_HIP(e, launch_mfcc_f32(mfcc_args<float>(e, pcm_dev, chunk, call, ids, n_active), tables<float>(e), e->n_cus, s));
     return PE_OK;
 }
 
@@ -766,11 +768,11 @@ GruArgs gru_args(const pe_engine* e) {
     a.wxd = e->wxd; a.use_delta = e->prm.use_delta;
     a.wx = e->wx; a.wr1 = e->wr1; a.wr2 = e->wr2; a.bias = e->bias; a.wd = e->wd;
     a.dense_bias = e->dense_bias;
-    a.rk = e->rk_plain; a.wd_plain = e->wd_plain;
-    a.ring = e->ring; a.st_ke = e->st_ke[e->cur]; a.ring_slots = e->ring_slots; a.ring_bf16 = e->prm.ring_precision;
+    a.ring = e->ring; a.ring_slots = e->ring_slots; a.ring_bf16 = e->prm.ring_precision;
+    a.ids = nullptr; a.rec = e->rec; a.n_padded = (uint32_t)e->n_padded; a.ke_plain = nullptr;
+    a.call = e->call_no + 1u;           // a reader behind every call so far (the network role of a fused launch: that call's own number)
     a.proj_ring = e->proj_on ? e->proj_ring : nullptr;
     a.predict_ke = 0;
-    a.st_q = e->st_q[e->cur]; a.st_kc = e->st_kc[e->cur];
     a.chunk = 0;
     a.window = emit_window(e->prm); a.hop = e->prm.hop_samples;
     a.frame_len = frame_len_of(e->prm);
@@ -782,8 +784,6 @@ GruArgs gru_args(const pe_engine* e) {
     // Four waves per tile cut the latency of a tile's chain; that only pays while every tile gets a CU of its
     // own next to one MFCC workgroup.  Measured (fused, f64 front end; tools/gpu_policy.py): 4096 streams
     // 21.9 us (4 waves) vs 32.0 (1); 8192: 41.5 vs 33.5; 16384: 76.0 vs 55.3; 65536: 284 vs 199.
-    // The DPP kernel (sixteen lanes per stream, no hand-offs) has the shortest chain of all, and needs the projection rows.
-    const bool dpp_ok = e->proj_on && e->units >= 17 && e->units <= 20;
     // Stock width: the re-tiled shapes (three full tiles + partial sums; gru_cw_device.h) cut the four-wave kernel's
     // timestep (14.2 vs 16.3 us per window chain, stand-alone) but cost the one-wave kernel 5 % in the throughput
     // regime (two-pass MFMAs + reductions: 81.0 vs 77.3 us at 65 536 streams), so an engine takes ONE tiling for all
@@ -795,7 +795,7 @@ GruArgs gru_args(const pe_engine* e) {
     // do not.  Measured per update, two launches against the fused classic tiling: 54 vs 69 us at 20 480 streams, 59 vs 69 at
     // 24 576, 69 vs 79 at 32 768, 128 vs 154 us at 65 536 -- and 48 vs 43 us at 16 384 (one tile per SIMD: the classic network
     // still runs in one round of waves, and the missing fused launch costs more than the cheaper network saves).
-    const bool x3_ok = e->x3_blob && !a.bf16 && !e->wide && !a.proj_ring && e->row_floats == kRowFloats && e->gru_waves != 16;
+    const bool x3_ok = e->x3_blob && !a.bf16 && !e->wide && !a.proj_ring && e->row_floats == kRowFloats;
     // ... and so do engines reserved for several updates per call (pe_reserve_updates) whose batched network launch has more
     // (update, tile) windows than the machine has SIMDs: ONE form per engine (every launch of a form agrees bit for bit), chosen
     // for the launch the engine was reserved for -- its single updates then run the one-wave XDL kernel in two launches.
@@ -804,19 +804,14 @@ GruArgs gru_args(const pe_engine* e) {
     const bool many_windows = e->max_updates > 1 && (long long)e->max_updates * e->n_tiles > 4LL * e->n_cus;
     a.x3 = x3_ok && (e->gru_tiling == 2 || (e->gru_tiling < 0 && (e->n_tiles > 4 * e->n_cus || many_windows))) ? e->x3_blob : nullptr;
     a.x3w = e->x3_blob;
-    const bool cw_ok = e->cw_blob && e->row_floats == kRowFloats && !a.proj_ring && !a.bf16 && !a.x3 && !e->wide && e->gru_waves != 16;
+    const bool cw_ok = e->cw_blob && e->row_floats == kRowFloats && !a.proj_ring && !a.bf16 && !a.x3 && !e->wide;
     const bool retile = cw_ok && (e->gru_tiling == 1 || (e->gru_tiling < 0 && e->n_tiles <= 2 * e->n_cus));
     const int auto_waves = retile ? (e->n_tiles <= 2 * e->n_cus ? 4 : 1) : (e->n_tiles <= e->n_cus ? 4 : 1);
-    a.waves_per_tile = a.x3 ? 1 : e->gru_waves ? e->gru_waves : auto_waves;      // (16 = DPP kernel: opt-in)
-    if (a.waves_per_tile == 16 && !dpp_ok) a.waves_per_tile = 4;
+    a.waves_per_tile = a.x3 ? 1 : e->gru_waves ? e->gru_waves : auto_waves;
     if (e->prm.use_delta && !retile) a.waves_per_tile = 1;       // (classic tiling: only the one-wave kernel carries the delta inputs)
     if (e->row_floats != kRowFloats && !(gru_small_regs(e->units) == 5 && !e->prm.use_delta && a.waves_per_tile == 4))
         a.waves_per_tile = 1;       // ... and the 32-float feature rows (stock width: four waves per tile exist, gru_tile_mw5<.., 2>)
     a.cw = retile ? e->cw_blob : nullptr;
-    // (tuning builds: PE_PAIR=1 = two tiles per network wave + mixed fused workgroups, tools/micro/gru_pair_device.h --
-    //  measured and rejected: an MFMA blocks the VALU of its SIMD for its whole duration)
-    a.pair = tuning_env_int("PE_PAIR", 0) != 0 && e->units >= 17 && e->units <= 20 && !a.cw && !a.proj_ring && !a.bf16 && !e->wide &&
-             !e->prm.use_delta && e->row_floats == kRowFloats && a.waves_per_tile == 1;
     return a;
 }
 
@@ -853,11 +848,11 @@ int launch_network(pe_engine* e, const GruArgs& g, int mode, hipStream_t s) {
     return PE_OK;
 }
 
-int launch_gru_ring(pe_engine* e, float* out_dev, hipStream_t s) {
+int launch_gru_ring(pe_engine* e, float* out_dev, hipStream_t s, const int32_t* ids = nullptr, int n_active = 0) {
     GruArgs a = gru_args(e);
     a.out = out_dev;
+    if (ids) { a.ids = ids; a.n_streams = n_active; }
     return launch_network(e, a, 1, s);
-    return PE_OK;
 }
 
 // ---- host-fed pipeline -------------------------------------------------------------------------------------------
@@ -945,30 +940,35 @@ bool can_fuse(const pe_engine* e, int chunk) {
     return true;
 }
 
+// ids / n_active: the streams that take part (pe_update_subset; device pointer, PCM rows and outputs in that order), or
+// null / 0 = every stream
 int do_update(pe_engine* e, const int16_t* pcm_dev, int chunk, float* raw_out_dev, float* feats_out_dev,
-              hipStream_t s) {
+              hipStream_t s, const int32_t* ids = nullptr, int n_active = 0) {
     int rc;
     const bool t = e->timing;
+    uint32_t call = 0;
+    if ((rc = begin_state_call(e, s, &call))) return rc;
     if (t) { PE_HIP(e, hipEventRecord(e->ev[0], s)); }
     if (raw_out_dev && can_fuse(e, chunk)) {
-        GruArgs g = gru_args(e);             // state BEFORE the update; the waves predict ke
+        GruArgs g = gru_args(e);             // the records as they stand BEFORE the update; the waves predict ke
+        g.call = call;                       // (records this launch writes are not read by it)
         g.predict_ke = 1;
         g.chunk = chunk;
         g.out = raw_out_dev;
-        if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_fused_f64(mfcc_args<double>(e, pcm_dev, chunk), tables<double>(e), g, e->n_cus, s));
-        else PE_HIP(e, launch_fused_f32(mfcc_args<float>(e, pcm_dev, chunk), tables<float>(e), g, e->n_cus, s));
-        flip_state(e);
+        if (ids) { g.ids = ids; g.n_streams = n_active; }
+        if (e->prm.mfcc_precision == 0) PE_HIP(e, launch_fused_f64(mfcc_args<double>(e, pcm_dev, chunk, call, ids, n_active), tables<double>(e), g, e->n_cus, s));
+        else PE_HIP(e, launch_fused_f32(mfcc_args<float>(e, pcm_dev, chunk, call, ids, n_active), tables<float>(e), g, e->n_cus, s));
         if (t) { PE_HIP(e, hipEventRecord(e->ev[1], s)); PE_HIP(e, hipEventRecord(e->ev[2], s)); e->ev_valid = true; e->ev_has_gru = false; }
     } else {
-        if ((rc = launch_mfcc(e, pcm_dev, chunk, s))) return rc;
+        if ((rc = launch_mfcc(e, pcm_dev, chunk, s, call, ids, n_active))) return rc;
         if (t) { PE_HIP(e, hipEventRecord(e->ev[1], s)); }
         if (raw_out_dev) {
-            if ((rc = launch_gru_ring(e, raw_out_dev, s))) return rc;
+            if ((rc = launch_gru_ring(e, raw_out_dev, s, ids, n_active))) return rc;
         }
         if (t) { PE_HIP(e, hipEventRecord(e->ev[2], s)); e->ev_valid = true; e->ev_has_gru = raw_out_dev != nullptr; }
     }
     if (feats_out_dev) {
-        GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, e->st_ke[e->cur], feats_out_dev, e->row_floats};
+        GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, state_of(e, e->call_no + 1u), feats_out_dev, e->row_floats};
         PE_HIP(e, launch_gather(g, s));
     }
     return PE_OK;
@@ -1074,14 +1074,8 @@ int pe_create(const pe_params* p, const double* mel_filters, const pe_weights* w
 
     int rc = PE_OK;
     do {
-        if ((rc = dev_alloc(e, &e->carry, (size_t)e->n_padded * e->carry_cap))) break;
-        if ((rc = dev_alloc(e, &e->carry_alt, (size_t)e->n_padded * e->carry_cap))) break;
-        for (int b = 0; b < 2 && !rc; ++b) {
-            if ((rc = dev_alloc(e, &e->st_q[b], (size_t)e->n_padded))) break;
-            if ((rc = dev_alloc(e, &e->st_kc[b], (size_t)e->n_padded))) break;
-            if ((rc = dev_alloc(e, &e->st_ke[b], (size_t)e->n_padded))) break;
-        }
-        if (rc) break;
+        if ((rc = dev_alloc(e, &e->carry, (size_t)2 * e->n_padded * e->carry_cap))) break;
+        if ((rc = dev_alloc(e, &e->rec, (size_t)2 * e->n_padded))) break;
         if ((rc = dev_alloc(e, &e->ring, ring_floats(e)))) break;
         if (wide) {
             // Any width 33..256 (and stacked layers of different widths) runs on the streamed-weight kernel at the next
@@ -1146,7 +1140,7 @@ int pe_destroy(pe_engine* e) {
     (void)hipSetDevice(e->device);
     (void)drain_async(e);
     for (void* p : e->allocs) (void)hipFree(p);
-    for (DeviceBuf* b : {&e->st_pcm, &e->st_out, &e->st_feats, &e->st_mask, &e->st_audio, &e->st_mfcc, &e->st_conf, &e->st_fired})
+    for (DeviceBuf* b : {&e->st_pcm, &e->st_out, &e->st_feats, &e->st_mask, &e->st_audio, &e->st_mfcc, &e->st_conf, &e->st_fired, &e->st_ids})
         if (b->p) (void)hipFree(b->p);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->s_compute) (void)hipStreamSynchronize(e->s_compute);
@@ -1177,7 +1171,9 @@ int pe_clear(pe_engine* e, const uint8_t* mask_host) {
         PE_HIP(e, hipMemcpy(e->st_mask.p, mask_host, (size_t)e->n_streams, hipMemcpyHostToDevice));
         mask_dev = static_cast<const uint8_t*>(e->st_mask.p);
     }
-    ClearArgs a{e->n_padded, e->ring_slots, mask_dev, e->st_q[e->cur], e->st_kc[e->cur], e->st_ke[e->cur], e->ring, e->prm.ring_precision, e->activation,
+    uint32_t call = 0;
+    { int crc = begin_state_call(e, nullptr, &call); if (crc) return crc; }
+    ClearArgs a{e->n_padded, e->ring_slots, mask_dev, state_of(e, call), e->ring, e->prm.ring_precision, e->activation,
                 e->proj_on ? e->proj_ring : nullptr,
                 e->proj_on ? reinterpret_cast<const float*>(e->table_blob + e->table_layout.proj_b) : nullptr, e->row_floats};
     if (mask_dev) a.n_streams = e->n_streams;
@@ -1225,6 +1221,53 @@ int pe_update(pe_engine* e, const int16_t* pcm_host, int32_t chunk, float* raw_o
     PE_HIP(e, hipMemcpy(e->st_pcm.p, pcm_host, pcm_bytes, hipMemcpyHostToDevice));
     if ((rc = do_update(e, static_cast<const int16_t*>(e->st_pcm.p), chunk, static_cast<float*>(e->st_out.p), nullptr, nullptr))) return rc;
     PE_HIP(e, hipMemcpy(raw_out_host, e->st_out.p, (size_t)e->n_streams * sizeof(float), hipMemcpyDeviceToHost));
+    return PE_OK;
+}
+
+// Streams that advance independently (network_runner.py:125-146: every Listener takes chunks at its own pace; one engine
+// process per client, runner/precise_runner/runner.py:54-67): the n_active streams named in stream_ids take one chunk each,
+// every other stream keeps its leftover samples, counters and feature window untouched and gets no output.
+int pe_update_subset_device(pe_engine* e, const int32_t* stream_ids_dev, int32_t n_active, const int16_t* pcm_dev, int32_t chunk,
+                            float* raw_out_dev, void* stream) {
+    if (!e) return PE_ERR_INVALID;
+    if (n_active < 0 || n_active > e->n_streams) return fail(e, PE_ERR_INVALID, "n_active=%d outside 0..%d", n_active, e->n_streams);
+    if (n_active == 0) return PE_OK;                 // nobody has audio: nothing moves
+    int rc = check_chunk(e, pcm_dev, chunk);
+    if (rc) return rc;
+    if (!stream_ids_dev || !raw_out_dev) return fail(e, PE_ERR_INVALID, "null argument to pe_update_subset_device");
+    PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
+    note_user_stream(e, stream);
+    return do_update(e, pcm_dev, chunk, raw_out_dev, nullptr, static_cast<hipStream_t>(stream), stream_ids_dev, n_active);
+}
+
+int pe_update_subset(pe_engine* e, const int32_t* stream_ids_host, int32_t n_active, const int16_t* pcm_host, int32_t chunk, float* raw_out_host) {
+    if (!e) return PE_ERR_INVALID;
+    if (n_active < 0 || n_active > e->n_streams) return fail(e, PE_ERR_INVALID, "n_active=%d outside 0..%d", n_active, e->n_streams);
+    if (n_active == 0) return PE_OK;
+    int rc = check_chunk(e, pcm_host, chunk);
+    if (rc) return rc;
+    if (!stream_ids_host || !raw_out_host) return fail(e, PE_ERR_INVALID, "null argument to pe_update_subset");
+    // the host entry point checks what the device one cannot: every id in range, none twice (two rows for one stream in one
+    // launch would race on its record)
+    e->seen_ids.assign((size_t)e->n_streams, 0);
+    for (int i = 0; i < n_active; ++i) {
+        const int32_t id = stream_ids_host[i];
+        if (id < 0 || id >= e->n_streams) return fail(e, PE_ERR_INVALID, "stream_ids[%d]=%d outside 0..%d", i, id, e->n_streams - 1);
+        if (e->seen_ids[(size_t)id]) return fail(e, PE_ERR_INVALID, "stream %d is named twice (stream_ids[%d])", id, i);
+        e->seen_ids[(size_t)id] = 1;
+    }
+    PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
+    const size_t pcm_bytes = (size_t)n_active * chunk * sizeof(int16_t), out_bytes = (size_t)n_active * sizeof(float), id_bytes = (size_t)n_active * sizeof(int32_t);
+    if ((rc = ensure(e, e->st_pcm, pcm_bytes))) return rc;
+    if ((rc = ensure(e, e->st_out, out_bytes))) return rc;
+    if ((rc = ensure(e, e->st_ids, id_bytes))) return rc;
+    PE_HIP(e, hipMemcpy(e->st_ids.p, stream_ids_host, id_bytes, hipMemcpyHostToDevice));
+    PE_HIP(e, hipMemcpy(e->st_pcm.p, pcm_host, pcm_bytes, hipMemcpyHostToDevice));
+    if ((rc = do_update(e, static_cast<const int16_t*>(e->st_pcm.p), chunk, static_cast<float*>(e->st_out.p), nullptr, nullptr,
+                        static_cast<const int32_t*>(e->st_ids.p), n_active))) return rc;
+    PE_HIP(e, hipMemcpy(raw_out_host, e->st_out.p, out_bytes, hipMemcpyDeviceToHost));
     return PE_OK;
 }
 
@@ -1335,7 +1378,7 @@ int pe_get_vectors(pe_engine* e, float* feats_out_host) {
     int rc;
     const size_t feat_bytes = (size_t)e->n_streams * e->prm.n_features * e->prm.n_mfcc * sizeof(float);
     if ((rc = ensure(e, e->st_feats, feat_bytes))) return rc;
-    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, e->st_ke[e->cur], static_cast<float*>(e->st_feats.p), e->row_floats};
+    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, state_of(e, e->call_no + 1u), static_cast<float*>(e->st_feats.p), e->row_floats};
     PE_HIP(e, launch_gather(g, nullptr));
     PE_HIP(e, hipMemcpy(feats_out_host, e->st_feats.p, feat_bytes, hipMemcpyDeviceToHost));
     return PE_OK;
@@ -1350,8 +1393,10 @@ int pe_set_vectors(pe_engine* e, const float* feats_host) {
     const size_t feat_bytes = (size_t)e->n_streams * e->prm.n_features * e->prm.n_mfcc * sizeof(float);
     if ((rc = ensure(e, e->st_feats, feat_bytes))) return rc;
     PE_HIP(e, hipMemcpy(e->st_feats.p, feats_host, feat_bytes, hipMemcpyHostToDevice));
-    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, e->st_ke[e->cur], static_cast<float*>(e->st_feats.p), e->row_floats};
-    PE_HIP(e, launch_scatter(g, e->st_q[e->cur], e->st_kc[e->cur], nullptr));
+    uint32_t call = 0;
+    if ((rc = begin_state_call(e, nullptr, &call))) return rc;
+    GatherArgs g{e->n_streams, e->prm.n_features, e->prm.n_mfcc, e->ring_slots, e->prm.ring_precision, e->ring, state_of(e, call), static_cast<float*>(e->st_feats.p), e->row_floats};
+    PE_HIP(e, launch_scatter(g, nullptr));
     if (e->proj_on)
         PE_HIP(e, launch_project_rows(e->ring, e->proj_ring, reinterpret_cast<const float*>(e->table_blob + e->table_layout.proj_w),
                                       reinterpret_cast<const float*>(e->table_blob + e->table_layout.proj_b), e->prm.n_mfcc,
@@ -1592,33 +1637,34 @@ int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, i
     if (e->prm.n_features + pending + frames > e->ring_slots) return fail(e, PE_ERR_INVALID, "reserved ring too small for %d updates of %d samples", n_updates, chunk);
     hipStream_t s = static_cast<hipStream_t>(stream);
     note_user_stream(e, stream);
+    uint32_t call = 0;
+    if ((rc = begin_state_call(e, s, &call))) return rc;
     if (e->general) {
         // the general front end: every frame the call completes in ONE launch (mfcc_general_device.h: general_stream with n_updates),
         // then the batched network launch over 16-float rows, or one network launch per update over 32-float rows
         if (e->prm.mfcc_precision == 0) {
-            GeneralStreamArgs<double> a = general_args<double>(e, pcm_dev, chunk);
+            GeneralStreamArgs<double> a = general_args<double>(e, pcm_dev, chunk, call);
             a.n_updates = n_updates; a.ke_hist = e->ke_hist;
             PE_HIP(e, launch_general_stream_f64(a, s));
         } else {
-            GeneralStreamArgs<float> a = general_args<float>(e, pcm_dev, chunk);
+            GeneralStreamArgs<float> a = general_args<float>(e, pcm_dev, chunk, call);
             a.n_updates = n_updates; a.ke_hist = e->ke_hist;
             PE_HIP(e, launch_general_stream_f32(a, s));
         }
-        flip_state(e);
         GruArgs g = gru_args(e);
-        g.st_ke = e->ke_hist;
+        g.ke_plain = e->ke_hist;
         g.out = raw_out_dev;
         if (e->wide || e->row_floats != kRowFloats) {
             for (int u = 0; u < n_updates; ++u) {
                 GruArgs gu = g;
-                gu.st_ke = e->ke_hist + (size_t)u * e->n_padded;
+                gu.ke_plain = e->ke_hist + (size_t)u * e->n_padded;
                 gu.out = raw_out_dev + (size_t)u * e->n_streams;
                 int nrc = launch_network(e, gu, 1, s);
                 if (nrc) return nrc;
             }
             return PE_OK;
         }
-        if (g.waves_per_tile != 16) g.waves_per_tile = 1;
+        g.waves_per_tile = 1;
         PE_HIP(e, launch_gru_many(g, n_updates, e->n_padded, s));
         return PE_OK;
     }
@@ -1627,32 +1673,30 @@ int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, i
     if (rows > kMaxFrameRows) return fail(e, PE_ERR_INVALID, "a call may complete at most %d frames per stream (%d updates of %d samples: %d)", kMaxFrameRows, n_updates, chunk, rows);
     (void)flen;
     if (e->prm.mfcc_precision == 0) {
-        MfccStreamArgs<double> a = mfcc_args<double>(e, pcm_dev, chunk);
+        MfccStreamArgs<double> a = mfcc_args<double>(e, pcm_dev, chunk, call);
         a.n_updates = n_updates; a.ke_hist = e->ke_hist; a.n_frame_rows = rows;
         PE_HIP(e, launch_mfcc_f64(a, tables<double>(e), e->n_cus, s));
     } else {
-        MfccStreamArgs<float> a = mfcc_args<float>(e, pcm_dev, chunk);
+        MfccStreamArgs<float> a = mfcc_args<float>(e, pcm_dev, chunk, call);
         a.n_updates = n_updates; a.ke_hist = e->ke_hist; a.n_frame_rows = rows;
         PE_HIP(e, launch_mfcc_f32(a, tables<float>(e), e->n_cus, s));
     }
-    flip_state(e);
     GruArgs g = gru_args(e);
-    g.st_ke = e->ke_hist;
+    g.ke_plain = e->ke_hist;
     g.out = raw_out_dev;
     if (e->wide) {
         // the streamed-weight network: one launch per update of the call (each fills the machine on its own), the
         // window of update u found through its row of the emitted-frame history
         for (int u = 0; u < n_updates; ++u) {
             GruArgs gu = g;
-            gu.st_ke = e->ke_hist + (size_t)u * e->n_padded;
+            gu.ke_plain = e->ke_hist + (size_t)u * e->n_padded;
             gu.out = raw_out_dev + (size_t)u * e->n_streams;
             int nrc = launch_network(e, gu, 1, s);
             if (nrc) return nrc;
         }
         return PE_OK;
     }
-    if (g.waves_per_tile != 16) g.waves_per_tile = 1;     // (16: the engine's updates run the DPP kernel, and so does the batch;
-                                                          //  otherwise the launcher picks one or four waves per window itself)
+    g.waves_per_tile = 1;                                 // (the launcher picks one or four waves per window itself)
     PE_HIP(e, launch_gru_many(g, n_updates, e->n_padded, s));
     return PE_OK;
 }
@@ -1692,10 +1736,25 @@ int pe_get_stream_state(pe_engine* e, int32_t* q_out, uint32_t* computed_out, ui
     PE_HIP(e, hipSetDevice(e->device));
     PE_DRAIN(e);
     PE_HIP(e, hipDeviceSynchronize());
-    const size_t n = (size_t)e->n_streams;
-    if (q_out) PE_HIP(e, hipMemcpy(q_out, e->st_q[e->cur], n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (computed_out) PE_HIP(e, hipMemcpy(computed_out, e->st_kc[e->cur], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (emitted_out) PE_HIP(e, hipMemcpy(emitted_out, e->st_ke[e->cur], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // both sides of every record; the current one is picked here exactly as the kernels pick it (pe_common.h: rec_side)
+    std::vector<StreamRec> host((size_t)2 * e->n_padded);
+    PE_HIP(e, hipMemcpy(host.data(), e->rec, host.size() * sizeof(StreamRec), hipMemcpyDeviceToHost));
+    const uint32_t call = e->call_no + 1u;
+    for (int s = 0; s < e->n_streams; ++s) {
+        const StreamRec& r0 = host[(size_t)s];
+        const StreamRec& r1 = host[(size_t)e->n_padded + s];
+        const StreamRec& c = (call - r1.wcall) - 1u < (call - r0.wcall) - 1u ? r1 : r0;
+        if (q_out) q_out[s] = c.q;
+        if (computed_out) computed_out[s] = c.kc;
+        if (emitted_out) emitted_out[s] = c.ke;
+    }
+    return PE_OK;
+}
+
+int pe_set_renumber_at(pe_engine* e, uint32_t call_number) {
+    if (!e) return PE_ERR_INVALID;
+    if (call_number < 8u || call_number > 0x7fff0000u) return fail(e, PE_ERR_INVALID, "renumbering threshold must be in 8..0x7fff0000");
+    e->renumber_at = call_number;
     return PE_OK;
 }
 
@@ -1724,12 +1783,7 @@ int pe_set_input_projection(pe_engine* e, int32_t enabled) {
 
 int pe_set_gru_waves(pe_engine* e, int32_t waves) {
     if (!e) return PE_ERR_INVALID;
-    if (waves != 0 && waves != 1 && waves != 4 && waves != 16) return fail(e, PE_ERR_INVALID, "gru kernel shape must be 0 (auto), 1 or 4 (waves per tile)");
-#ifndef PE_TUNING
-    // 16 = sixteen lanes per stream without matrix cores (tools/micro/gru_dpp_device.h): measured, rejected,
-    // compiled into tuning builds only
-    if (waves == 16) return fail(e, PE_ERR_UNSUPPORTED, "the sixteen-lanes-per-stream kernel exists in -DPE_TUNING builds only (tools/build_variants.sh)");
-#endif
+    if (waves != 0 && waves != 1 && waves != 4) return fail(e, PE_ERR_INVALID, "gru kernel shape must be 0 (auto), 1 or 4 (waves per tile)");
     PE_DRAIN(e);
     e->gru_waves = waves;
     return PE_OK;

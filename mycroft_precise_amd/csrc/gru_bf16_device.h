@@ -61,19 +61,11 @@ __device__ __forceinline__ void gru_tile_bf16(const GruArgs& a, const int tile, 
     uint32_t first = 0;
     const uint32_t mask = (uint32_t)(a.ring_slots - 1);
     if (MODE == kRing) {
-        uint32_t ke = a.st_ke[stream];               // counters exist for padded streams too
-        if (a.predict_ke) {
-            const int q = a.st_q[stream];
-            const uint32_t kc = a.st_kc[stream];
-            const int avail = q + a.chunk;
-            const int nnew = avail >= a.frame_len ? 1 + (avail - a.frame_len) / a.hop : 0;
-            const int qn = avail - nnew * a.hop;
-            const int m = qn + a.hop * (int)(kc + (uint32_t)nnew - ke);
-            if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
-        }
+        const long long sid = gru_stream_of(a, stream, valid);      // the stream whose record and ring rows this lane reads
+        const uint32_t ke = gru_window_end(a, sid);
         first = ke - (uint32_t)T;
-        xbase = RB ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.ring) + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats)
-                   : a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats;
+        xbase = RB ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.ring) + gru_ring_cell(a, sid) * kRowFloats)
+                   : a.ring + gru_ring_cell(a, sid) * kRowFloats;
     } else if (MODE == kRows) {
         const long long w = valid ? stream : 0;
         xbase = a.feats + ((size_t)w * a.row_stride) * kRowFloats;

@@ -98,19 +98,7 @@ __device__ __forceinline__ void cw_pin(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void cw_pin(f32x4& v) { asm volatile("" : "+v"(v)); }      // (also: computed HERE, not sunk below a later loop)
 
 // post-update emitted-frame count of a stream (same arithmetic as gru_tile / mfcc_book_tile)
-__device__ __forceinline__ uint32_t cw_window_end(const GruArgs& a, const long long stream) {
-    uint32_t ke = a.st_ke[stream];                 // counters exist for padded streams too
-    if (a.predict_ke) {
-        const int q = a.st_q[stream];
-        const uint32_t kc = a.st_kc[stream];
-        const int avail = q + a.chunk;
-        const int nnew = avail >= a.frame_len ? 1 + (avail - a.frame_len) / a.hop : 0;
-        const int qn = avail - nnew * a.hop;
-        const int m = qn + a.hop * (int)(kc + (uint32_t)nnew - ke);
-        if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
-    }
-    return ke;
-}
+__device__ __forceinline__ uint32_t cw_window_end(const GruArgs& a, const long long sid) { return gru_window_end(a, sid); }
 
 // x.W + b of one 16-row tile: bias as the initial accumulator, then the four k-steps in order
 __device__ __forceinline__ f32x4 cw_xproj(const float (&w)[4], const f32x4& b, const f32x4& x) {
@@ -240,8 +228,9 @@ __device__ __forceinline__ void gru_tile_v(const GruArgs& a, const int tile, con
     uint32_t first = 0;
     const uint32_t mask = (uint32_t)(a.ring_slots - 1);
     if (MODE == kRing) {
-        first = (valid ? cw_window_end(a, stream) : 0u) - (uint32_t)T;
-        xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats + 4 * g;
+        const long long sid = gru_stream_of(a, stream, valid);      // the stream whose record and ring rows this lane reads
+        first = cw_window_end(a, sid) - (uint32_t)T;
+        xbase = a.ring + gru_ring_cell(a, sid) * kRowFloats + 4 * g;
     } else if (MODE == kRows) {
         const long long w = valid ? stream : 0;               // padded lanes shadow window 0
         xbase = a.feats + ((size_t)w * a.row_stride) * kRowFloats + 4 * g;
@@ -357,28 +346,19 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
     if (wave == 0) PE_GT(0);
 
     // ---- one round trip: the counters, this wave's share of the tile's ring, the weights ------------------------
-    const float* xbase = a.ring + ((size_t)tile * kCwSlots * kTileStreams + j) * kRowFloats + 4 * g;
+    // (a.ring_slots == kCwSlots here: cw_four_waves_ok)
+    const long long sid = gru_stream_of(a, stream, valid);      // the stream whose record and ring rows this lane reads
+    const float* xbase = a.ring + gru_ring_cell(a, sid) * kRowFloats + 4 * g;
     f32x4 stage[kCwSlots / 4];
 #pragma unroll
     for (int i = 0; i < kCwSlots / 4; ++i) stage[i] = *reinterpret_cast<const f32x4*>(xbase + (size_t)(wave + 4 * i) * kTileStreams * kRowFloats);
     // (the counters are only REQUESTED here: the arithmetic on them -- first_slot() -- comes after a role has requested its
     //  weights.  Loads return in order: consumed up here, the counters made every role wait for its share of the ring before
     //  the weight loads even went out, a second round trip in the prologue: 4.1 k cycles instead of ~2.3 k)
-    const uint32_t ke0 = a.st_ke[stream];                 // counters exist for padded streams too
-    int q0 = 0;
-    uint32_t kc0 = 0;
-    if (a.predict_ke) { q0 = a.st_q[stream]; kc0 = a.st_kc[stream]; }
+    const KeRequest ke_req = gru_ke_request(a, sid);      // the stream's record, both sides (records exist for padded streams too)
     uint32_t first = 0;
-    auto first_slot = [&]() {                               // cw_window_end(a, stream) - T, from the values requested above
-        uint32_t ke = ke0;
-        if (a.predict_ke) {
-            const int avail = q0 + a.chunk;
-            const int nnew = avail >= a.frame_len ? 1 + (avail - a.frame_len) / a.hop : 0;
-            const int qn = avail - nnew * a.hop;
-            const int m = qn + a.hop * (int)(kc0 + (uint32_t)nnew - ke);
-            if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
-        }
-        first = ke - (uint32_t)T;
+    auto first_slot = [&]() {                               // cw_window_end(a, sid) - T, from the values requested above
+        first = gru_ke_resolve(a, ke_req) - (uint32_t)T;
     };
     float* const XR = S + CwLds::XR;
     float* const L4 = S + lane * 4;

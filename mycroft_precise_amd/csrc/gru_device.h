@@ -78,8 +78,8 @@ enum GruInput {
 // load of a tile's accumulators reads 1 KB contiguous (a row-per-stream layout made every lane touch its own 64-byte
 // segment: 340 cycles of address processing per timestep in the one-wave kernel).  Slot `s` of the ring is
 // s * kTileStreams * kProjRow floats further; output tile tl adds tl * kTileStreams * 16 floats.
-__device__ __forceinline__ const float* proj_base(const GruArgs& a, int tile, int j, int g) {
-    return a.proj_ring + (size_t)tile * a.ring_slots * kTileStreams * kProjRow + (size_t)(j * 4 + g) * 4;
+__device__ __forceinline__ const float* proj_base(const GruArgs& a, const long long sid, int g) {
+    return a.proj_ring + (size_t)(sid >> 4) * a.ring_slots * kTileStreams * kProjRow + (size_t)((int)(sid & 15) * 4 + g) * 4;
 }
 constexpr int kProjTileStride = kTileStreams * 16;       // floats between the accumulators of consecutive output tiles
 
@@ -131,21 +131,11 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
     const float* xbase = nullptr;
     uint32_t first = 0;           // ring: frame index of timestep 0
     const uint32_t mask = (uint32_t)(a.ring_slots - 1);
+    const long long sid = FROM_RING ? gru_stream_of(a, stream, valid) : 0;      // the stream whose record and ring rows this lane reads
     if (FROM_RING) {
-        uint32_t ke = valid ? a.st_ke[stream] : 0u;
-        if (a.predict_ke && valid) {
-            // running beside the MFCC role of the same update: derive the emitted-frame count this
-            // update will produce from the state before it (same arithmetic as mfcc_book_tile)
-            const int q = a.st_q[stream];
-            const uint32_t kc = a.st_kc[stream];
-            const int avail = q + a.chunk;
-            const int nnew = avail >= a.frame_len ? 1 + (avail - a.frame_len) / a.hop : 0;
-            const int qn = avail - nnew * a.hop;
-            const int m = qn + a.hop * (int)(kc + (uint32_t)nnew - ke);
-            if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
-        }
+        const uint32_t ke = gru_window_end(a, sid);
         first = ke - (uint32_t)T;
-        xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * RF + 4 * g;
+        xbase = a.ring + gru_ring_cell(a, sid) * RF + 4 * g;
     } else if (MODE == kRows) {
         const long long w = valid ? stream : 0;               // padded lanes shadow window 0
         xbase = a.feats + ((size_t)w * a.row_stride) * RF + 4 * g;
@@ -188,7 +178,7 @@ __device__ __forceinline__ void gru_tile(const GruArgs& a, const int tile, const
 #pragma unroll
     for (int rho = 0; rho < R; ++rho) h[rho] = 0.f;
 
-    const float* pbase = PROJ ? proj_base(a, tile, j, g) : nullptr;
+    const float* pbase = PROJ ? proj_base(a, sid, g) : nullptr;
     auto load_p = [&](int t, f32x4 (&p)[G::NT]) {
         const int tc = t < T ? t : T - 1;
         const uint32_t slot = (first + (uint32_t)tc) & mask;
@@ -349,20 +339,12 @@ __device__ __forceinline__ void gru_tile_mw(const GruArgs& a, const int tile, co
 #pragma unroll
     for (int rho = 0; rho < R; ++rho) wd[rho] = a.wd[rho * 64 + lane];
 
-    uint32_t ke = a.st_ke[stream];                 // counters exist for padded streams too
-    if (a.predict_ke) {
-        const int q = a.st_q[stream];
-        const uint32_t kc = a.st_kc[stream];
-        const int avail = q + a.chunk;
-        const int nnew = avail >= a.frame_len ? 1 + (avail - a.frame_len) / a.hop : 0;
-        const int qn = avail - nnew * a.hop;
-        const int m = qn + a.hop * (int)(kc + (uint32_t)nnew - ke);
-        if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
-    }
+    const long long sid = gru_stream_of(a, stream, valid);      // the stream whose record and ring rows this lane reads
+    const uint32_t ke = gru_window_end(a, sid);
     const uint32_t first = ke - (uint32_t)T;
     const uint32_t mask = (uint32_t)(a.ring_slots - 1);
-    const float* xbase = a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * kRowFloats + 4 * g;
-    const float* pbase = PROJ ? proj_base(a, tile, j, g) + kProjTileStride * (wave < G::NT ? wave : 0) : nullptr;
+    const float* xbase = a.ring + gru_ring_cell(a, sid) * kRowFloats + 4 * g;
+    const float* pbase = PROJ ? proj_base(a, sid, g) + kProjTileStride * (wave < G::NT ? wave : 0) : nullptr;
     auto load_x = [&](int t) -> f32x4 {
         const int tc = t < T ? t : T - 1;
         const uint32_t slot = (first + (uint32_t)tc) & mask;
@@ -484,22 +466,14 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
         wd[rho] = a.wd[rho * 64 + lane];
     }
 
-    uint32_t ke = a.st_ke[stream];                 // counters exist for padded streams too
-    if (a.predict_ke) {
-        const int q = a.st_q[stream];
-        const uint32_t kc = a.st_kc[stream];
-        const int avail = q + a.chunk;
-        const int nnew = avail >= a.frame_len ? 1 + (avail - a.frame_len) / a.hop : 0;
-        const int qn = avail - nnew * a.hop;
-        const int m = qn + a.hop * (int)(kc + (uint32_t)nnew - ke);
-        if (m >= a.window) ke += 1u + (uint32_t)((m - a.window) / a.hop);
-    }
+    const long long sid = gru_stream_of(a, stream, valid);      // the stream whose record and ring rows this lane reads
+    const uint32_t ke = gru_window_end(a, sid);
     const uint32_t first = ke - (uint32_t)T;
     const uint32_t mask = (uint32_t)(a.ring_slots - 1);
     // what a wave fetches per timestep: the feature row (4 features per lane) -- or, PROJ, the input projection of
     // ITS OWN output tile as the MFCC stage stored it (then no wave computes projections and nothing is handed over)
-    const float* xbase = PROJ ? proj_base(a, tile, j, g) + kProjTileStride * wave
-                              : a.ring + ((size_t)tile * a.ring_slots * kTileStreams + j) * RF + 4 * g;
+    const float* xbase = PROJ ? proj_base(a, sid, g) + kProjTileStride * wave
+                              : a.ring + gru_ring_cell(a, sid) * RF + 4 * g;
     const size_t xstride = (size_t)kTileStreams * (PROJ ? kProjRow : RF);
     struct XRow { f32x4 lo, hi; };
     auto load_x = [&](int t) -> XRow {

@@ -80,7 +80,7 @@ template <int R, bool PROJ>
 __global__ __launch_bounds__(64) void gru_many_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
     const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
     GruArgs b = a;
-    b.st_ke = a.st_ke + (size_t)u * n_padded;
+    b.ke_plain = a.ke_plain + (size_t)u * n_padded;      // row u of the emitted-frame history
     b.out = a.out + (size_t)u * a.n_streams;
     b.predict_ke = 0;
     gru_tile<R, kRing, PROJ>(b, tile, threadIdx.x);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void gru_many_mw_kernel(const GruArgs a, const
     __shared__ __attribute__((aligned(16))) float S[3 * R * 64 + 256];
     const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
     GruArgs b = a;
-    b.st_ke = a.st_ke + (size_t)u * n_padded;
+    b.ke_plain = a.ke_plain + (size_t)u * n_padded;      // row u of the emitted-frame history
     b.out = a.out + (size_t)u * a.n_streams;
     b.predict_ke = 0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -104,7 +104,7 @@ template <bool DELTA>
 __global__ __launch_bounds__(64) void gru_many_v_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
     const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
     GruArgs b = a;
-    b.st_ke = a.st_ke + (size_t)u * n_padded;
+    b.ke_plain = a.ke_plain + (size_t)u * n_padded;      // row u of the emitted-frame history
     b.out = a.out + (size_t)u * a.n_streams;
     b.predict_ke = 0;
     gru_tile_v<kRing, DELTA>(b, tile, threadIdx.x);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void gru_many_cw_kernel(const GruArgs a, const
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
     GruArgs b = a;
-    b.st_ke = a.st_ke + (size_t)u * n_padded;
+    b.ke_plain = a.ke_plain + (size_t)u * n_padded;      // row u of the emitted-frame history
     b.out = a.out + (size_t)u * a.n_streams;
     b.predict_ke = 0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -124,7 +124,7 @@ template <bool DELTA, bool RB>
 __global__ __launch_bounds__(64) void gru_many_bf16_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
     const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
     GruArgs b = a;
-    b.st_ke = a.st_ke + (size_t)u * n_padded;
+    b.ke_plain = a.ke_plain + (size_t)u * n_padded;      // row u of the emitted-frame history
     b.out = a.out + (size_t)u * a.n_streams;
     b.predict_ke = 0;
     if (b.b20) { gru_tile_b20<kRing, DELTA, RB>(b, tile, threadIdx.x); return; }      // <= 20 units: five values per lane
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64) void gru_x3_kernel(const GruArgs a) {
 __global__ __launch_bounds__(64) void gru_many_x3_kernel(const GruArgs a, const int n_tiles, const int n_padded) {
     const int u = blockIdx.x / n_tiles, tile = blockIdx.x % n_tiles;
     GruArgs b = a;
-    b.st_ke = a.st_ke + (size_t)u * n_padded;
+    b.ke_plain = a.ke_plain + (size_t)u * n_padded;      // row u of the emitted-frame history
     b.out = a.out + (size_t)u * a.n_streams;
     b.predict_ke = 0;
     gru_tile_x3<kRing>(b, tile, threadIdx.x);
@@ -785,14 +785,16 @@ __global__ void gather_kernel(const GatherArgs a) {
     const int f = (int)(idx % a.n_mfcc);
     const int t = (int)((idx / a.n_mfcc) % a.n_features);
     const long long s = idx / ((long long)a.n_mfcc * a.n_features);
-    const uint32_t slot = (a.st_ke[s] - (uint32_t)a.n_features + (uint32_t)t) & (uint32_t)(a.ring_slots - 1);
+    const RecPair both = rec_request(a.st.rec, a.st.n_padded, s);
+    const uint32_t ke = rec_pick(both, rec_side(both, a.st.call)).ke;
+    const uint32_t slot = (ke - (uint32_t)a.n_features + (uint32_t)t) & (uint32_t)(a.ring_slots - 1);
     const long long tile = s / kTileStreams;
     const int j = (int)(s % kTileStreams);
     const size_t at = (((size_t)tile * a.ring_slots + slot) * kTileStreams + j) * a.row_floats + f;
     a.out[idx] = a.ring_bf16 ? (float)reinterpret_cast<const __bf16*>(a.ring)[at] : a.ring[at];
 }
 
-__global__ void scatter_kernel(const GatherArgs a, int32_t* st_q, uint32_t* st_kc) {
+__global__ void scatter_kernel(const GatherArgs a) {
     // inverse of gather_kernel: the stream restarts with the given [T][F] window already emitted
     // (frames 0..T-1 in slots 0..T-1, nothing held toward the next frame)
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -808,17 +810,31 @@ __global__ void scatter_kernel(const GatherArgs a, int32_t* st_q, uint32_t* st_k
     const size_t at = (((size_t)tile * a.ring_slots + t) * kTileStreams + j) * RF + f;
     if (a.ring_bf16) reinterpret_cast<__bf16*>(const_cast<float*>(a.ring))[at] = (__bf16)v;
     else const_cast<float*>(a.ring)[at] = v;
-    if (f == 0 && t == 0) {
-        st_q[s] = 0;
-        st_kc[s] = (uint32_t)a.n_features;
-        const_cast<uint32_t*>(a.st_ke)[s] = (uint32_t)a.n_features;
+    if (f == 0 && t == 0) {       // side 0 becomes the current one (stamped with this call), side 1 the older
+        a.st.rec[s] = StreamRec{0, (uint32_t)a.n_features, (uint32_t)a.n_features, a.st.call};
+        a.st.rec[(size_t)a.st.n_padded + s] = StreamRec{0, (uint32_t)a.n_features, (uint32_t)a.n_features, a.st.call - 1u};
     }
 }
 
-hipError_t launch_scatter(const GatherArgs& a, int32_t* st_q, uint32_t* st_kc, hipStream_t s) {
+hipError_t launch_scatter(const GatherArgs& a, hipStream_t s) {
     const long long total = (long long)a.n_streams * a.n_features * a.row_floats;
     if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, st_q, st_kc);
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// call numbers wrap after 2^32 calls: long before, every record is renumbered (current side 2, other side 1) and the host
+// restarts its counter at 3 -- only the ORDER of a stream's two sides and "not this call" are ever read
+__global__ void renumber_kernel(const StreamState st, const int n_padded) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_padded) return;
+    const RecPair both = rec_request(st.rec, st.n_padded, s);
+    const int side = rec_side(both, st.call);
+    st.rec[(size_t)side * st.n_padded + s].wcall = 2u;
+    st.rec[(size_t)(side ^ 1) * st.n_padded + s].wcall = 1u;
+}
+hipError_t launch_renumber(const StreamState& st, int n_padded, hipStream_t s) {
+    hipLaunchKernelGGL(renumber_kernel, dim3((n_padded + 255) / 256), dim3(256), 0, s, st, n_padded);
     return hipGetLastError();
 }
 
@@ -827,7 +843,11 @@ __global__ void clear_kernel(const ClearArgs a) {
     const long long s = blockIdx.x;
     if (s >= a.n_streams) return;
     if (a.mask && !a.mask[s]) return;
-    if (threadIdx.x == 0) { a.st_q[s] = 0; a.st_kc[s] = 0u; a.st_ke[s] = 0u; if (a.activation) a.activation[s] = 0; }
+    if (threadIdx.x == 0) {         // side 0 becomes the current one (stamped with this call), side 1 the older
+        a.st.rec[s] = StreamRec{0, 0u, 0u, a.st.call};
+        a.st.rec[(size_t)a.st.n_padded + s] = StreamRec{0, 0u, 0u, a.st.call - 1u};
+        if (a.activation) a.activation[s] = 0;
+    }
     const long long tile = s / kTileStreams;
     const int j = (int)(s % kTileStreams);
     for (int i = threadIdx.x; i < a.ring_slots * a.row_floats; i += blockDim.x) {

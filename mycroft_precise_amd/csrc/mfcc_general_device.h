@@ -388,11 +388,9 @@ struct GeneralStreamArgs {
     const int16_t* pcm;         // [n_streams][chunk]
     int chunk;
     int pcm_pairs_ok;           // chunk even and pcm 4-byte aligned: int16 pairs may be loaded as one dword
-    const int16_t* carry;       // [n_streams_padded][carry_cap] leftover before the update
-    int16_t* carry_next;        // ... and after it (must not alias)
+    const int32_t* ids;         // row v of pcm belongs to stream ids[v] (pe_update_subset), or to stream v (null)
+    StreamState st;             // records and leftover PCM, two sides per stream (pe_common.h: StreamRec); carry rows of carry_cap samples
     int carry_cap;
-    const int32_t* st_q; const uint32_t* st_kc; const uint32_t* st_ke;
-    int32_t* st_q_next; uint32_t* st_kc_next; uint32_t* st_ke_next;
     float* ring;                // [tiles][slots][16 streams][row_floats] -- or, ring_bf16, 16 bf16 per row (row_floats == 16 only)
     int row_floats;
     int ring_bf16;
@@ -412,13 +410,18 @@ template <class R, int BITS, bool BLUE = false>
 __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R* S, const int s, const int par, const int lane, const int n_par = 2) {
     const StreamGeom& geo = a.geo;
     const int C = a.chunk, hop = geo.hop, flen = geo.frame_len, slots = geo.ring_slots;
-    const int q = a.st_q[s];
-    const uint32_t kc = a.st_kc[s];
-    uint32_t ke = a.st_ke[s];
+    const int sid = a.ids ? a.ids[s] : s;                 // s: position in this launch (PCM row); sid: the stream (state, ring rows)
+    const RecPair both = rec_request(a.st.rec, a.st.n_padded, sid);
+    const int side = rec_side(both, a.st.call);
+    const StreamRec now = rec_pick(both, side);
+    const int q = now.q;
+    const uint32_t kc = now.kc;
+    uint32_t ke = now.ke;
     const int U = a.n_updates;
     const int avail = q + U * C;
     const int nnew = avail >= flen ? 1 + (avail - flen) / hop : 0;
-    const int16_t* car = a.carry + (size_t)s * a.carry_cap;
+    const size_t carry_side = (size_t)a.st.n_padded * a.carry_cap;
+    const int16_t* car = a.st.carry + (size_t)side * carry_side + (size_t)sid * a.carry_cap;
     const int16_t* row0 = a.pcm + (size_t)s * C;
     const size_t update_stride = (size_t)geo.n_streams * C;
     // sample w >= 0 of the call's chunks of this stream, one after the other (pe_update_many: chunk u = w / C, a row of its own)
@@ -431,7 +434,7 @@ __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R*
     // (even, odd) sample pairs as one dword: every quantity that shifts a pair boundary must be even (then a pair never
     // straddles the carry / chunk seam, and every pair address is 4-byte aligned: carry rows are 128-byte aligned)
     const bool pairs = a.pcm_pairs_ok && ((q | hop | flen) & 1) == 0;
-    const int tile = s >> 4, j = s & 15;
+    const int tile = sid >> 4, j = sid & 15;
     for (int kb = (nnew > slots ? nnew - slots : 0) + par; kb < nnew; kb += n_par) {
         const int vb = kb * hop;
         R coeff[1];
@@ -466,7 +469,7 @@ __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R*
     if (par != 0) return;
     // leftover samples, counters (the arithmetic of mfcc_book_tile)
     const int qn = avail - nnew * hop;
-    int16_t* carw = a.carry_next + (size_t)s * a.carry_cap;
+    int16_t* carw = a.st.carry + (size_t)(side ^ 1) * carry_side + (size_t)sid * a.carry_cap;
     if (!(PE_GEN_ABL & 1)) {
         if (pairs) {
             // qn is even here (q, C, hop even): dword loads, four in flight, dword stores
@@ -498,9 +501,9 @@ __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R*
             kcu += (uint32_t)nn;
             const int mm = qu + hop * (int)(kcu - ke);
             if (mm >= geo.window) ke += 1u + (uint32_t)((mm - geo.window) / hop);
-            if (a.ke_hist) a.ke_hist[(size_t)u * a.n_padded + s] = ke;
+            if (a.ke_hist) a.ke_hist[(size_t)u * a.n_padded + sid] = ke;
         }
-        a.st_q_next[s] = qu; a.st_kc_next[s] = kcu; a.st_ke_next[s] = ke;
+        a.st.rec[(size_t)(side ^ 1) * a.st.n_padded + sid] = StreamRec{qu, kcu, ke, a.st.call};
     }
 }
 

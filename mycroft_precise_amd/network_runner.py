@@ -255,9 +255,11 @@ class Listener:
 
 class BatchedListener:
     """
-    ``Listener`` for ``n_streams`` independent streams that advance in lock step: every
-    ``update`` takes one equal-sized chunk per stream ([n_streams, chunk_samples] int16, or a list
-    of bytes objects) and returns one prediction per stream.  Stream state never leaves HBM.
+    ``Listener`` for ``n_streams`` independent streams on one device.  ``update(chunks)`` takes one equal-sized chunk for
+    EVERY stream ([n_streams, chunk_samples] int16, or a list of bytes objects) and returns one prediction per stream;
+    ``update(chunks, streams=ids)`` takes chunks for the named streams only ([len(ids), chunk_samples]) and leaves every other
+    stream exactly as it is -- each stream then advances at its own pace, as one reference ``Listener`` per client does
+    (network_runner.py:125-146), and the call costs what its active streams cost.  Stream state never leaves HBM.
     """
 
     def __init__(self, model, n_streams: int, device: int = 0, mfcc_precision: str = 'f64', params=None,
@@ -283,19 +285,28 @@ class BatchedListener:
         self.engine.set_trigger(chunk_size, sensitivity, trigger_level)
         self._trigger = True
 
-    def _pcm(self, chunks) -> np.ndarray:
+    def _pcm(self, chunks, n_rows=None) -> np.ndarray:
+        n_rows = self.n_streams if n_rows is None else n_rows
         if isinstance(chunks, np.ndarray):
             pcm = chunks
         else:
             rows = [pcm16_from(c) for c in chunks]
             if len({r.size for r in rows}) > 1:
-                raise ValueError('all streams must supply equal-sized chunks')
+                raise ValueError('all streams of one call must supply equal-sized chunks (one call per chunk length)')
             pcm = np.stack(rows) if rows else np.empty((0, 0), dtype='<i2')
-        if pcm.ndim != 2 or pcm.shape[0] != self.n_streams:
-            raise ValueError('expected [%d, chunk_samples] int16, got %r' % (self.n_streams, pcm.shape))
-        if pcm.shape[1] == 0:
+        if pcm.ndim != 2 or pcm.shape[0] != n_rows:
+            raise ValueError('expected [%d, chunk_samples] int16, got %r' % (n_rows, pcm.shape))
+        if pcm.shape[1] == 0 and n_rows > 0:
             raise EOFError
         return pcm
+
+    def _ids(self, streams) -> np.ndarray:
+        ids = np.asarray(streams, dtype=np.int64).reshape(-1)
+        if ids.size and (ids.min() < 0 or ids.max() >= self.n_streams):
+            raise ValueError('stream ids must be in 0..%d' % (self.n_streams - 1))
+        if np.unique(ids).size != ids.size:
+            raise ValueError('a stream may be named once per call')
+        return ids.astype(np.int32)
 
     def clear(self, mask=None):
         self.engine.clear(mask)
@@ -304,13 +315,22 @@ class BatchedListener:
         """-> [n_streams, n_features, n_mfcc] float32"""
         return self.engine.update_vectors(self._pcm(chunks))
 
-    def update_raw(self, chunks) -> np.ndarray:
-        """-> raw network outputs float32 [n_streams]"""
-        return self.engine.update(self._pcm(chunks))
+    def update_raw(self, chunks, streams=None) -> np.ndarray:
+        """-> raw network outputs float32 [n_streams]; with ``streams=ids``: [len(ids)], in the order of ``ids``"""
+        if streams is None:
+            return self.engine.update(self._pcm(chunks))
+        ids = self._ids(streams)
+        if ids.size == 0:
+            return np.empty(0, dtype=np.float32)
+        return self.engine.update_subset(ids, self._pcm(chunks, ids.size))
 
-    def update(self, chunks) -> np.ndarray:
-        """-> decoded confidences float64 [n_streams] (ThresholdDecoder.decode on the device)"""
-        return self.engine.decode(self.update_raw(chunks))
+    def update(self, chunks, streams=None) -> np.ndarray:
+        """-> decoded confidences float64 [n_streams] (ThresholdDecoder.decode on the device); with ``streams=ids`` the
+        confidences of those streams only (decoded on the host, one value each, as the reference's Listener.update does)"""
+        if streams is None:
+            return self.engine.decode(self.update_raw(chunks))
+        raw = self.update_raw(chunks, streams)
+        return np.array([self.threshold_decoder.decode(r) for r in raw], dtype=np.float64)
 
     # -- host-fed pipeline: what a server that receives audio over the network does (scripts/engine.py:60-63 per stream) --
     def chunk_buffer(self, chunk_samples: int = 1024) -> np.ndarray:

@@ -1640,6 +1640,236 @@ def test_bench_two_ranks_on_one_gpu_shards_streams_correctly():
     assert not np.array_equal(both[:, :512], both[:, 512:])          # the two shards really are different streams
 
 
+# ---- streams that advance independently (pe_update_subset) ------------------------------------------------------------------------
+def _cadence_run(hip, refs, rng, n_calls, sizes, audio, pos, check_every_raw=True):
+    """`n_calls` subset calls: each picks one chunk length and a random set of streams; every active stream is compared with
+    its own OracleListener (network_runner.py:125-153 restated), inactive streams must not move."""
+    n = len(refs)
+    worst = 0.0
+    for call in range(n_calls):
+        chunk = int(sizes[int(rng.integers(0, len(sizes)))])
+        p_active = rng.random(n)                                   # per-stream cadence: some streams speak often, some rarely
+        active = np.nonzero(rng.random(n) < hip._cadence * (0.2 + p_active))[0]
+        active = active[(pos[active] + chunk) <= audio.shape[1]]
+        rng.shuffle(active)                                        # (the order of the ids is the order of rows and outputs)
+        if active.size == 0:
+            assert hip.update_raw(np.empty((0, chunk), np.int16), streams=[]).size == 0
+            continue
+        pcm = np.stack([audio[s, pos[s]:pos[s] + chunk] for s in active])
+        before = hip.engine.stream_state()
+        got = hip.update_raw(pcm, streams=active)
+        after = hip.engine.stream_state()
+        idle = np.setdiff1d(np.arange(n), active)
+        for b, a in zip(before, after):
+            assert np.array_equal(b[idle], a[idle]), call          # streams without audio did not move
+        for k, s in enumerate(active):
+            want = refs[s].update_raw(pcm[k].tobytes())
+            worst = max(worst, abs(float(got[k]) - want))
+            pos[s] += chunk
+        assert worst <= GUARD_RAW, (call, chunk, worst)
+    return worst
+
+
+@pytest.mark.parametrize('n,cadence,sizes', [(64, 0.5, (1024,)), (64, 0.6, (1024, 2048, 640, 801, 160)), (200, 0.3, (1024, 512))])
+def test_streams_advance_independently(stock_weights, n, cadence, sizes):
+    """n streams fed at n different random cadences and chunk phases for 200 calls, every stream against its own
+    OracleListener at GUARD_RAW; leftover length, counters and feature windows of every stream at the end."""
+    from mycroft_precise_amd.network_runner import BatchedListener
+    rng = np.random.default_rng(20260930 + n + len(sizes))
+    kinds = (['tone_noise'] * (n - 4)) + ['zeros', 'square', 'quiet', 'tone_noise']
+    audio = np.stack([synth.stream_pcm(s, 200 * 1024, k) for s, k in enumerate(kinds)])
+    hip = BatchedListener(stock_weights, n)
+    hip._cadence = cadence
+    refs = [ol.OracleListener(stock_weights) for _ in range(n)]
+    pos = np.zeros(n, dtype=np.int64)
+    # phases: every stream starts with a private odd-sized first chunk (one call per length)
+    first = rng.integers(1, 1500, n)
+    for length in np.unique(first):
+        ids = np.nonzero(first == length)[0]
+        pcm = np.stack([audio[s, :length] for s in ids])
+        got = hip.update_raw(pcm, streams=ids)
+        for k, s in enumerate(ids):
+            assert abs(float(got[k]) - refs[s].update_raw(pcm[k].tobytes())) <= GUARD_RAW
+            pos[s] = length
+    _cadence_run(hip, refs, rng, 200, sizes, audio, pos)
+    q, kc, ke = hip.engine.stream_state()
+    left = np.array([len(r.window_audio) for r in refs])
+    assert np.array_equal(q + 800 * (kc - ke).astype(np.int64), left)
+    want = np.stack([r.mfccs for r in refs])
+    assert np.abs(hip.engine.get_vectors().astype(np.float64) - want).max() <= TOL_FEAT32
+    assert len(np.unique(pos)) > n // 2                            # the streams really are at different places
+    hip.engine.close()
+
+
+def test_subset_of_all_streams_equals_full_update_bitwise(stock_weights):
+    """pe_update_subset over every stream in order == pe_update, bit for bit, fused and in two launches, interleaved with full
+    updates and pe_update_many on the same engine; a permutation of the ids permutes rows and outputs; the host entry point
+    refuses ids out of range / named twice, and an empty chunk is EOF."""
+    from mycroft_precise_amd._lib import HipEngine
+    n, n_up = 70, 36
+    pcm = _stream_batch(['tone_noise'] * (n - 3) + ['zeros', 'square', 'quiet'], n_up)
+    a = HipEngine(P.pr, stock_weights, n_streams=n)
+    b = HipEngine(P.pr, stock_weights, n_streams=n)
+    c = HipEngine(P.pr, stock_weights, n_streams=n)
+    c.set_fused(False)
+    perm = np.random.default_rng(3).permutation(n)
+    ids = np.arange(n)
+    for u in range(n_up):
+        want = a.update(pcm[u])
+        if u % 3 == 0:
+            got = b.update(pcm[u])                                 # a full update between subset calls
+        elif u % 3 == 1:
+            got = b.update_subset(ids, pcm[u])
+        else:
+            got = np.empty(n, np.float32)
+            got[perm] = b.update_subset(perm, pcm[u][perm])
+        assert np.array_equal(got, want), u
+        two = np.empty(n, np.float32)
+        half = perm[:n // 2], perm[n // 2:]                        # the same update as two calls over disjoint halves
+        for h in half:
+            two[h] = c.update_subset(h, pcm[u][h])
+        assert np.array_equal(two, want), u
+    for x, y, z in zip(a.stream_state(), b.stream_state(), c.stream_state()):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    assert np.array_equal(a.get_vectors(), b.get_vectors()) and np.array_equal(a.get_vectors(), c.get_vectors())
+    with pytest.raises(ValueError):
+        b.update_subset([0, n], pcm[0][:2])
+    with pytest.raises(ValueError):
+        b.update_subset([3, 3], pcm[0][:2])
+    with pytest.raises(EOFError):
+        b.update_subset([1], np.empty((1, 0), np.int16))
+    assert b.update_subset([], np.empty((0, 1024), np.int16)).size == 0
+    for x, y in zip(a.stream_state(), b.stream_state()):           # the refused calls moved nothing
+        assert np.array_equal(x, y)
+    a.close(); b.close(); c.close()
+
+
+@pytest.mark.parametrize('kw', [dict(gru_precision='bf16', ring_precision='bf16', mfcc_precision='f32'), dict(units=(256, 256)),
+                                dict(params=dict(n_fft=1024, n_filt=40, n_mfcc=20)), dict(use_delta=True), dict(tiling=2)],
+                         ids=['bf16', 'wide256x2', 'general_fft1024', 'use_delta', 'x3'])
+def test_subset_updates_in_every_network_and_front_end(kw):
+    """The id indirection sits in every network prologue and both front ends: bf16 rows + five-values network, the wide streamed
+    network, the general front end (32-float rows), delta inputs, the float32 network on the bf16 pipe -- each: random subsets at
+    random chunk lengths; streams 0..5 also run alone on private single-stream engines, which must see the same bits (one stream
+    alone vs the same stream at some position of some tile: same arithmetic per stream)."""
+    import warnings
+    from mycroft_precise_amd._lib import HipEngine
+    kw = dict(kw)
+    hpr = P.pr.copy()
+    hpr.__dict__.update(kw.pop('params', {}))
+    if kw.pop('use_delta', False):
+        hpr.__dict__['use_delta'] = True
+    tiling = kw.pop('tiling', None)
+    units = kw.pop('units', (20,))
+    n_in = hpr.n_mfcc * (2 if hpr.use_delta else 1)
+    w = synth.make_weights(n_in=n_in, units=units, seed=13)
+    n = 40
+    rng = np.random.default_rng(77)
+    audio = np.stack([synth.stream_pcm(s, 60 * 1024) for s in range(n)])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        eng = HipEngine(hpr, w, n_streams=n, **kw)
+        solo = [HipEngine(hpr, w, n_streams=1, **kw) for _ in range(6)]        # private single-stream engines for streams 0..5
+    if tiling is not None:
+        eng.set_gru_tiling(tiling)
+        for e1 in solo:
+            e1.set_gru_tiling(tiling)
+    pos = np.zeros(n, dtype=np.int64)
+    tol = TOL_BF16 if kw.get('gru_precision') == 'bf16' else 0.0
+    for call in range(60):
+        chunk = int(rng.choice([1024, 1024, 2048, 800]))
+        active = np.nonzero(rng.random(n) < 0.5)[0]
+        active = active[pos[active] + chunk <= audio.shape[1]]
+        if active.size == 0:
+            continue
+        rng.shuffle(active)
+        pcm = np.stack([audio[s, pos[s]:pos[s] + chunk] for s in active])
+        got = eng.update_subset(active, pcm)
+        assert np.isfinite(got).all()
+        for k, s in enumerate(active):
+            if s < len(solo):
+                want = solo[s].update(pcm[k][None])[0]
+                # one stream alone vs the same stream inside a tile of sixteen: same arithmetic per stream, same bits
+                assert abs(float(got[k]) - float(want)) <= tol, (call, s)
+            pos[s] += chunk
+    for s, e1 in enumerate(solo):
+        assert np.array_equal(e1.get_vectors()[0], eng.get_vectors()[s])
+        e1.close()
+    eng.close()
+
+
+def test_call_numbers_renumbered_before_they_wrap(stock_weights):
+    """Records carry the number of the call that wrote them; the count is renumbered in place at a threshold (default 0x7fff0000;
+    here 40, crossed several times) -- with streams that were idle across the renumbering."""
+    from mycroft_precise_amd._lib import HipEngine
+    n, n_up = 37, 120
+    pcm = _stream_batch(['tone_noise'] * n, n_up)
+    a = HipEngine(P.pr, stock_weights, n_streams=n)
+    b = HipEngine(P.pr, stock_weights, n_streams=n)
+    b.set_renumber_at(40)
+    odd, even = np.arange(1, n, 2), np.arange(0, n, 2)
+    for u in range(n_up):
+        want = a.update(pcm[u])
+        got = np.empty(n, np.float32)
+        # even streams in one call, odd streams in a later one: between the two, half of the records are one call "older"
+        got[even] = b.update_subset(even, pcm[u][even])
+        got[odd] = b.update_subset(odd, pcm[u][odd])
+        assert np.array_equal(got, want), u
+    for x, y in zip(a.stream_state(), b.stream_state()):
+        assert np.array_equal(x, y)
+    with pytest.raises(ValueError):
+        b.set_renumber_at(3)
+    a.close(); b.close()
+
+
+def test_subset_at_full_batch_costs_what_a_full_update_costs(stock_weights):
+    """4096 of 4096 streams through pe_update_subset_device: bit-identical to pe_update_device, and within a few
+    percent of its time -- the headline's fused launch with one extra load per stream."""
+    import torch
+    from mycroft_precise_amd._lib import HipEngine
+    B, n_res = 4096, 16
+    dev = torch.device('cuda', 0)
+    base = synth.batch_pcm(64, n_res)                                           # [n_res][64][1024]
+    pcm = torch.from_numpy(np.ascontiguousarray(np.tile(base, (1, B // 64, 1)))).to(dev)
+    ids = torch.arange(B, dtype=torch.int32, device=dev)
+    a = HipEngine(P.pr, stock_weights, n_streams=B)
+    b = HipEngine(P.pr, stock_weights, n_streams=B)
+    oa, ob = torch.zeros(B, device=dev), torch.zeros(B, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(eng, out, subset, n):
+        for i in range(n):
+            if subset:
+                eng.update_subset_device(ids.data_ptr(), B, pcm[i % n_res].data_ptr(), 1024, out.data_ptr(), st)
+            else:
+                eng.update_device(pcm[i % n_res].data_ptr(), 1024, out.data_ptr(), st)
+
+    for i in range(40):
+        run(a, oa, False, 1); run(b, ob, True, 1)
+        assert torch.equal(oa, ob), i
+    times = {}
+    for name, eng, out, subset in (('full', a, oa, False), ('subset', b, ob, True), ('full', a, oa, False), ('subset', b, ob, True)):
+        run(eng, out, subset, 1500)                                            # (also takes the GPU out of idle)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(); run(eng, out, subset, 1500); ev1.record(); ev1.synchronize()
+        times[name] = min(times.get(name, 1e9), ev0.elapsed_time(ev1) / 1500)
+    print('full %.2f us, subset of all %.2f us per update' % (1e3 * times['full'], 1e3 * times['subset']))
+    assert times['subset'] <= 1.06 * times['full'], times
+    # a quarter of the streams active: the call costs less than the full one (cost follows the active streams)
+    some = torch.arange(0, B, 4, dtype=torch.int32, device=dev)
+    osome = torch.zeros(B // 4, device=dev)
+    part = pcm[:, ::4].contiguous()
+    for i in range(200):
+        b.update_subset_device(some.data_ptr(), B // 4, part[i % n_res].data_ptr(), 1024, osome.data_ptr(), st)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for i in range(1000):
+        b.update_subset_device(some.data_ptr(), B // 4, part[i % n_res].data_ptr(), 1024, osome.data_ptr(), st)
+    ev1.record(); ev1.synchronize()
+    assert ev0.elapsed_time(ev1) / 1000 <= 1.05 * times['full']
+    a.close(); b.close()
+
+
 def test_bench_starts_its_own_ranks_and_delivers_per_step():
     """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's N = 1 command): bench.py re-executes itself
     under torch.distributed.run on 127.0.0.1 with a free port.  Both ranks on cuda:0 over gloo (PE_BENCH_SHARED_GPU=1: this
