@@ -42,7 +42,7 @@ struct pe_engine {
     int64_t device_bytes = 0;
     // streaming state: per stream two sides of (16-byte record, leftover PCM); a call that advances a stream reads its
     // current side and writes the other (pe_common.h: StreamRec) -- streams that take no part in a call are not touched
-    StreamRec* rec = nullptr;                // [2][n_padded]
+    StreamRec* rec = nullptr;                // [n_padded][2 sides]
     int16_t* carry = nullptr;                // [2][n_padded][carry_cap]
     uint32_t call_no = 1;                    // number of the last call that wrote records (readers of later launches pass call_no + 1)
     uint32_t renumber_at = 0x7fff0000u;      // call number at which every record is renumbered and the count restarts (pe_set_renumber_at: tests)
@@ -1741,8 +1741,8 @@ int pe_get_stream_state(pe_engine* e, int32_t* q_out, uint32_t* computed_out, ui
     PE_HIP(e, hipMemcpy(host.data(), e->rec, host.size() * sizeof(StreamRec), hipMemcpyDeviceToHost));
     const uint32_t call = e->call_no + 1u;
     for (int s = 0; s < e->n_streams; ++s) {
-        const StreamRec& r0 = host[(size_t)s];
-        const StreamRec& r1 = host[(size_t)e->n_padded + s];
+        const StreamRec& r0 = host[rec_at((uint32_t)e->n_padded, s, 0)];
+        const StreamRec& r1 = host[rec_at((uint32_t)e->n_padded, s, 1)];
         const StreamRec& c = (call - r1.wcall) - 1u < (call - r0.wcall) - 1u ? r1 : r0;
         if (q_out) q_out[s] = c.q;
         if (computed_out) computed_out[s] = c.kc;

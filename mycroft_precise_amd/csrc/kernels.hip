@@ -811,8 +811,8 @@ __global__ void scatter_kernel(const GatherArgs a) {
     if (a.ring_bf16) reinterpret_cast<__bf16*>(const_cast<float*>(a.ring))[at] = (__bf16)v;
     else const_cast<float*>(a.ring)[at] = v;
     if (f == 0 && t == 0) {       // side 0 becomes the current one (stamped with this call), side 1 the older
-        a.st.rec[s] = StreamRec{0, (uint32_t)a.n_features, (uint32_t)a.n_features, a.st.call};
-        a.st.rec[(size_t)a.st.n_padded + s] = StreamRec{0, (uint32_t)a.n_features, (uint32_t)a.n_features, a.st.call - 1u};
+        a.st.rec[rec_at(a.st.n_padded, s, 0)] = StreamRec{0, (uint32_t)a.n_features, (uint32_t)a.n_features, a.st.call};
+        a.st.rec[rec_at(a.st.n_padded, s, 1)] = StreamRec{0, (uint32_t)a.n_features, (uint32_t)a.n_features, a.st.call - 1u};
     }
 }
 
@@ -830,8 +830,8 @@ __global__ void renumber_kernel(const StreamState st, const int n_padded) {
     if (s >= n_padded) return;
     const RecPair both = rec_request(st.rec, st.n_padded, s);
     const int side = rec_side(both, st.call);
-    st.rec[(size_t)side * st.n_padded + s].wcall = 2u;
-    st.rec[(size_t)(side ^ 1) * st.n_padded + s].wcall = 1u;
+    st.rec[rec_at(st.n_padded, s, side)].wcall = 2u;
+    st.rec[rec_at(st.n_padded, s, side ^ 1)].wcall = 1u;
 }
 hipError_t launch_renumber(const StreamState& st, int n_padded, hipStream_t s) {
     hipLaunchKernelGGL(renumber_kernel, dim3((n_padded + 255) / 256), dim3(256), 0, s, st, n_padded);
@@ -844,8 +844,8 @@ __global__ void clear_kernel(const ClearArgs a) {
     if (s >= a.n_streams) return;
     if (a.mask && !a.mask[s]) return;
     if (threadIdx.x == 0) {         // side 0 becomes the current one (stamped with this call), side 1 the older
-        a.st.rec[s] = StreamRec{0, 0u, 0u, a.st.call};
-        a.st.rec[(size_t)a.st.n_padded + s] = StreamRec{0, 0u, 0u, a.st.call - 1u};
+        a.st.rec[rec_at(a.st.n_padded, s, 0)] = StreamRec{0, 0u, 0u, a.st.call};
+        a.st.rec[rec_at(a.st.n_padded, s, 1)] = StreamRec{0, 0u, 0u, a.st.call - 1u};
         if (a.activation) a.activation[s] = 0;
     }
     const long long tile = s / kTileStreams;

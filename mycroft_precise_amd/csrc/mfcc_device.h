@@ -188,7 +188,7 @@ __device__ __forceinline__ void mfcc_book_tile(const MfccStreamArgs<R>& a, const
             if (m >= geo.window) ke += 1u + (uint32_t)by_hop(m - geo.window);
             if (a.ke_hist) a.ke_hist[(size_t)u * a.n_padded + sid] = ke;
         }
-        a.st.rec[(size_t)(side ^ 1) * a.st.n_padded + sid] = StreamRec{qu, kcu, ke, a.st.call};      // one 16-byte store
+        a.st.rec[rec_at(a.st.n_padded, sid, side ^ 1)] = StreamRec{qu, kcu, ke, a.st.call};      // one 16-byte store
     }
 }
 

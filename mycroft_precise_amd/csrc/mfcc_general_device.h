@@ -503,7 +503,7 @@ __device__ __forceinline__ void general_stream(const GeneralStreamArgs<R>& a, R*
             if (mm >= geo.window) ke += 1u + (uint32_t)((mm - geo.window) / hop);
             if (a.ke_hist) a.ke_hist[(size_t)u * a.n_padded + sid] = ke;
         }
-        a.st.rec[(size_t)(side ^ 1) * a.st.n_padded + sid] = StreamRec{qu, kcu, ke, a.st.call};
+        a.st.rec[rec_at(a.st.n_padded, sid, side ^ 1)] = StreamRec{qu, kcu, ke, a.st.call};
     }
 }
 

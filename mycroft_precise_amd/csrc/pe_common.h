@@ -62,8 +62,12 @@ struct FastDiv {
 // the host renumbers all records long before: engine.hip renormalize.)
 struct __attribute__((aligned(16))) StreamRec { int32_t q; uint32_t kc, ke, wcall; };
 
+// where side `side` of stream s sits: the two sides of a stream are neighbours (32 bytes, one cache line: a reader's two loads
+// miss together).  Measured against the sides n_padded records apart: no difference at 4096 streams (profiles/round6/r6e_*)
+__host__ __device__ __forceinline__ size_t rec_at(const uint32_t, const long long s, const int side) { return 2 * (size_t)s + (size_t)side; }
+
 struct StreamState {
-    StreamRec* rec;         // [2][n_padded]
+    StreamRec* rec;         // [n_padded][2 sides]
     int16_t* carry;         // [2][n_padded][carry_cap] leftover PCM of the one frame that straddles two calls
     uint32_t n_padded;      // records per side
     uint32_t call;          // number of this engine call (readers: records with wcall == call are not yet valid)
@@ -72,8 +76,8 @@ struct StreamState {
 struct RecPair { StreamRec r0, r1; };
 __device__ __forceinline__ RecPair rec_request(const StreamRec* rec, const uint32_t n_padded, const long long s) {
     RecPair p;              // two independent 16-byte loads: one round trip
-    p.r0 = rec[s];
-    p.r1 = rec[(size_t)n_padded + s];
+    p.r0 = rec[rec_at(n_padded, s, 0)];
+    p.r1 = rec[rec_at(n_padded, s, 1)];
     return p;
 }
 // side whose record is current for a reader of call `call`: smallest non-zero distance call - wcall
@@ -183,7 +187,7 @@ struct GruArgs {
     // n_streams counts the windows of THIS launch; window v belongs to stream ids[v] (pe_update_subset) or, ids == null, to
     // stream v: records and ring rows are addressed by the stream, out[] by v
     const int32_t* ids;
-    const StreamRec* rec;   // [2][n_padded]
+    const StreamRec* rec;   // [n_padded][2 sides]
     uint32_t n_padded, call;
     const uint32_t* ke_plain;   // non-null: the emitted-frame counter of stream s is ke_plain[s] (pe_update_many: one row of the
                                 // per-update history) and the records are not read

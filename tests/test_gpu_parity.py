@@ -314,11 +314,8 @@ def test_gru_kernel_shapes_agree_bitwise(stock_weights):
             assert np.array_equal(o, outs[0]), u
     with pytest.raises(ValueError):
         engines[0].engine.set_gru_waves(3)
-    # 16 = sixteen LANES per stream without matrix cores: measured, rejected, moved out of the product
-    # library (tools/micro/gru_dpp_device.h, -DPE_TUNING builds only): the product refuses it loudly
-    d = BatchedListener(stock_weights, n)
-    with pytest.raises(NotImplementedError):
-        d.engine.set_gru_waves(16)
+    with pytest.raises(ValueError):          # (16 = the sixteen-lanes-per-stream experiment of round 2: gone since round 6)
+        engines[0].engine.set_gru_waves(16)
 
 
 def test_input_projection_rows_agree_with_recomputed_projection(stock_weights):
