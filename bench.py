@@ -6,8 +6,10 @@ bench.py -- windows/sec of the MI355X wake-word hot path (BASELINE.json metric).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (pe_update_device: int16 PCM chunk -> MFCC frames -> feature
-window -> GRU -> probability) over one batch of synthetic streams: one 1024-sample chunk for each
+A "step" is one pass of the hot path (pe_update_device_keep: int16 PCM chunk -> MFCC frames -> feature
+window -> GRU -> probability; the PCM slabs are resident and outlive the calls, so the leftover samples of
+Listener.update_vectors stay in them -- `--keep 0` / the line's "carry_copy_path": pe_update_device, which copies
+them to the engine's carry in every call, same bits) over one batch of synthetic streams: one 1024-sample chunk for each
 of ``--streams`` (4096) streams per GPU = BASELINE.json configs[1] at N=1 and configs[2] at N=8
 (weak scaling, streams sharded across ranks, no collective on the data path; the per-step
 probabilities of the timed region are gathered to rank 0 once at its end, inside the timing).
@@ -282,7 +284,7 @@ def wait_for_gpu():
 
 
 def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_precision, ring_precision, steps, warmup, n_res, tol,
-                 params_kw=None, roofline_kind=None, gru_tiling=-1):
+                 params_kw=None, roofline_kind=None, gru_tiling=-1, keep=False):
     """One non-headline configuration on this GPU (N = 1 only, after the headline's timed region): the same step
     definition, its own roofline object, and a parity spot-check of the timed region's last probabilities against
     the oracle (the checker: never inside a timed region) on the first 256 streams (32 for the wide network).
@@ -290,7 +292,8 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
     roofline_kind: 'hbm' (fused launch vs HBM), 'mfma' (network launch vs fp32 MFMA), 'mfma_fused' (fused launch vs fp32
     MFMA: the capacity point, where the update IS the network + MFCC roles of one launch), 'mfma_update_x3' (the same for
     the float32 network on the bf16 pipe, whose update is two launches), 'hbm_mfcc' (MFCC launch vs HBM).
-    gru_tiling: pe_set_gru_tiling (-1 = the engine's own choice)."""
+    gru_tiling: pe_set_gru_tiling (-1 = the engine's own choice).
+    keep: pe_update_device_keep -- the resident slabs outlive every call, so the leftover samples stay in them."""
     import warnings
     from oracle import listener as oracle_listener
     hpr, opr = pr, None
@@ -316,7 +319,7 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
 
     def run(first, n):
         for i in range(n):
-            engine.update_device(pcm.data_ptr() + ((first + i) % n_res) * chunk_bytes, CHUNK, out.data_ptr(), st)
+            engine.update_device(pcm.data_ptr() + ((first + i) % n_res) * chunk_bytes, CHUNK, out.data_ptr(), st, keep=keep)
 
     run(0, warmup)
     torch.cuda.synchronize()
@@ -389,6 +392,7 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
                                    {0: 'classic tiling, v_mfma_f32_16x16x4_f32', 1: 're-tiled stock width, v_mfma_f32_16x16x4_f32',
                                     2: 'float32 operands as 3 x bf16 pieces, 6 piece products on v_mfma_f32_16x16x32_bf16, float32 accumulate / gates / state'}[tiling_used]),
                       'resident_pcm_mb': n_res * chunk_bytes / 1e6},
+           'entry_point': 'pe_update_device_keep' if keep else 'pe_update_device',
            'stage_ms': {'update_back_to_back': update_ms, 'mfcc_launch_alone': mfcc_ms, 'network_launch_alone': gru_ms},
            'roofline': roof,
            'parity': {'max_abs_err': err, 'tol': tol, 'streams_checked': n_check, 'ok': bool(err <= tol),
@@ -554,6 +558,9 @@ def main():
     ap.add_argument('--units', default='20', help="GRU widths, e.g. 20 (stock, default) or 256,256 (BASELINE configs[3])")
     ap.add_argument('--gru-tiling', type=int, default=-1, help='pe_set_gru_tiling: -1 automatic (default), 0 classic, 1 re-tiled stock width, 2 float32 products on the bf16 pipe')
     ap.add_argument('--gru-waves', type=int, default=0, help='pe_set_gru_waves: 0 automatic (default), 1 or 4 waves per tile')
+    ap.add_argument('--keep', type=int, default=1, choices=[0, 1],
+                    help='1 (default): every update goes through pe_update_device_keep -- the PCM slabs are resident in HBM and outlive the calls, so the '
+                         'leftover samples stay in them; 0: pe_update_device (the engine copies them to its carry in every call)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-configs', action='store_true', help='skip the non-headline BASELINE configurations (wide 256x2, bf16) after the headline')
     ap.add_argument('--only-extra', default='', help='run only the extra configurations whose name contains this text')
@@ -629,12 +636,13 @@ def main():
 
     # which slab of the resident PCM every update since the engine's creation was fed (headline_parity replays its tail)
     fed = []
+    keep = bool(args.keep)
 
     def run(first_step, n, out_rows):
         for i in range(n):
             u = (first_step + i) % n_res
             engine.update_device(pcm_base + u * chunk_bytes, CHUNK,
-                                 probs_base + i * B * 4 if out_rows else scratch.data_ptr(), stream)
+                                 probs_base + i * B * 4 if out_rows else scratch.data_ptr(), stream, keep=keep)
 
     # The launch the timed region uses (MFCC || GRU roles in one kernel): HIP events on the launch
     # stream bracketing a run of launches (per-launch events would add ~2.5 us of their own to a 22 us
@@ -644,7 +652,7 @@ def main():
         ev0.record()
         for i in range(n):
             u = (warmup + steps + i) % n_res
-            engine.update_device(pcm_base + u * chunk_bytes, CHUNK, scratch.data_ptr(), stream)
+            engine.update_device(pcm_base + u * chunk_bytes, CHUNK, scratch.data_ptr(), stream, keep=keep)
         ev1.record()
         ev1.synchronize()
         return ev0.elapsed_time(ev1) / n
@@ -726,7 +734,7 @@ def main():
         works, evs = [], []
         for i in range(steps):
             u = (warmup + i) % n_res
-            engine.update_device(pcm_base + u * chunk_bytes, CHUNK, probs_base + i * B * 4, stream)
+            engine.update_device(pcm_base + u * chunk_bytes, CHUNK, probs_base + i * B * 4, stream, keep=keep)
             if mode == 'host' or (mode == 'rccl' and shared_gpu) or world == 1:
                 ev = torch.cuda.Event()
                 ev.record()                                       # behind update i on the launch stream
@@ -766,6 +774,23 @@ def main():
                     'ms_per_step': 1e3 * dt / steps, 'value': n_global * steps / dt, 'unit': 'windows/s',
                     'final_gather_ms_per_step': 1e3 * elapsed / steps, 'delivered_equals_device': delivered_ok}
 
+    # ---- the same K steps through pe_update_device (the leftover samples copied to the engine's carry in every call): the figure
+    #      a caller gets whose chunks do NOT outlive the call -- reported beside the headline, N = 1 only
+    carry_path = None
+    if keep and world == 1:
+        def plain(first, n):
+            for i in range(n):
+                engine.update_device(pcm_base + ((first + i) % n_res) * chunk_bytes, CHUNK, scratch.data_ptr(), stream, keep=False)
+        plain(warmup + steps, max(warmup, 5))            # (the first of them moves the kept leftovers to the carry)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        plain(warmup + steps + max(warmup, 5), steps)
+        wait_for_gpu()
+        dt2 = time.perf_counter() - t2
+        carry_path = {'entry_point': 'pe_update_device', 'value': B * steps / dt2, 'unit': 'windows/s', 'ms_per_step': 1e3 * dt2 / steps,
+                      'note': 'same engine, same slabs, %d steps right after the timed region: every call copies the leftover samples into the '
+                              "engine's carry (bit-identical results; tests/test_gpu_parity.py::test_kept_leftovers_*)" % steps}
+
     # ---- instrumented passes: HIP-event time per launch, on the launch stream --------------------
     def timed_pass(fused):
         engine.set_fused(fused)
@@ -773,7 +798,7 @@ def main():
         first, second = [], []
         for i in range(min(steps, 100)):
             u = (warmup + steps + i) % n_res
-            engine.update_device(pcm_base + u * chunk_bytes, CHUNK, scratch.data_ptr(), stream)
+            engine.update_device(pcm_base + u * chunk_bytes, CHUNK, scratch.data_ptr(), stream, keep=keep)
             a, b = engine.last_timing()
             first.append(a)
             second.append(b)
@@ -855,6 +880,11 @@ def main():
                     dict(name='capacity: stock GRU fp32 + f64 MFCC, batch=65536 streams on 1 MI355X (max concurrent real-time streams)', units=(20,), streams=65536,
                          mfcc_precision='f64', gru_precision='f32', ring_precision='f32', steps=100, warmup=40, n_res=32, tol=1e-4,
                          roofline_kind='mfma_update_x3'),
+                    # ... the same point through pe_update_device_keep: the resident slabs outlive the calls, the leftover samples stay
+                    # in them (no carry copy: ~200 of the ~390 bytes the MFCC launch writes per stream)
+                    dict(name='capacity, leftovers kept in the resident chunks (pe_update_device_keep), batch=65536 streams', units=(20,), streams=65536,
+                         mfcc_precision='f64', gru_precision='f32', ring_precision='f32', steps=100, warmup=40, n_res=32, tol=1e-4,
+                         roofline_kind='mfma_update_x3', keep=True),
                     # ... and the same point forced onto the f32-input MFMAs (classic tiling, fused launch) for comparison
                     dict(name='capacity, classic tiling forced (pe_set_gru_tiling 0: v_mfma_f32_16x16x4_f32, fused launch), batch=65536 streams', units=(20,), streams=65536,
                          mfcc_precision='f64', gru_precision='f32', ring_precision='f32', steps=100, warmup=40, n_res=32, tol=1e-4,
@@ -941,6 +971,7 @@ def main():
                                       'stock' if stock else 'wide %s' % 'x'.join(map(str, units)), args.gru_precision, B,
                                       ' (batch=%d streams sharded across %d x MI355X, RCCL gather over xGMI)' % (n_global, world) if world > 1 else ''),
                        'streams_per_gpu': B, 'global_streams': n_global, 'chunk_samples': CHUNK,
+                       'entry_point': 'pe_update_device_keep' if keep else 'pe_update_device',
                        'gru': 'H=%s, T=29, F=13, ' % args.units + ('f32 operands as 3 x bf16 pieces, 6 piece products on bf16 MFMA 16x16x32, f32 accumulate / gates / state' if x3 else 'f32 MFMA 16x16x4' if args.gru_precision == 'f32' else 'bf16 MFMA 16x16x32, f32 accumulate'),
                        'mfcc_dtype': args.mfcc_precision, 'feature_rows': args.ring_precision,
                        'parallelism': 'streams sharded over %d rank(s), final RCCL gather of probabilities to rank 0' % world},
@@ -994,6 +1025,8 @@ def main():
             line['time_batched'] = time_batched
         if per_step is not None:
             line['per_step_delivery'] = per_step
+        if carry_path is not None:
+            line['carry_copy_path'] = carry_path
         if cpu is not None:
             line['cpu_baseline'] = cpu
         if cpu_b1 is not None:

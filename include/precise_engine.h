@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PE_ABI_VERSION 6
+#define PE_ABI_VERSION 7
 
 typedef enum pe_status {
     PE_OK = 0,
@@ -123,6 +123,18 @@ int pe_clear(pe_engine* e, const uint8_t* mask);
 int pe_update(pe_engine* e, const int16_t* pcm_host, int32_t chunk_samples, float* raw_out_host);
 int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples,
                      float* raw_out_dev, void* hip_stream);
+
+/* The same update for a caller whose device chunks OUTLIVE the call (a ring of resident PCM slabs, a capture buffer that is
+ * written ahead).  Listener.update_vectors keeps the samples that do not yet fill a frame (network_runner.py:127-131: the
+ * `leftover` of chop_array); pe_update_device copies them into the engine's own carry, every call, for every stream.  Here they
+ * stay where they lie -- in pcm_dev -- and the NEXT call cuts the head of its first frame from there.  The promise: pcm_dev
+ * stays allocated and unchanged until the work of the next call that advances or clears streams on this engine has completed
+ * on its stream (or the engine is destroyed).  Any entry point may follow (a call of another style first moves the leftovers
+ * to the carry in one small launch); results are bit-identical to pe_update_device.  Chunks that cannot hold a leftover (odd
+ * length, fewer than frame_len - 1 samples, an address that is not 4-byte aligned, a non-stock front end) are taken exactly
+ * as pe_update_device takes them.  pe_update_async works this way by itself: its device chunks are the engine's own. */
+int pe_update_device_keep(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples,
+                          float* raw_out_dev, void* hip_stream);
 
 /* Streams that advance independently.  Every reference Listener consumes chunks at its own pace (network_runner.py:125-146;
  * one engine process per client, runner/precise_runner/runner.py:54-67, :232-243); a server that multiplexes many clients on

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PE_LIB') or os.path.join(HERE, 'libprecise_engine.so')
 
 PE_OK, PE_ERR_INVALID, PE_ERR_HIP, PE_ERR_UNSUPPORTED, PE_ERR_NOMEM, PE_ERR_EOF = range(6)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class PeParams(C.Structure):
@@ -52,6 +52,7 @@ EXPORTS = {
     'pe_clear': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pe_update': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     'pe_update_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'pe_update_device_keep': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'pe_update_subset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     'pe_update_subset_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'pe_set_renumber_at': (C.c_int, [C.c_void_p, C.c_uint32]),
@@ -408,8 +409,11 @@ class HipEngine:
             self._check(self._lib.pe_clear(self._h, m.ctypes.data))
 
     # -- device entry points (pointers are ints, e.g. torch.Tensor.data_ptr()) ---------------
-    def update_device(self, pcm_ptr: int, chunk_samples: int, out_ptr: int, stream: int = 0):
-        self._check(self._lib.pe_update_device(self._h, pcm_ptr, chunk_samples, out_ptr, stream))
+    def update_device(self, pcm_ptr: int, chunk_samples: int, out_ptr: int, stream: int = 0, keep: bool = False):
+        """keep=True: the caller promises the chunks at pcm_ptr stay alive and unchanged until the next update's work is
+        done -- the leftover samples then stay there instead of being copied to the engine's carry (pe_update_device_keep)."""
+        fn = self._lib.pe_update_device_keep if keep else self._lib.pe_update_device
+        self._check(fn(self._h, pcm_ptr, chunk_samples, out_ptr, stream))
 
     def update_vectors_device(self, pcm_ptr: int, chunk_samples: int, feats_ptr: int = 0, stream: int = 0):
         self._check(self._lib.pe_update_vectors_device(self._h, pcm_ptr, chunk_samples, feats_ptr or None, stream))

@@ -44,6 +44,11 @@ struct pe_engine {
     // current side and writes the other (pe_common.h: StreamRec) -- streams that take no part in a call are not touched
     StreamRec* rec = nullptr;                // [n_padded][2 sides]
     int16_t* carry = nullptr;                // [2][n_padded][carry_cap]
+    // leftovers kept in place (pe_update_device_keep / pe_update_async): non-null = the chunks of the last call,
+    // [n_streams][kept_chunk], still hold every stream's leftover and the carry was NOT written; any call of another style
+    // first copies them into the carry (flush_kept).  call_head / call_keep: what the launches of the call being built take.
+    const int16_t* kept = nullptr; int kept_chunk = 0;
+    const int16_t* call_head = nullptr; int call_head_chunk = 0; bool call_keep = false;
     uint32_t call_no = 1;                    // number of the last call that wrote records (readers of later launches pass call_no + 1)
     uint32_t renumber_at = 0x7fff0000u;      // call number at which every record is renumbered and the count restarts (pe_set_renumber_at: tests)
     bool fused = true;      // MFCC || GRU in one launch when the chunk size allows it
@@ -721,6 +726,7 @@ MfccStreamArgs<R> mfcc_args(const pe_engine* e, const int16_t* pcm_dev, int chun
     a.pcm_pairs_ok = ((chunk & 1) == 0) && ((reinterpret_cast<uintptr_t>(pcm_dev) & 3u) == 0);
     a.ids = ids;
     a.st = state_of(e, call);
+    a.head = ids ? nullptr : e->call_head; a.head_chunk = e->call_head_chunk; a.keep = (!ids && e->call_keep) ? 1 : 0;
     a.ring = e->ring; a.ring_bf16 = e->prm.ring_precision;
     a.proj_ring = e->proj_on ? e->proj_ring : nullptr;
     a.n_updates = 1; a.ke_hist = nullptr; a.n_padded = e->n_padded;
@@ -918,6 +924,22 @@ int check_chunk(pe_engine* e, const void* pcm, int chunk) {
     return PE_OK;
 }
 
+// Leaving the keep style: the leftovers that still lie in the last call's chunks go to the carry (one small launch on the
+// stream of the call that needs them there), and the engine forgets the chunks.
+int flush_kept(pe_engine* e, hipStream_t s) {
+    if (!e->kept) return PE_OK;
+    PE_HIP(e, launch_materialize_carry(state_of(e, e->call_no + 1u), e->kept, e->kept_chunk, e->n_streams, s));
+    e->kept = nullptr; e->kept_chunk = 0;
+    return PE_OK;
+}
+
+// May the leftover of an update of these chunks stay in them?  The stock front end (the general one keeps its own carry
+// arithmetic), whole sample pairs (the frame role's dword loads), and a chunk that holds any leftover (< frame_len samples).
+bool keep_eligible(const pe_engine* e, const int16_t* pcm_dev, int chunk) {
+    return !e->general && (chunk & 1) == 0 && (reinterpret_cast<uintptr_t>(pcm_dev) & 3u) == 0 && chunk >= frame_len_of(e->prm) - 1
+        && chunk >= e->carry_cap - 1;
+}
+
 // True when no frame computed by an update of `chunk` samples can become visible in that same
 // update (it needs window - frame_len more samples), so the network does not depend on it.
 bool can_fuse(const pe_engine* e, int chunk) {
@@ -942,10 +964,18 @@ bool can_fuse(const pe_engine* e, int chunk) {
 
 // ids / n_active: the streams that take part (pe_update_subset; device pointer, PCM rows and outputs in that order), or
 // null / 0 = every stream
+// keep: the caller promises that pcm_dev stays alive and unchanged until the NEXT state-moving call's work has completed
+// (pe_update_device_keep; pe_update_async: the engine's own ring of device buffers) -- the leftover then stays in the chunk
 int do_update(pe_engine* e, const int16_t* pcm_dev, int chunk, float* raw_out_dev, float* feats_out_dev,
-              hipStream_t s, const int32_t* ids = nullptr, int n_active = 0) {
+              hipStream_t s, const int32_t* ids = nullptr, int n_active = 0, bool keep = false) {
     int rc;
     const bool t = e->timing;
+    const bool keep_call = keep && !ids && keep_eligible(e, pcm_dev, chunk);
+    if (!keep_call && (rc = flush_kept(e, s))) return rc;
+    e->call_head = keep_call ? e->kept : nullptr; e->call_head_chunk = e->kept_chunk; e->call_keep = keep_call;
+    // (whatever happens below, the launches of later calls must not inherit this call's style)
+    struct Reset { pe_engine* e; ~Reset() { e->call_head = nullptr; e->call_head_chunk = 0; e->call_keep = false; } } reset{e};
+    e->kept = keep_call ? pcm_dev : nullptr; e->kept_chunk = keep_call ? chunk : 0;
     uint32_t call = 0;
     if ((rc = begin_state_call(e, s, &call))) return rc;
     if (t) { PE_HIP(e, hipEventRecord(e->ev[0], s)); }
@@ -1171,6 +1201,9 @@ int pe_clear(pe_engine* e, const uint8_t* mask_host) {
         PE_HIP(e, hipMemcpy(e->st_mask.p, mask_host, (size_t)e->n_streams, hipMemcpyHostToDevice));
         mask_dev = static_cast<const uint8_t*>(e->st_mask.p);
     }
+    // (a masked clear leaves the other streams' leftovers where they are: out of kept chunks first; a full clear empties them)
+    if (mask_dev) { int frc = flush_kept(e, nullptr); if (frc) return frc; }
+    else { e->kept = nullptr; e->kept_chunk = 0; }
     uint32_t call = 0;
     { int crc = begin_state_call(e, nullptr, &call); if (crc) return crc; }
     ClearArgs a{e->n_padded, e->ring_slots, mask_dev, state_of(e, call), e->ring, e->prm.ring_precision, e->activation,
@@ -1190,6 +1223,20 @@ int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, float*
     if (!raw_out_dev) return fail(e, PE_ERR_INVALID, "raw_out_dev is null");
     note_user_stream(e, stream);
     return do_update(e, pcm_dev, chunk, raw_out_dev, nullptr, static_cast<hipStream_t>(stream));
+}
+
+// The same update for a caller whose chunks outlive the call (a ring of resident PCM slabs, a capture buffer written ahead):
+// the samples left over toward the next frame stay in pcm_dev instead of being copied to the engine's carry, and the next
+// call reads the head of its first frame from there.  Any other entry point may follow: it finds the leftovers (one small
+// copy launch moves them to the carry first).  Falls back to pe_update_device for chunks that cannot hold a leftover.
+int pe_update_device_keep(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, float* raw_out_dev, void* stream) {
+    int rc = check_chunk(e, pcm_dev, chunk);
+    if (rc) return rc;
+    PE_HIP(e, hipSetDevice(e->device));
+    PE_DRAIN(e);
+    if (!raw_out_dev) return fail(e, PE_ERR_INVALID, "raw_out_dev is null");
+    note_user_stream(e, stream);
+    return do_update(e, pcm_dev, chunk, raw_out_dev, nullptr, static_cast<hipStream_t>(stream), nullptr, 0, true);
 }
 
 int pe_update_vectors_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, float* feats_out_dev, void* stream) {
@@ -1327,10 +1374,14 @@ int pe_update_async(pe_engine* e, const int16_t* pcm_host, int32_t chunk, float*
     // free, and the error goes to the caller (the streams' state may then be one update ahead of what was delivered --
     // the message says so; pe_clear restarts the streams).
     auto enqueue = [&]() -> int {
+        // this slot's device chunk was the `head` of the update AFTER the one the slot last carried (the leftovers stay in the
+        // chunks: do_update(..., keep)): that update must be through before the copy overwrites it
+        pe_engine::AsyncSlot& reader = e->aslot[(e->async_next + 1) % pe_engine::kAsyncDepth];
+        if (reader.busy) PE_HIP(e, hipStreamWaitEvent(e->s_copy, reader.done, 0));
         PE_HIP(e, hipMemcpyAsync(sl.dev_in.p, pcm_host, pcm_bytes, hipMemcpyHostToDevice, e->s_copy));
         PE_HIP(e, hipEventRecord(sl.copied, e->s_copy));
         PE_HIP(e, hipStreamWaitEvent(e->s_compute, sl.copied, 0));
-        int urc = do_update(e, static_cast<const int16_t*>(sl.dev_in.p), chunk, static_cast<float*>(sl.dev_out.p), nullptr, e->s_compute);
+        int urc = do_update(e, static_cast<const int16_t*>(sl.dev_in.p), chunk, static_cast<float*>(sl.dev_out.p), nullptr, e->s_compute, nullptr, 0, true);
         if (urc) return urc;
         PE_HIP(e, hipMemcpyAsync(sl.direct_out ? raw_out_host : sl.pin_out, sl.dev_out.p, out_bytes, hipMemcpyDeviceToHost, e->s_compute));
         PE_HIP(e, hipEventRecord(sl.done, e->s_compute));
@@ -1637,6 +1688,7 @@ int pe_update_many_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk, i
     if (e->prm.n_features + pending + frames > e->ring_slots) return fail(e, PE_ERR_INVALID, "reserved ring too small for %d updates of %d samples", n_updates, chunk);
     hipStream_t s = static_cast<hipStream_t>(stream);
     note_user_stream(e, stream);
+    if ((rc = flush_kept(e, s))) return rc;
     uint32_t call = 0;
     if ((rc = begin_state_call(e, s, &call))) return rc;
     if (e->general) {

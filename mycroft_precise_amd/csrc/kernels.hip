@@ -833,6 +833,23 @@ __global__ void renumber_kernel(const StreamState st, const int n_padded) {
     st.rec[rec_at(st.n_padded, s, side)].wcall = 2u;
     st.rec[rec_at(st.n_padded, s, side ^ 1)].wcall = 1u;
 }
+// leaving the keep style (MfccStreamArgs::head): 16 lanes per stream copy its leftover -- the last q samples of its row of the
+// kept chunks -- into its current carry side (a rare launch: one per switch of calling styles)
+__global__ __launch_bounds__(256) void materialize_carry_kernel(const StreamState st, const int16_t* head, const int head_chunk, const int n_streams) {
+    const int s = blockIdx.x * 16 + (threadIdx.x >> 4), r = threadIdx.x & 15;
+    if (s >= n_streams) return;
+    const RecPair both = rec_request(st.rec, st.n_padded, s);
+    const int side = rec_side(both, st.call);
+    const int q = side ? both.r1.q : both.r0.q;
+    const int16_t* const src = head + (size_t)s * head_chunk + (head_chunk - q);
+    int16_t* const dst = st.carry + ((size_t)side * st.n_padded + (size_t)s) * kCarryCap;
+    for (int i = r; i < q; i += 16) dst[i] = src[i];
+}
+hipError_t launch_materialize_carry(const StreamState& st, const int16_t* head, int head_chunk, int n_streams, hipStream_t s) {
+    hipLaunchKernelGGL(materialize_carry_kernel, dim3((n_streams + 15) / 16), dim3(256), 0, s, st, head, head_chunk, n_streams);
+    return hipGetLastError();
+}
+
 hipError_t launch_renumber(const StreamState& st, int n_padded, hipStream_t s) {
     hipLaunchKernelGGL(renumber_kernel, dim3((n_padded + 255) / 256), dim3(256), 0, s, st, n_padded);
     return hipGetLastError();

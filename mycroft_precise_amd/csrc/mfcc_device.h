@@ -140,7 +140,9 @@ __device__ __forceinline__ void mfcc_book_tile(const MfccStreamArgs<R>& a, const
     // issues 16, and a quarter of its address arithmetic (round 5: the role was 55 of ~500 vector instructions per stream and
     // update of the launch, profiles/round5/r5h_mfcc_quad.log).
     const int vb1 = nnew * hop;
-    if (U == 1 && C >= 8 && __all(!fast ? 0 : (qn <= 0 || vb1 >= q))) {
+    if (a.keep) {
+        // the leftover stays in this call's chunk (the next call's `head`): nothing to move
+    } else if (U == 1 && C >= 8 && __all(!fast ? 0 : (qn <= 0 || vb1 >= q))) {
         struct __attribute__((packed, aligned(4))) Pcm8 { int d[4]; };
         const int16_t* src = base + (vb1 - q);                   // sample 0 of the leftover
         const int full8 = qn > 0 ? (qn & ~7) : 0;                // samples covered by whole eights

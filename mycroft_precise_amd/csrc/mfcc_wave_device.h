@@ -535,8 +535,12 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
     auto load_counters = [&]() {
         const int s = base + lane;
         const int sc = s < s_end ? s : 0;                       // (unconditional loads: see wave_tables_issue)
-        const int sid = a.ids ? a.ids[sc] : sc;
-        const RecPair both = rec_request(a.st.rec, a.st.n_padded, sid);
+        // (two requests, one per branch: a stream id that is either loaded or computed would be waited for at the join of the
+        //  branches -- together with everything else in flight, the table image included -- before the records could be requested)
+        int sid;
+        RecPair both;
+        if (a.ids) { sid = a.ids[sc]; both = rec_request(a.st.rec, a.st.n_padded, sid); }
+        else { sid = sc; both = rec_request(a.st.rec, a.st.n_padded, sc); asm volatile("; streams in order"); }   // (the marker keeps the compiler from merging the two requests back into one behind the join)
         const int side = rec_side(both, a.st.call);
         vq = side ? both.r1.q : both.r0.q; vkc = (int)(side ? both.r1.kc : both.r0.kc);
         vq = s < s_end ? vq : 0; vkc = s < s_end ? vkc : 0;
@@ -565,7 +569,10 @@ __device__ __forceinline__ void mfcc_frame_tasks(const MfccStreamArgs<R>& a, con
         const int ss = __builtin_amdgcn_readlane(vss, i);
         const int sid = ss >> 1;                              // the stream: leftover PCM, ring rows
         const int tile = sid >> 4, j = sid & 15;
-        f.car = a.st.carry + ((size_t)(ss & 1) * a.st.n_padded + (size_t)sid) * kCarryCap;
+        // the q samples in front of the chunk: the stream's current carry side -- or the tail of its row of the previous
+        // call's chunks where those were kept (car[v], v < q, never dereferenced when q <= 0)
+        f.car = a.head ? a.head + (size_t)s * a.head_chunk + (a.head_chunk - q)
+                       : a.st.carry + ((size_t)(ss & 1) * a.st.n_padded + (size_t)sid) * kCarryCap;
         f.vb = kb * hop; f.q = q;
         const int w0 = f.vb - q;
         int u0 = 0;

@@ -112,6 +112,14 @@ struct MfccStreamArgs {
     // to stream v.  State, leftover PCM and ring rows are addressed by the stream, PCM rows and outputs by v.
     const int32_t* ids;
     StreamState st;         // read: each stream's current side; written: its other side (see StreamRec)
+    // Leftover samples that stay where they lie (pe_update_device_keep, pe_update_async; full single updates only, position ==
+    // stream).  head != null: the previous call's chunks [n_streams][head_chunk] are still alive, and stream s's q leftover
+    // samples are the LAST q samples of its row there -- the carry is not read.  keep != 0: this call's own chunks will be the
+    // next call's `head`, so the bookkeeping role moves no samples and only publishes the record (the leftover of a call is
+    // always shorter than a frame, hence inside a chunk of >= frame_len - 1 samples).
+    const int16_t* head;
+    int head_chunk;
+    int keep;
     float* ring;            // [n_tiles][ring_slots][16 streams][16 floats] -- or, ring_bf16, 16 bf16 per row (32 bytes)
     int ring_bf16;
     float* proj_ring;       // [n_tiles][ring_slots][16 streams][64 floats] x.W + b of every frame, or null
@@ -223,9 +231,13 @@ __device__ __forceinline__ size_t gru_ring_cell(const GruArgs& a, const long lon
 // the loads behind a window's end (issued early, consumed by gru_ke_resolve: nothing here waits)
 struct KeRequest { RecPair p; uint32_t plain; };
 __device__ __forceinline__ KeRequest gru_ke_request(const GruArgs& a, const long long sid) {
+    // (the records are requested whether or not they will be used: loaded values that meet constants at a join of two branches
+    //  cost a wait for them right there -- in front of the weight loads of the network's prologue, 0.36 us per launch of the
+    //  stand-alone network, profiles/round6)
     KeRequest r;
-    if (a.ke_plain) { r.plain = a.ke_plain[sid]; r.p.r0 = StreamRec{0, 0u, 0u, 0u}; r.p.r1 = r.p.r0; }
-    else { r.plain = 0u; r.p = rec_request(a.rec, a.n_padded, sid); }
+    r.p = rec_request(a.rec, a.n_padded, sid);
+    r.plain = 0u;
+    if (a.ke_plain) r.plain = a.ke_plain[sid];
     return r;
 }
 // emitted-frame count the window of this launch ends at: the record's own, or -- predict_ke, the network role of a fused
@@ -327,6 +339,9 @@ hipError_t launch_gather(const GatherArgs& a, hipStream_t s);
 hipError_t launch_scatter(const GatherArgs& a, hipStream_t s);   // a.out is read
 // every record's wcall rewritten to 2 (current side) / 1 (other side): the host then continues counting calls from 3
 hipError_t launch_renumber(const StreamState& st, int n_padded, hipStream_t s);
+// leftovers that were kept in the previous call's chunks (MfccStreamArgs::head) are copied into each stream's CURRENT carry
+// side, records untouched: after it every kernel finds the state where it always was (st.call: a reader's number)
+hipError_t launch_materialize_carry(const StreamState& st, const int16_t* head, int head_chunk, int n_streams, hipStream_t s);
 hipError_t launch_clear(const ClearArgs& a, hipStream_t s);
 // proj[row][o] = b[o] + sum_c ring[row][c] w[c][o] for n_rows feature rows (after the ring was written from outside)
 hipError_t launch_project_rows(const float* ring, float* proj, const float* w, const float* b, int n_mfcc, long long n_rows, hipStream_t s);

@@ -1867,6 +1867,116 @@ def test_subset_at_full_batch_costs_what_a_full_update_costs(stock_weights):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize('kw', [dict(), dict(mfcc_precision='f32'), dict(gru_precision='bf16', ring_precision='bf16', mfcc_precision='f32'),
+                                dict(tiling=2), dict(units=(256,))],
+                         ids=['stock_f64', 'front_end_f32', 'bf16', 'x3_two_launches', 'wide256'])
+def test_kept_leftovers_equal_carried_leftovers(kw):
+    """pe_update_device_keep: the leftover of Listener.update_vectors (network_runner.py:127-131) stays in the
+    caller's chunk and the next call cuts its first frame's head from there.  Bit-identical to pe_update_device -- raw outputs
+    after every call, feature windows and per-stream counters at the end -- through random chunk lengths (including ones that
+    cannot hold a leftover: odd, 510 samples, and a tiny 160-sample chunk), with calls of every other style in between
+    (plain device updates, subsets, a masked clear, get_vectors), each of which must find the kept leftovers."""
+    import torch
+    import warnings
+    from mycroft_precise_amd._lib import HipEngine
+    kw = dict(kw)
+    tiling = kw.pop('tiling', None)
+    units = kw.pop('units', (20,))
+    w = synth.make_weights(n_in=P.pr.n_mfcc, units=units, seed=5)
+    n, total = 70, 80 * 1024
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(2026)
+    kinds = ['tone_noise'] * (n - 3) + ['zeros', 'square', 'quiet']
+    audio = np.stack([synth.stream_pcm(s, total, k) for s, k in enumerate(kinds)])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        a = HipEngine(P.pr, w, n_streams=n, **kw)            # carried leftovers (pe_update_device)
+        b = HipEngine(P.pr, w, n_streams=n, **kw)            # kept leftovers
+    if tiling is not None:
+        a.set_gru_tiling(tiling); b.set_gru_tiling(tiling)
+    oa, ob = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    alive = []                                              # the promise: a kept chunk outlives the next call
+    pos, n_keep = 0, 0
+    for call in range(400):
+        chunk = int(rng.choice([1024, 1024, 1024, 2048, 512, 600, 510, 1023, 160, 800]))
+        if pos + chunk > total:
+            break
+        pcm = torch.from_numpy(np.ascontiguousarray(audio[:, pos:pos + chunk])).to(dev)
+        alive = alive[-2:] + [pcm]
+        style = rng.choice(['keep', 'keep', 'keep', 'plain', 'subset', 'clear', 'vectors'])
+        a.update_device(pcm.data_ptr(), chunk, oa.data_ptr(), st)
+        if style == 'keep':
+            b.update_device(pcm.data_ptr(), chunk, ob.data_ptr(), st, keep=True); n_keep += 1
+        elif style == 'subset':                              # every stream, shuffled: the same update through the id list
+            ids = torch.from_numpy(rng.permutation(n).astype(np.int32)).to(dev)
+            rows = pcm[ids.long()].contiguous()
+            osub = torch.zeros(n, device=dev)
+            b.update_subset_device(ids.data_ptr(), n, rows.data_ptr(), chunk, osub.data_ptr(), st)
+            ob[ids.long()] = osub
+            alive.append(rows)
+        else:
+            b.update_device(pcm.data_ptr(), chunk, ob.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert torch.equal(oa, ob), (call, style, chunk)
+        if style == 'clear':
+            mask = (rng.random(n) < 0.3)
+            a.clear(mask); b.clear(mask)
+        elif style == 'vectors':
+            assert np.array_equal(a.get_vectors(), b.get_vectors()), call
+        pos += chunk
+    assert n_keep > 20
+    assert np.array_equal(a.get_vectors(), b.get_vectors())
+    for x, y in zip(a.stream_state(), b.stream_state()):
+        assert np.array_equal(x, y)
+    a.close(); b.close()
+
+
+def test_kept_leftovers_at_full_batch(stock_weights):
+    """4096 streams (the headline's fused launch) and 20 000 (two launches, the XDL network): keep calls over a ring of resident
+    slabs, as bench.py cycles them, against plain calls -- same bits; then the engine is switched to update_many in the middle
+    (leftovers move to the carry first)."""
+    import torch
+    from mycroft_precise_amd._lib import HipEngine
+    dev = torch.device('cuda', 0)
+    st = torch.cuda.current_stream().cuda_stream
+    for B in (4096, 20000):
+        n_res = 6
+        base = synth.batch_pcm(64, n_res)
+        reps = (B + 63) // 64
+        pcm = torch.from_numpy(np.ascontiguousarray(np.tile(base, (1, reps, 1))[:, :B])).to(dev)
+        a = HipEngine(P.pr, stock_weights, n_streams=B)
+        b = HipEngine(P.pr, stock_weights, n_streams=B)
+        oa, ob = torch.zeros(B, device=dev), torch.zeros(B, device=dev)
+        for i in range(30):
+            a.update_device(pcm[i % n_res].data_ptr(), 1024, oa.data_ptr(), st)
+            b.update_device(pcm[i % n_res].data_ptr(), 1024, ob.data_ptr(), st, keep=True)
+            assert torch.equal(oa, ob), (B, i)
+        for x, y in zip(a.stream_state(), b.stream_state()):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a.get_vectors(), b.get_vectors())
+        a.close(); b.close()
+    # keep calls, then several updates per call on the same (reserved) engine
+    B = 256
+    pcm = torch.from_numpy(np.ascontiguousarray(synth.batch_pcm(B, 12))).to(dev)        # [12][B][1024]
+    a = HipEngine(P.pr, stock_weights, n_streams=B); a.reserve_updates(4, 1024)
+    b = HipEngine(P.pr, stock_weights, n_streams=B); b.reserve_updates(4, 1024)
+    oa, ob = torch.zeros(B, device=dev), torch.zeros(B, device=dev)
+    ma, mb = torch.zeros(4, B, device=dev), torch.zeros(4, B, device=dev)
+    for i in range(4):
+        a.update_device(pcm[i].data_ptr(), 1024, oa.data_ptr(), st)
+        b.update_device(pcm[i].data_ptr(), 1024, ob.data_ptr(), st, keep=True)
+        assert torch.equal(oa, ob)
+    a.update_many_device(pcm[4:8].data_ptr(), 1024, 4, ma.data_ptr(), st)
+    b.update_many_device(pcm[4:8].data_ptr(), 1024, 4, mb.data_ptr(), st)
+    assert torch.equal(ma, mb)
+    for i in range(8, 12):
+        a.update_device(pcm[i].data_ptr(), 1024, oa.data_ptr(), st)
+        b.update_device(pcm[i].data_ptr(), 1024, ob.data_ptr(), st, keep=True)
+        assert torch.equal(oa, ob)
+    a.close(); b.close()
+
+
 def test_bench_starts_its_own_ranks_and_delivers_per_step():
     """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's N = 1 command): bench.py re-executes itself
     under torch.distributed.run on 127.0.0.1 with a free port.  Both ranks on cuda:0 over gloo (PE_BENCH_SHARED_GPU=1: this
