@@ -569,10 +569,12 @@ def main():
                     help='back-to-back launches of the roofline pass that precedes the warm-up (HIP events around the run)')
     ap.add_argument('--resident-updates', type=int, default=256,
                     help='distinct PCM chunks kept in HBM per stream (reused cyclically beyond that)')
-    ap.add_argument('--gather-every-step', choices=['rccl', 'host'], default=None,
+    ap.add_argument('--gather-every-step', choices=['rccl', 'host', 'direct', 'none'], default='direct',
                     help="after the headline's timed region, a second one in which step u's probabilities leave the GPU while update "
                          "u + 1 runs: 'rccl' = one asynchronous gather to rank 0 per step (gloo on host copies with PE_BENCH_SHARED_GPU=1), "
-                         "'host' = every rank copies its own [B] floats into its own pinned host ring on a side stream (no collective per step)")
+                         "'host' = every rank copies its own [B] floats into its own pinned host ring on a side stream (no collective per step), "
+                         "'direct' = the update's own output pointer IS a row of the rank's pinned host ring: the network role's final store "
+                         "crosses PCIe itself, no copy, no side stream, no call beside the update")
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -721,7 +723,7 @@ def main():
 
     # ---- --gather-every-step: a second region, same K steps, step u's probabilities leaving while update u + 1 runs ----------
     per_step = None
-    if args.gather_every_step:
+    if args.gather_every_step != 'none':
         mode = args.gather_every_step
         side = torch.cuda.Stream(device=device)
         host_ring = torch.empty((steps, B), dtype=torch.float32).pin_memory()
@@ -732,8 +734,13 @@ def main():
         barrier()
         t1 = time.perf_counter()
         works, evs = [], []
+        direct = mode == 'direct'
+        ring_base = host_ring.data_ptr()
         for i in range(steps):
             u = (warmup + i) % n_res
+            if direct:                                             # pinned host memory is device-visible: the kernel writes it
+                engine.update_device(pcm_base + u * chunk_bytes, CHUNK, ring_base + i * B * 4, stream, keep=keep)
+                continue
             engine.update_device(pcm_base + u * chunk_bytes, CHUNK, probs_base + i * B * 4, stream, keep=keep)
             if mode == 'host' or (mode == 'rccl' and shared_gpu) or world == 1:
                 ev = torch.cuda.Event()
@@ -762,13 +769,21 @@ def main():
             dist.all_reduce(mine, op=dist.ReduceOp.MAX)
             dt = float(mine.item())
         delivered_ok = None
-        if rank == 0:
+        if direct:
+            # the last step again from the feature windows as they stand (pe_run_device: the network alone, nothing advances),
+            # into device memory: must be the bits the last update wrote to the host ring; every other row must be finite
+            engine.run_device(scratch.data_ptr(), stream)
+            torch.cuda.synchronize()
+            delivered_ok = bool(torch.equal(host_ring[steps - 1].to(device), scratch)) and bool(torch.isfinite(host_ring).all().item())
+        elif rank == 0:
             if recv is not None:
                 delivered_ok = bool(torch.equal(recv[0].to(device), probs))
             else:
                 delivered_ok = bool(torch.equal(host_ring.to(device), probs))
-        per_step = {'mode': mode if world > 1 or mode == 'host' else 'host (one rank: nothing to gather)',
-                    'transport': ('gloo on host copies (PE_BENCH_SHARED_GPU=1: plumbing only, the host waits for every step)' if (mode == 'rccl' and shared_gpu and world > 1)
+        per_step = {'mode': mode if world > 1 or mode in ('host', 'direct') else 'host (one rank: nothing to gather)',
+                    'transport': ("the update's output pointer is a row of the rank's own pinned host ring: the network role's final store crosses PCIe "
+                                  "(4 B x %d per step), no copy, no side stream" % B if direct else
+                                  'gloo on host copies (PE_BENCH_SHARED_GPU=1: plumbing only, the host waits for every step)' if (mode == 'rccl' and shared_gpu and world > 1)
                                   else 'RCCL gather to rank 0 per step, asynchronous beside the next update' if (mode == 'rccl' and world > 1)
                                   else "each rank's own pinned host ring, one 4 B x %d copy per step on a side stream" % B),
                     'ms_per_step': 1e3 * dt / steps, 'value': n_global * steps / dt, 'unit': 'windows/s',

@@ -2013,6 +2013,12 @@ def test_bench_starts_its_own_ranks_and_delivers_per_step():
     assert solo_line['parity']['ok'] and solo_line['per_step_delivery']['delivered_equals_device'] is True
     solo = np.load(env1['PE_BENCH_DUMP'])
     assert solo.shape == (20, 512) and np.array_equal(both[:, 512:], solo)
+    # 'direct': the update's output pointer is a row of a pinned host ring -- the kernel's own final store is the delivery
+    direct = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--gather-every-step', 'direct', '--no-extra-configs', '--no-batched'] + common,
+                            env={k: v for k, v in env.items() if k != 'PE_BENCH_DUMP'}, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert direct.returncode == 0, direct.stderr[-3000:]
+    dline = json.loads([l for l in direct.stdout.splitlines() if l.startswith('{')][-1])
+    assert dline['per_step_delivery']['mode'] == 'direct' and dline['per_step_delivery']['delivered_equals_device'] is True
     # a rank count the node cannot serve is refused by name before anything is launched (no PE_BENCH_SHARED_GPU)
     env2 = {k: v for k, v in env.items() if k != 'PE_BENCH_SHARED_GPU'}
     import torch
