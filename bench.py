@@ -995,7 +995,7 @@ def main():
             'parity': parity,
             # what the communicator reported and every rank's own clock around the timed region (value uses the max)
             'sequence': 'roofline pass (%d back-to-back launches, HIP events) -> %d warm-up steps -> %d timed steps; a region entered '
-                        'from an idle GPU measures ~8 %% slower (DESIGN 5)' % (roofline_launches, warmup, steps),
+                        'from an idle GPU measures ~8 %% slower (DESIGN.md 5)' % (roofline_launches, warmup, steps),
             'untimed_launches_before_timed_region': roofline_launches + warmup,
             'resident_pcm': {'slabs': n_res, 'mb': n_res * chunk_bytes / 1e6,
                              'note': 'distinct [B][1024] int16 slabs cycled by every pass; independent of --steps'},

@@ -281,7 +281,7 @@ int pe_set_fused(pe_engine* e, int32_t enabled);
 /* Input projections: 1 = the MFCC stage stores x.W + b of every frame beside its feature row (256 bytes per frame and
  * stream) and the network starts each timestep from that row instead of recomputing the projection in each of the
  * n_features windows a frame appears in (16 of its 41 MFMAs per timestep); 0 = recompute (the default: measured, the
- * rows cost more to load every timestep than the MFMAs they save).  Available for the float32
+ * rows cost more to load every timestep than the MFMAs they save, profiles/DESIGN_notebook_r1-r5.md 4.6).  Available for the float32
  * network of 17..20 units without delta features.  Both settings agree to float32 rounding (different summation
  * order), each is deterministic; changing the setting restarts all streams. */
 int pe_set_input_projection(pe_engine* e, int32_t enabled);

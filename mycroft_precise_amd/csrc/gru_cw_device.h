@@ -27,7 +27,7 @@
 //                  feature ring of the tile (32 slots x 1 KB) is staged in LDS by all four waves in the SAME round trip
 //                  as the stream counters (which slot is which timestep is decided afterwards, per lane), so the chain
 //                  contains no global access.  The splits that were built and timed are listed at gru_tile_cw below
-//                  and in DESIGN.md 4.2b.
+//                  and in DESIGN.md 4.2 (form 1) / profiles/DESIGN_notebook_r1-r5.md 4.2b.
 #pragma once
 #include "gru_device.h"
 #include "gru_cw_pack.h"
