@@ -11,7 +11,7 @@ import weakref
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# PE_LIB: load an experiment build (tools/build_variants.sh) instead of the in-tree library
+# PE_LIB: load another build of the library (an A/B against an older tree) instead of the in-tree one
 LIB_PATH = os.environ.get('PE_LIB') or os.path.join(HERE, 'libprecise_engine.so')
 
 PE_OK, PE_ERR_INVALID, PE_ERR_HIP, PE_ERR_UNSUPPORTED, PE_ERR_NOMEM, PE_ERR_EOF = range(6)

@@ -506,8 +506,7 @@ int pack_gru_weights_x3(pe_engine* e, const pe_gru_layer& L, const float* dense_
 // lo), and 8 gk + 4 + e <-> the first difference of that feature (use_delta: kernel rows F .. 2 F - 1).
 bool b20_eligible(const pe_params& p, const pe_gru_layer& L) {
     const int F = p.use_delta ? L.n_in / 2 : L.n_in;
-    // (tuning builds: PE_B20=0 keeps every engine on the eight-values layout)
-    return tuning_env_int("PE_B20", 1) != 0 && p.gru_precision == 1 && L.units <= 20 && F <= 14 && p.n_mfcc <= kRowFloats;
+    return p.gru_precision == 1 && L.units <= 20 && F <= 14 && p.n_mfcc <= kRowFloats;
 }
 
 int pack_gru_weights_b20(pe_engine* e, const pe_gru_layer& L, const float* dense_kernel) {
@@ -809,7 +808,6 @@ GruArgs gru_args(const pe_engine* e) {
     // the XDL form's rate of ~26 us for the same 32 768 windows (profiles/round5/r5zz_kernel_stats.csv; round 6: profiles/round6).
     const bool many_windows = e->max_updates > 1 && (long long)e->max_updates * e->n_tiles > 4LL * e->n_cus;
     a.x3 = x3_ok && (e->gru_tiling == 2 || (e->gru_tiling < 0 && (e->n_tiles > 4 * e->n_cus || many_windows))) ? e->x3_blob : nullptr;
-    a.x3w = e->x3_blob;
     const bool cw_ok = e->cw_blob && e->row_floats == kRowFloats && !a.proj_ring && !a.bf16 && !a.x3 && !e->wide;
     const bool retile = cw_ok && (e->gru_tiling == 1 || (e->gru_tiling < 0 && e->n_tiles <= 2 * e->n_cus));
     const int auto_waves = retile ? (e->n_tiles <= 2 * e->n_cus ? 4 : 1) : (e->n_tiles <= e->n_cus ? 4 : 1);

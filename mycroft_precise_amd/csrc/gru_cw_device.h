@@ -31,22 +31,14 @@
 #pragma once
 #include "gru_device.h"
 #include "gru_cw_pack.h"
-#include "gru_x3_device.h"     // (round 5, PE_CW_VAR bit 6: the timing experiment with XDL chains on wave R)
 
 namespace pe {
 
 
 // LDS of one tile (floats): the mailboxes (CwBox), then the staged ring
-#ifndef PE_CW_VAR
-#define PE_CW_VAR 5         // gru_tile_cw split variants (round 4, tools/micro/gru_chain.hip): bit 0 = the r partial sums of units
-#endif                      // 16..19 issued WITH the X chain; bit 1 = candidate of units 16..19 on Z2, all of z on Z1; bit 2 = C chain pinned; bit 3 = R's timestep hand-scheduled
 struct CwLds {
     static constexpr int BOX = 0;                       // mailboxes (CwBox)
-#ifdef PE_CW_BIG_BOX                                     // (the mailboxes of variant bits 1 and 4: tools/micro/gru_chain.hip)
-    static constexpr int XR = 3072;                     // [32 slots][64][4]
-#else
-    static constexpr int XR = 2048;
-#endif
+    static constexpr int XR = 2048;                     // [32 slots][64][4]
     static constexpr int FLOATS = XR + kCwSlots * 256;
 };
 constexpr size_t kCwLdsBytes = (size_t)CwLds::FLOATS * sizeof(float);
@@ -309,41 +301,21 @@ struct CwBox {                  // LDS mailboxes (floats), [64 lanes][4] each un
     static constexpr int TAG = SZ1 + 64;        // [1] timestep whose h is in SH4 / SH1
     static constexpr int END = TAG + 4;
     // (kernels.hip keeps four role-slot ints at 1984 .. 1987)
-    // variant bit 1: r*h from R to Z2, the candidate of units 16..19 back, the z init of units 16..19 from Z2 to Z1
-    static constexpr int SRH4 = 2048;           // r*h of units 4 q + g
-    static constexpr int SRH1 = SRH4 + 256;     // [64] r*h of unit 16 + g
-    static constexpr int SC1 = SRH1 + 64;       // [64] candidate of unit 16 + g
-    static constexpr int PZ = SC1 + 64;         // [2 parities][64] z init of unit 16 + g
-    static constexpr int TAG2 = PZ + 128;       // [1] timestep + 1 whose r*h is in SRH4 / SRH1
-    // variant bit 4: R reads z(t) and the inits of step t + 1 BEFORE barrier B(t) (their LDS latency hides under its candidate
-    // chain) and validates the read afterwards with the tags the helpers store behind their data: [Z1, Z2, P] = t + 1
-    static constexpr int TAGH = TAG2 + 4;       // [3]
-    static constexpr int END2 = TAGH + 4;
 };
 static_assert(CwBox::END <= 1984 && CwBox::END <= CwLds::XR, "mailboxes overlap the role slots / the staged ring");
 
-template <bool VF, int VAR = PE_CW_VAR>
+// (the other splits and instruction orders of this timestep that were built and timed -- candidate of units 16..19 on Z2, R's
+//  timestep hand-interleaved, mailbox reads before the barrier with tag validation, no barrier at all, XDL chains on R -- are in
+//  the history of this file and in profiles/DESIGN_notebook_r1-r5.md 4.2b / 4.6; what is here is the one that won:
+//  the r partial sums ride in the slack of the X chain, the candidate chain and its partial sums are ONE pinned sequence)
+template <bool VF>
 __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, const int wave, const int lane, float* S) {
 #pragma clang fp contract(off)      // every fusion in the gate arithmetic is spelled out: all kernel shapes round alike
-    constexpr bool PR_FIRST = !VF && (VAR & 1) != 0;      // r partial sums of units 16..19 interleaved with the X chain
-    constexpr bool C4_ON_Z2 = !VF && (VAR & 2) != 0;      // candidate of units 16..19 on Z2 (from the r*h R publishes), all of z on Z1
-    constexpr bool PC_PINNED = !VF && (VAR & 4) != 0;     // candidate chain and its partial sums interleaved instruction by instruction
-    constexpr bool HAND = !VF && (VAR & 8) != 0;          // R's whole timestep as one pinned sequence
-    constexpr bool EARLY = !VF && (VAR & 16) != 0 && !C4_ON_Z2 && !HAND;     // R's mailbox reads issued before the barrier, tag-validated
-    constexpr bool NOBAR = !VF && (VAR & 32) != 0 && !C4_ON_Z2 && !HAND && !EARLY;   // no s_barrier in the time loop: every hand-off tag-polled
-    // bit 6 (round 5, VERDICT r4 #6: "the one variant that is still an estimate"): R's two chains as float32 products on the bf16
-    // pipe (gru_x3_device.h: four dependent 4-pass MFMAs instead of five dependent 8-pass ones + five two-pass partial sums +
-    // a cross-lane reduction), h and r.h split into three bf16 pieces on R.  TIMING EXPERIMENT ONLY: the helpers keep their
-    // float32 layout (unit 4 q + g), R computes in the x3 layout (unit 4 g + q) -- the instruction stream of the real thing,
-    // wrong numbers; tuning builds, never the product (profiles/round5/r5g_cw_x3_chain.log).
-    constexpr bool X3R = !VF && (VAR & 64) != 0;
-    static_assert(!(C4_ON_Z2 || EARLY || NOBAR) || CwBox::END2 <= CwLds::XR, "variant bits 1, 4 and 5 need -DPE_CW_BIG_BOX");
     const int g = lane >> 4, j = lane & 15;
     const long long stream = (long long)tile * kTileStreams + j;
     const bool valid = stream < a.n_streams;
     const int T = a.n_features;
     const float* cw = a.cw;
-    if (wave == 0) PE_GT(0);
 
     // ---- one round trip: the counters, this wave's share of the tile's ring, the weights ------------------------
     // (a.ring_slots == kCwSlots here: cw_four_waves_ok)
@@ -369,15 +341,6 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
     typedef const volatile __attribute__((address_space(3))) float* lds_vfloat;
     typedef const volatile __attribute__((address_space(3))) f32x4* lds_vf4;
     const lds_vint TAG = (lds_vint)(S + CwBox::TAG);
-    const lds_vint TAG2 = (lds_vint)(S + CwBox::TAG2);
-    const lds_vint TAGH = (lds_vint)(S + CwBox::TAGH);
-    // a helper's "data of step t are in my mailboxes" mark, stored behind the data (DS operations of a wave execute in order)
-    auto helper_tag = [&](const int who, const int value) {
-        if (EARLY || NOBAR) {
-            asm volatile("" ::: "memory");
-            if (lane == 0) TAGH[who] = value;
-        }
-    };
     auto x_row = [&](int t) -> f32x4 {                         // the stream's timestep t from the staged ring
         const int tc = t < T ? t : T - 1;
         const uint32_t slot = (first + (uint32_t)tc) & (uint32_t)(kCwSlots - 1);
@@ -396,9 +359,6 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
             h[4] = *(lds_vfloat)(L1 + CwBox::SH1);
             h[0] = h4[0]; h[1] = h4[1]; h[2] = h4[2]; h[3] = h4[3];
             if (__builtin_amdgcn_readfirstlane(tag) == t) break;
-#ifdef PE_POLL_SLEEP
-            __builtin_amdgcn_s_sleep(PE_POLL_SLEEP);
-#endif
         }
     };
     auto partials = [&](const float (&wf)[4][5], const float (&wv)[5], const float (&v)[5]) -> f32x4 {
@@ -445,133 +405,28 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
             wd[rho] = a.wd[rho * 64 + lane];
         }
         load_v(1, wfr, wvr);
-        if (!C4_ON_Z2) load_v(2, wfc, wvc);
+        load_v(2, wfc, wvc);
         stage_out();
         float h[5];
 #pragma unroll
         for (int rho = 0; rho < 5; ++rho) h[rho] = 0.f;
         *reinterpret_cast<f32x4*>(L4 + CwBox::SH4) = f32x4{0.f, 0.f, 0.f, 0.f};
         L1[CwBox::SH1] = 0.f;
-        if (lane == 0) { *TAG = 0; if (C4_ON_Z2) *TAG2 = 0; if (EARLY || NOBAR) { TAGH[0] = 0; TAGH[1] = 0; TAGH[2] = 0; } }
+        if (lane == 0) *TAG = 0;
 #pragma unroll
         for (int rho = 0; rho < 5; ++rho) { cw_pin(wrX[rho]); cw_pin(wrC[rho]); cw_pin(wd[rho]); }
         pin_v(wfr, wvr);
-        if (!C4_ON_Z2) pin_v(wfc, wvc);
+        pin_v(wfc, wvc);
         cw_barrier();                       // ring staged, h(0) = 0 published
         cw_barrier();                       // inits of step 0 in the mailboxes
         f32x4 accX = *reinterpret_cast<const f32x4*>(L4 + CwBox::PX);
         f32x4 accC = *reinterpret_cast<const f32x4*>(L4 + CwBox::PC);
         float ri = L2[CwBox::PV], ci = L2[CwBox::PV + 1];
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        PE_GT(1);
-        // (bit 6) the XDL operands of the r tile, the candidate tile and the quarter tile
-        bf16x8 x3ar[3][kX3RecOps];
-        X3Ident x3id = x3_identity(lane);
-        uint4 x3keep = {0u, 0u, 0u, 0u};
-        if (X3R) {
-            const uint4* blob = reinterpret_cast<const uint4*>(a.x3w);
-#pragma unroll
-            for (int tsel = 0; tsel < 3; ++tsel)
-#pragma unroll
-                for (int m = 0; m < kX3RecOps; ++m) x3ar[tsel][m] = __builtin_bit_cast(bf16x8, blob[kX3ArOff + ((tsel + 1) * kX3RecOps + m) * 64 + lane]);
-        }
         for (int t = 0; t < T; ++t) {
-            if (t == 10) PE_GT(2);
             // phase 1: r.  Units 0..15: + h.U on TX; units 16..19: partial sums, reduced across the lane groups
             f32x4 pr;
-            if (X3R) {
-                auto recur = [&](const bf16x8 (&w)[kX3RecOps], const X3Ops& o, const uint4& b3, f32x4 c) -> f32x4 {
-                    c = mfma_bf16(w[0], __builtin_bit_cast(bf16x8, o.b0), c);
-                    c = mfma_bf16(w[1], __builtin_bit_cast(bf16x8, o.b0), c);
-                    c = mfma_bf16(w[2], __builtin_bit_cast(bf16x8, o.b2), c);
-                    c = mfma_bf16(w[3], __builtin_bit_cast(bf16x8, b3), c);
-                    return c;
-                };
-                const f32x4 hq = {h[0], h[1], h[2], h[3]};
-                const X3Ops oh = x3_split_tile(hq, x3keep, x3id);
-                const uint4 oh4 = x3_split_one(h[4]);
-                const f32x4 arr = recur(x3ar[0], oh, oh4, accX);
-                const f32x4 aq = recur(x3ar[2], oh, oh4, f32x4{0.f, ri, ci, 0.f});
-                f32x4 rhq;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rhq[q] = hard_sigmoid(arr[q]) * h[q];
-                const float rh4 = hard_sigmoid(aq[1]) * h[4];
-                const X3Ops orh = x3_split_tile(rhq, x3keep, x3id);
-                const uint4 orh4 = x3_split_one(rh4);
-                accC = recur(x3ar[1], orh, orh4, accC);
-                const f32x4 aq2 = recur(x3ar[2], orh, orh4, aq);
-                if (t == 10) PE_GT(4);
-                cw_barrier();                                                   // B(t)
-                if (t == 10) PE_GT(5);
-                const int nbx = (t + 1) & 1;
-                const f32x4 zx = *reinterpret_cast<const f32x4*>(L4 + CwBox::SZ4);
-                const float z4x = L1[CwBox::SZ1];
-                const f32x4 nXx = *reinterpret_cast<const f32x4*>(L4 + CwBox::PX + nbx * 256);
-                const f32x4 nCx = *reinterpret_cast<const f32x4*>(L4 + CwBox::PC + nbx * 256);
-                const float nrix = L2[CwBox::PV + nbx * 128], ncix = L2[CwBox::PV + nbx * 128 + 1];
-                f32x4 hnx;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) hnx[q] = h[q] = gru_blend(zx[q], h[q], accC[q]);
-                h[4] = gru_blend(z4x, h[4], aq2[2]);
-                *reinterpret_cast<f32x4*>(L4 + CwBox::SH4) = hnx;
-                L1[CwBox::SH1] = h[4];
-                if (lane == 0) *TAG = t + 1;
-                accX = nXx; accC = nCx; ri = nrix; ci = ncix;
-                if (t == 10) PE_GT(6);
-                continue;
-            }
-            if (HAND) {
-                // The whole timestep of R as ONE pinned instruction sequence (sched_barrier between the groups).  What the
-                // order encodes (measured with tools/micro/gru_chain.hip, round 4): a dependent eight-pass MFMA can issue
-                // every ~40 cycles, the matrix pipe is busy for 32 of them -- one two-pass 4x4x1 MFMA fits in the slack for
-                // free, and a handful of the wave's own VALU instructions run in an MFMA's shadow.  So: the r partial sums of
-                // units 16..19 ride behind X0..X3 (two behind X0), their cross-lane reduction runs under X4; every r*h is
-                // formed right before the candidate MFMA that consumes it; the candidate partial sums ride behind C0..C4.
-                auto fence = []() { __builtin_amdgcn_sched_barrier(0); };
-                accX = mfma(wrX[0], h[0], accX); fence();
-                pr = mfma4(wvr[0], h[0], f32x4{0.f, 0.f, 0.f, 0.f}); fence();
-                pr = mfma4(wvr[1], h[1], pr); fence();
-                accX = mfma(wrX[1], h[1], accX); fence();
-                pr = mfma4(wvr[2], h[2], pr); fence();
-                accX = mfma(wrX[2], h[2], accX); fence();
-                pr = mfma4(wvr[3], h[3], pr); fence();
-                accX = mfma(wrX[3], h[3], accX); fence();
-                pr = mfma4(wvr[4], h[4], pr); fence();
-                accX = mfma(wrX[4], h[4], accX); fence();
-                const float rh4 = hard_sigmoid(ri + v_sum4(pr)) * h[4]; fence();      // under X4
-                float rhq = hard_sigmoid(accX[0]) * h[0]; fence();
-                accC = mfma(wrC[0], rhq, accC); fence();
-                f32x4 pc = mfma4(wvc[0], rhq, f32x4{0.f, 0.f, 0.f, 0.f}); fence();
-#pragma unroll
-                for (int q = 1; q < 4; ++q) {
-                    rhq = hard_sigmoid(accX[q]) * h[q]; fence();
-                    accC = mfma(wrC[q], rhq, accC); fence();
-                    pc = mfma4(wvc[q], rhq, pc); fence();
-                }
-                accC = mfma(wrC[4], rh4, accC); fence();
-                pc = mfma4(wvc[4], rh4, pc); fence();
-                const float c4h = ci + v_sum4(pc); fence();
-                if (t == 10) PE_GT(4);
-                cw_barrier();                                                   // B(t)
-                if (t == 10) PE_GT(5);
-                const int nbh = (t + 1) & 1;
-                const f32x4 zh = *reinterpret_cast<const f32x4*>(L4 + CwBox::SZ4);
-                const float z4h = L1[CwBox::SZ1];
-                const f32x4 nXh = *reinterpret_cast<const f32x4*>(L4 + CwBox::PX + nbh * 256);
-                const f32x4 nCh = *reinterpret_cast<const f32x4*>(L4 + CwBox::PC + nbh * 256);
-                const float nrih = L2[CwBox::PV + nbh * 128], ncih = L2[CwBox::PV + nbh * 128 + 1];
-                f32x4 hnh;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) hnh[q] = h[q] = gru_blend(zh[q], h[q], accC[q]);
-                h[4] = gru_blend(z4h, h[4], c4h);
-                *reinterpret_cast<f32x4*>(L4 + CwBox::SH4) = hnh;
-                L1[CwBox::SH1] = h[4];
-                if (lane == 0) *TAG = t + 1;
-                accX = nXh; accC = nCh; ri = nrih; ci = ncih;
-                if (t == 10) PE_GT(6);
-                continue;
-            }
-            if (PR_FIRST) {
+            if (!VF) {
                 // the partial sums depend on h only: issued WITH the X chain (a two-pass MFMA in the slack behind every
                 // eight-pass one), their reduction runs under the chain's tail and r of units 16..19 is ready with the rest
                 // (pinned instruction by instruction: left alone the scheduler moves the whole partial-sum chain behind the X chain)
@@ -595,16 +450,9 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
             rh[4] = hard_sigmoid(ri + v_sum4(pr)) * h[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) rh[q] = hard_sigmoid(accX[q]) * h[q];
-            if (C4_ON_Z2) {                                                 // fire and forget: Z2 polls the tag
-                *reinterpret_cast<f32x4*>(L4 + CwBox::SRH4) = f32x4{rh[0], rh[1], rh[2], rh[3]};
-                L1[CwBox::SRH1] = rh[4];
-                asm volatile("" ::: "memory");                                 // (the tag is stored AFTER the values, in program order)
-                if (lane == 0) *TAG2 = t + 1;
-            }
-            if (t == 10) PE_GT(3);
             // phase 2: candidate
             float c4 = 0.f;
-            if (PC_PINNED && !C4_ON_Z2) {
+            if (!VF) {
                 // the candidate chain and its partial sums, interleaved and pinned like phase 1
                 f32x4 pc;
                 accC = mfma(wrC[0], rh[0], accC);
@@ -622,15 +470,12 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
             } else {
 #pragma unroll
                 for (int rho = 0; rho < 5; ++rho) accC = mfma(wrC[rho], rh[rho], accC);
-                if (!C4_ON_Z2) {
-                    const f32x4 pc = partials(wfc, wvc, rh);
-                    c4 = ci + v_sum4(pc);
-                }
+                const f32x4 pc = partials(wfc, wvc, rh);
+                c4 = ci + v_sum4(pc);
             }
             const int nb = (t + 1) & 1;
             f32x4 z, nX, nC;
             float z4, nri, nci;
-            int tg0 = 0, tg1 = 0, tg2 = 0;
             auto read_boxes = [&]() {
                 z = *(lds_vf4)(L4 + CwBox::SZ4);
                 z4 = *(lds_vfloat)(L1 + CwBox::SZ1);
@@ -639,28 +484,8 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
                 nri = *(lds_vfloat)(L2 + CwBox::PV + nb * 128);
                 nci = *(lds_vfloat)(L2 + CwBox::PV + nb * 128 + 1);
             };
-            if (EARLY) {
-                // the helpers are a timestep ahead: their data of this step is normally there long before R gets here.  Tags
-                // first, data second (in-order DS execution): a tag that reads t + 1 vouches for the data read behind it
-                tg0 = TAGH[0]; tg1 = TAGH[1]; tg2 = TAGH[2];
-                read_boxes();
-            }
-            if (t == 10) PE_GT(4);
-            if (NOBAR) {
-                // no barrier: spin on the helpers' tags (normally already there), the data read behind them in the same pass
-                // (>=: P may legally be one timestep ahead -- its inits are parity-buffered; the spin is bounded so that a
-                //  protocol slip shows up as a wrong result in the harness, not as a hung GPU)
-                for (int spin = 0; spin < (1 << 22); ++spin) {
-                    tg0 = TAGH[0]; tg1 = TAGH[1]; tg2 = TAGH[2];
-                    read_boxes();
-                    if (!__builtin_amdgcn_readfirstlane((tg0 < t + 1) | (tg1 < t + 1) | (tg2 < t + 1))) break;
-                }
-            } else {
-                cw_barrier();                                               // B(t): z(t) and the inits of step t + 1 are in LDS
-            }
-            if (t == 10) PE_GT(5);
-            if (!NOBAR && (!EARLY || __builtin_amdgcn_readfirstlane((tg0 != t + 1) | (tg1 != t + 1) | (tg2 != t + 1)))) read_boxes();
-            if (C4_ON_Z2) c4 = L1[CwBox::SC1];
+            cw_barrier();                                                   // B(t): z(t) and the inits of step t + 1 are in LDS
+            read_boxes();
             f32x4 hn;
 #pragma unroll
             for (int q = 0; q < 4; ++q) hn[q] = h[q] = gru_blend(z[q], h[q], accC[q]);
@@ -669,35 +494,29 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
             L1[CwBox::SH1] = h[4];
             if (lane == 0) *TAG = t + 1;
             accX = nX; accC = nC; ri = nri; ci = nci;
-            if (t == 10) PE_GT(6);
         }
-        PE_GT(8);
         cw_head(a, h, wd, stream, valid, g);
-        PE_GT(9);
     } else if (wave == 1) {
-        // ================= Z1: z of units 0..15 (variant bit 1: and of units 16..19) =========================
-        float wrZ[5], wx[4], bb[4], wfz1[4][5], wvz1[5];
+        // ================= Z1: z of units 0..15 ==============================================================
+        float wrZ[5], wx[4], bb[4];
 #pragma unroll
         for (int rho = 0; rho < 5; ++rho) wrZ[rho] = cw[CwPack::WR + (0 * 5 + rho) * 64 + lane];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { wx[kk] = cw[CwPack::WX + (kTZ * 4 + kk) * 64 + lane]; bb[kk] = cw[CwPack::BIAS + (kTZ * 4 + kk) * 64 + lane]; }
         float wxd[4];
         load_wxd(kTZ, wxd);
-        if (C4_ON_Z2) load_v(0, wfz1, wvz1);
         first_slot();
         stage_out();
 #pragma unroll
         for (int rho = 0; rho < 5; ++rho) cw_pin(wrZ[rho]);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { cw_pin(wx[kk]); cw_pin(bb[kk]); cw_pin(wxd[kk]); }
-        if (C4_ON_Z2) pin_v(wfz1, wvz1);
         const f32x4 bias = {bb[0], bb[1], bb[2], bb[3]};
         cw_barrier();
         f32x4 xc = x_row(0);
         f32x4 accZ = cw_xproj(wx, bias, xc);
         f32x4 xn = x_row(1);
         cw_barrier();
-        float zi = C4_ON_Z2 ? L1[CwBox::PZ] : 0.f;
         for (int t = 0; t < T; ++t) {
             f32x4 nZ = cw_xproj(wx, bias, xn);              // next step's init, while h(t) is on its way
             if (delta) { nZ = cw_dproj(wxd, nZ, xn - xc); xc = xn; }
@@ -707,20 +526,17 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
             wait_h(t, h);
 #pragma unroll
             for (int rho = 0; rho < 5; ++rho) accZ = mfma(wrZ[rho], h[rho], accZ);
-            if (C4_ON_Z2) L1[CwBox::SZ1] = hard_sigmoid(zi + v_sum4(partials(wfz1, wvz1, h)));
             f32x4 z;
 #pragma unroll
             for (int q = 0; q < 4; ++q) z[q] = hard_sigmoid(accZ[q]);
             *reinterpret_cast<f32x4*>(L4 + CwBox::SZ4) = z;
-            helper_tag(0, t + 1);
-            if (!NOBAR) cw_barrier();                                       // B(t)  (NOBAR: the next z is not written before R published h(t + 1), i.e. after it read this one)
+            cw_barrier();                                                   // B(t)
             accZ = nZ;
-            if (C4_ON_Z2) zi = L1[CwBox::PZ + ((t + 1) & 1) * 64];
         }
     } else if (wave == 2) {
-        // ================= Z2: z of units 16..19 (variant bit 1: their candidate instead); inits of the quarter tile ====
+        // ================= Z2: z of units 16..19; inits of the quarter tile =================================
         float wfz[4][5], wvz[5], wx[4], bb[4];
-        load_v(C4_ON_Z2 ? 2 : 0, wfz, wvz);
+        load_v(0, wfz, wvz);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { wx[kk] = cw[CwPack::WX + (kTV * 4 + kk) * 64 + lane]; bb[kk] = cw[CwPack::BIAS + (kTV * 4 + kk) * 64 + lane]; }
         float wxd[4];
@@ -734,10 +550,9 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
         cw_barrier();
         f32x4 xc = x_row(0);
         f32x4 v = cw_xproj(wx, bias, xc);
-        float zi = v[0];                    // (variant bit 1: the candidate init instead)
+        float zi = v[0];
         L2[CwBox::PV] = v[1];
         L2[CwBox::PV + 1] = v[2];
-        if (C4_ON_Z2) { L1[CwBox::PZ] = v[0]; zi = v[2]; }
         f32x4 xn = x_row(1);
         cw_barrier();
         for (int t = 0; t < T; ++t) {
@@ -748,28 +563,11 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
             cw_pin(v);
             L2[CwBox::PV + nb * 128] = v[1];
             L2[CwBox::PV + nb * 128 + 1] = v[2];
-            if (C4_ON_Z2) {
-                L1[CwBox::PZ + nb * 64] = v[0];
-                // r*h(t) as R published it right after phase 1: spin on the tag, then the lane's own position
-                float rh[5];
-                for (;;) {
-                    const int tag = *TAG2;
-                    const f32x4 r4 = *(lds_vf4)(L4 + CwBox::SRH4);
-                    rh[4] = *(lds_vfloat)(L1 + CwBox::SRH1);
-                    rh[0] = r4[0]; rh[1] = r4[1]; rh[2] = r4[2]; rh[3] = r4[3];
-                    if (__builtin_amdgcn_readfirstlane(tag) == t + 1) break;
-                }
-                L1[CwBox::SC1] = zi + v_sum4(partials(wfz, wvz, rh));
-                cw_barrier();                                               // B(t)
-                zi = v[2];
-            } else {
-                float h[5];
-                wait_h(t, h);
-                L1[CwBox::SZ1] = hard_sigmoid(zi + v_sum4(partials(wfz, wvz, h)));
-                helper_tag(1, t + 1);
-                if (!NOBAR) cw_barrier();                                   // B(t)
-                zi = v[0];
-            }
+            float h[5];
+            wait_h(t, h);
+            L1[CwBox::SZ1] = hard_sigmoid(zi + v_sum4(partials(wfz, wvz, h)));
+            cw_barrier();                                                   // B(t)
+            zi = v[0];
         }
     } else {
         // ================= P: inits of TX and TC ===========================================================
@@ -802,14 +600,7 @@ __device__ __forceinline__ void gru_tile_cw(const GruArgs& a, const int tile, co
             *reinterpret_cast<f32x4*>(L4 + CwBox::PX + nb * 256) = p0;
             *reinterpret_cast<f32x4*>(L4 + CwBox::PC + nb * 256) = p1;
             xn = x_row(t + 2);
-            helper_tag(2, t + 1);
-            if (NOBAR) {
-                // pacing without the barrier: the parity buffer written next (inits of step t + 2) still holds the inits of step
-                // t, which R reads at the end of step t - 1, before it publishes h(t): wait for that tag
-                for (int spin = 0; spin < (1 << 22) && __builtin_amdgcn_readfirstlane(*TAG) < t; ++spin) { }
-            } else {
-                cw_barrier();                                               // B(t)
-            }
+            cw_barrier();                                                   // B(t)
         }
     }
 }

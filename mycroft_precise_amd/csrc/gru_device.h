@@ -29,15 +29,6 @@ namespace pe {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Section timers of the four-wave shapes for the tuning harness (tools/micro/gru_chain.hip builds with
-// -DPE_GRU_TIMERS): shader-clock stamps of one wave per workgroup; compiled out of the product.
-#ifdef PE_GRU_TIMERS
-__device__ unsigned long long pe_gru_timers[256 * 32];
-#define PE_GT(i) do { if (lane == 0 && blockIdx.x < 256) pe_gru_timers[blockIdx.x * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define PE_GT(i) do { } while (0)
-#endif
-
 __device__ __forceinline__ float hard_sigmoid(float v) {
     // Keras/TF: clip(0.2 * x + 0.5, 0, 1), as ONE fused multiply-add with the clamp (one rounding where TF does two:
     // <= 1 ulp apart, inside the 1e-4 parity budget by three orders of magnitude).  The fusion is spelled out: left to
@@ -499,14 +490,12 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
         __builtin_amdgcn_s_barrier();
     };
     float* Sl = S + lane;
-    if (wave == 2) PE_GT(0);
 
     float h[R], z[R];
 #pragma unroll
     for (int rho = 0; rho < R; ++rho) { h[rho] = 0.f; z[rho] = 0.f; }
     f32x4 accx = xproj(wx, wxh, bias, load_x(0));       // this wave's tile, timestep 0
     XRow x1 = load_x(1);
-    if (wave == 2) PE_GT(1);
 
     for (int t = 0; t < T; ++t) {
         if (wave == 3) {
@@ -528,14 +517,11 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
             lds_barrier();                                           // B
             accx = an;
         } else if (wave == 2) {
-            if (t == 10) PE_GT(2);
             f32x4 acc = accx;
 #pragma unroll
             for (int rho = 0; rho < R; ++rho) acc = mfma(wrA[rho], h[rho], acc);
             Sl[8 * 64] = hard_sigmoid(acc[0]); Sl[9 * 64] = hard_sigmoid(acc[1]);
-            if (t == 10) PE_GT(3);
             lds_barrier();                                           // A
-            if (t == 10) PE_GT(4);
             float rr[R];
 #pragma unroll
             for (int rho = 0; rho < R; ++rho) { z[rho] = Sl[rho * 64]; rr[rho] = Sl[(R + rho) * 64]; }
@@ -545,9 +531,7 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
 #pragma unroll
             for (int rho = 0; rho < R; ++rho) acc = mfma(wrB[rho], rr[rho] * h[rho], acc);
             Sl[10 * 64] = acc[2]; Sl[11 * 64] = acc[3];
-            if (t == 10) PE_GT(5);
             lds_barrier();                                           // B
-            if (t == 10) PE_GT(6);
             accx = an;
         } else {
             f32x4 acc = accx;
@@ -569,7 +553,6 @@ __device__ __forceinline__ void gru_tile_mw5(const GruArgs& a, const int tile, c
         for (int rho = 0; rho < R; ++rho) h[rho] = gru_blend(z[rho], h[rho], hh[rho]);
     }
 
-    if (wave == 2) PE_GT(8);
     if (wave == 0) {
         float part = 0.f;
 #pragma unroll

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64) void gru_many_x3_kernel(const GruArgs a, const 
 // Returns the index in the canonical order [network | frames | bookkeeping].
 constexpr int kFramesFirst = 1, kBySimd = 2;       // launch flags of fused_update_kernel (its last argument)
 constexpr int kCwRoleSlot = 1984;                  // four ints of the GRU workgroup's LDS between the mailboxes and the staged ring
-static_assert(CwBox::END <= kCwRoleSlot && kCwRoleSlot + 4 <= CwLds::XR && kCwRoleSlot + 4 <= CwBox::SRH4, "role slots overlap");
+static_assert(CwBox::END <= kCwRoleSlot && kCwRoleSlot + 4 <= CwLds::XR, "role slots overlap");
 __device__ __forceinline__ int role_block(const int b, const int n_gru, const int n_frames, const int frames_first) {
     if (!frames_first || b >= n_gru + n_frames) return b;
     return b < n_frames ? n_gru + b : b - n_frames;
@@ -381,23 +381,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PE_FRAME_WP
 
 // Workgroups of the frame role: one wave per task while that fits the machine (4 workgroups of 4 waves per compute
 // unit are resident: LDS and a 128-register budget), more tasks per wave beyond.
-// Launch-shape knobs of the tuning harness (tools/): read from the environment ONLY in -DPE_TUNING builds
-// (tools/build_variants.sh); the product library ignores the environment -- two of the knobs skip a role of the
-// launch on purpose and would yield silently wrong results.
-static int env_int(const char* name, int dflt) {
-#ifdef PE_TUNING
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-#else
-    (void)name;
-    return dflt;
-#endif
-}
-int tuning_env_int(const char* name, int dflt) { return env_int(name, dflt); }
-
-static int frame_blocks(long long n_tasks, int n_cus, int per_cu_default = 4) {
-    static const int per_cu_env = env_int("PE_FRAME_WG_PER_CU", 0);      // tuning knob (tools/): resident frame workgroups per CU
-    const int per_cu = per_cu_env ? per_cu_env : per_cu_default;
+static int frame_blocks(long long n_tasks, int n_cus, int per_cu = 4) {      // per_cu: resident frame workgroups per compute unit
     const long long need = (n_tasks + kFrameWaves - 1) / kFrameWaves;
     const long long cap = (long long)n_cus * per_cu;
     return (int)(need < cap ? (need < 1 ? 1 : need) : cap);
@@ -426,9 +410,6 @@ static hipError_t launch_mfcc(const MfccStreamArgs<R>& a, const WaveTables<R>& t
     const int tiles = (a.geo.n_streams + kTileStreams - 1) / kTileStreams;
     const int fb = stream_frame_blocks(a.geo.n_streams, n_cus);
     if (!blob_matches_shape(t)) return hipErrorInvalidValue;
-    static const int skip = env_int("PE_MFCC_SKIP", 0);        // tuning aid (wrong results): 1 = frame role only, 2 = bookkeeping role only
-    if (skip == 1) { PE_LAUNCH_R(R, mfcc_kernel, (ShapeStock), dim3(fb), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb); return hipGetLastError(); }
-    if (skip == 2) { PE_LAUNCH_R(R, mfcc_kernel, (ShapeStock), dim3(tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, 0); return hipGetLastError(); }
     const bool single = a.n_updates == 1 && !a.proj_ring;
     if (t.L.mel_pad == ShapeStock::MEL) {
         if (single) PE_LAUNCH_R(R, mfcc_kernel, (ShapeStock, true), dim3(fb + tiles), dim3(64 * kFrameWaves), frame_lds(t), s, a, t, fb);
@@ -597,29 +578,23 @@ static hipError_t launch_fused_rg(const MfccStreamArgs<R>& m, const WaveTables<R
     // streams through the remaining wave slots (measured at 16384 / 65536 streams, bf16 network + float32 front end:
     // 31.8 / 103.8 us against 35.5 / 109.0 us network-first; the float64 front end gains nothing either way -- its
     // FP64 multiply-adds and the MFMAs do not overlap on a SIMD)
-    static const int ff_env = env_int("PE_FUSED_FRAMES_FIRST", -1);
     // one network tile per compute unit on the critical-wave kernel: roles by SIMD, frame slots split by SIMD load
-    static const int bs_env = env_int("PE_BY_SIMD", -1);
-    const bool by_simd = g.cw && g.waves_per_tile == 4 && cw_four_waves_ok(g) && tiles <= n_cus && bs_env != 0;
-    const int frames_first = (ff_env >= 0 ? ff_env : (g.waves_per_tile != 4 && tiles >= 4 * n_cus)) | (by_simd ? kBySimd : 0);
+    const bool by_simd = g.cw && g.waves_per_tile == 4 && cw_four_waves_ok(g) && tiles <= n_cus;
+    const int frames_first = ((g.waves_per_tile != 4 && tiles >= 4 * n_cus) ? 1 : 0) | (by_simd ? kBySimd : 0);
     // resident frame workgroups per compute unit: at one network tile per compute unit the launch lasts as long as the
     // network's dependent chain, and two frame workgroups (two streams per wave, the second one's samples prefetched)
     // disturb that chain less than four (measured, 4096 streams: 20.6 vs 20.9 us in phase, 21.1 vs 22.5 us with
     // desynchronised streams); larger batches want every wave slot
     const int fb = stream_frame_blocks(m.geo.n_streams, n_cus, tiles <= n_cus ? 2 : (frames_first & kFramesFirst) ? 3 : 4);
-    int gru_blocks = g.waves_per_tile == 4 ? tiles : (tiles + 3) / 4;
-    static const int skip = env_int("PE_FUSED_SKIP", 0);       // tuning aid (wrong results): 1 = launch without the MFCC roles, 2 = without the network role, 3 = without the bookkeeping role
-    int fb_ = fb, book = tiles;
-    if (skip == 1) { fb_ = 0; book = 0; }
-    if (skip == 2) gru_blocks = 0;
-    if (skip == 3) book = 0;
+    const int gru_blocks = g.waves_per_tile == 4 ? tiles : (tiles + 3) / 4;
+    const int fb_ = fb, book = tiles;
     const dim3 grid(gru_blocks + fb_ + book);
     if constexpr (RG == 5) {
         if (g.cw) {                          // stock width, re-tiled: the four-wave shape wants its LDS (mailboxes + staged ring)
             if (g.waves_per_tile == 4 && cw_four_waves_ok(g)) {
                 PE_LAUNCH_R(R, fused_update_kernel, (ShapeStock, RG, true, false, true), grid, dim3(256), lds > kCwLdsBytes ? lds : kCwLdsBytes, s, m, t, g, gru_blocks, fb_, tiles, frames_first);
             } else {
-                const int gb = skip == 2 ? 0 : (tiles + 3) / 4;
+                const int gb = (tiles + 3) / 4;
                 PE_LAUNCH_R(R, fused_update_kernel, (ShapeStock, RG, false, false, true), dim3(gb + fb_ + book), dim3(256), lds, s, m, t, g, gb, fb_, tiles, frames_first);
             }
             return hipGetLastError();
@@ -644,17 +619,12 @@ static hipError_t launch_fused(const MfccStreamArgs<R>& m, const WaveTables<R>& 
     if (t.L.mel_pad != ShapeStock::MEL || !blob_matches_shape(t)) return hipErrorInvalidValue;
     if (g.bf16) {
         const int tiles = (m.geo.n_streams + kTileStreams - 1) / kTileStreams;
-        static const int tpw_env = env_int("PE_BF16_TPW", 0);
-        const int tpw = tpw_env ? tpw_env : 4;
-        int gru_blocks = (tiles + tpw - 1) / tpw;
-        static const int ff_env = env_int("PE_FUSED_FRAMES_FIRST", -1);
-        const int ff = ff_env >= 0 ? ff_env : (tiles >= 4 * n_cus);
+        const int tpw = 4;                     // network tiles per network workgroup
+        const int gru_blocks = (tiles + tpw - 1) / tpw;
+        const int ff = tiles >= 4 * n_cus ? 1 : 0;
         const int frames_first = (ff & 1) | (tpw << 8);
-        int fb = stream_frame_blocks(m.geo.n_streams, n_cus, ff ? 3 : 4);
-        static const int skip = env_int("PE_FUSED_SKIP", 0);       // tuning aid (wrong results), as in launch_fused_rg
-        int book = tiles;
-        if (skip == 1) { fb = 0; book = 0; }
-        if (skip == 2) gru_blocks = 0;
+        const int fb = stream_frame_blocks(m.geo.n_streams, n_cus, ff ? 3 : 4);
+        const int book = tiles;
         const dim3 grid(gru_blocks + fb + book);
         if (g.use_delta && g.ring_bf16) PE_LAUNCH_R(R, fused_update_bf16_kernel, (ShapeStock, true, true), grid, dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles, frames_first);
         else if (g.use_delta) PE_LAUNCH_R(R, fused_update_bf16_kernel, (ShapeStock, true, false), grid, dim3(256), frame_lds(t), s, m, t, g, gru_blocks, fb, tiles, frames_first);
@@ -954,25 +924,7 @@ hipError_t launch_clear(const ClearArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-#ifdef PE_GRU_TIMERS
-extern "C" int pe_debug_read_gru_timers(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pe_gru_timers), sizeof(unsigned long long) * (n < 256 * 32 ? n : 256 * 32));
-}
-#endif
 
-#ifdef PE_SECTION_TIMERS
-extern "C" int pe_debug_read_timers(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pe_dbg_timers), sizeof(unsigned long long) * (n < 32 ? n : 32));
-}
-extern "C" int pe_debug_read_wave_times(unsigned long long* out, int n_waves) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pe_dbg_wave_times), sizeof(unsigned long long) * 4 * (n_waves < 8192 ? n_waves : 8192));
-}
-#endif
 
 }  // namespace pe
 
-#ifdef PE_DBG_CAPTURE
-extern "C" int pe_dbg_capture_read(void* dst, size_t bytes) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pe::pe_dbg_capture), bytes < sizeof(pe::pe_dbg_capture) ? bytes : sizeof(pe::pe_dbg_capture));
-}
-#endif

@@ -190,7 +190,7 @@ struct GruArgs {
     // float32 network on the XDL pipe, operands as three bf16 pieces (gru_x3_device.h; pe_set_gru_tiling(e, 2)):
     // non-null = the launchers take gru_tile_x3 for every input mode
     const void* x3;         // [4 tiles][4][64] + [4 tiles][3][64] uint4 of 8 bf16, then float wd[5][64]
-    const void* x3w;        // the same blob whatever form the launches take (PE_CW_VAR bit 6, the timing experiment of gru_cw_device.h), may be null
+    const void* reserved_;  // (null; keeps the layout of the argument segment the kernels' scalar loads were measured with)
     // input: either the feature ring (+ each stream's record: its emitted-frame counter) ...
     // n_streams counts the windows of THIS launch; window v belongs to stream ids[v] (pe_update_subset) or, ids == null, to
     // stream v: records and ring rows are addressed by the stream, out[] by v
@@ -325,8 +325,6 @@ hipError_t launch_gru_many(const GruArgs& a, int n_updates, int n_padded, hipStr
 // frame_len: no frame computed now becomes visible now)
 hipError_t launch_fused_f64(const MfccStreamArgs<double>& m, const WaveTables<double>& t, const GruArgs& g, int n_cus, hipStream_t s);
 hipError_t launch_fused_f32(const MfccStreamArgs<float>& m, const WaveTables<float>& t, const GruArgs& g, int n_cus, hipStream_t s);
-// tuning aid (-DPE_TUNING builds only; 0 in the product): an integer knob read from the environment
-int tuning_env_int(const char* name, int dflt);
 hipError_t launch_mfcc_offline_f64(const MfccOfflineArgs<double>& a, const WaveTables<double>& t, int n_cus, hipStream_t s);
 hipError_t launch_mfcc_offline_f32(const MfccOfflineArgs<float>& a, const WaveTables<float>& t, int n_cus, hipStream_t s);
 hipError_t launch_gru_small(const GruArgs& a, int input_mode, hipStream_t s);   // units <= 32; 0 feats, 1 ring, 2 rows
