@@ -25,7 +25,7 @@ def shard_bounds(n_streams: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_probabilities(local, n_streams: int, group=None, dst=None):
+def gather_probabilities(local, n_streams: int, group=None, dst=None, force_collective: bool = False):
     """
     Gather per-rank probability blocks into global stream order.
 
@@ -37,10 +37,12 @@ def gather_probabilities(local, n_streams: int, group=None, dst=None):
     dst=r:    gather to rank r only (RCCL send/recv group: the 7 peers of an 8-GPU node write to r over
               7 different xGMI links at once, ~3x cheaper than the ring all-gather for this payload);
               rank r returns [..., n_streams], the others None.
+    force_collective: issue the collective even in a world of one rank (a 1-GPU box can then run the RCCL calls themselves:
+              tests/rccl_one_rank_check.py); by default a single rank returns its block untouched.
     """
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force_collective):
         if local.shape[-1] != n_streams:
             raise ValueError('single-rank gather expects all %d streams, got %d' % (n_streams, local.shape[-1]))
         return local

@@ -1977,6 +1977,18 @@ def test_kept_leftovers_at_full_batch(stock_weights):
     a.close(); b.close()
 
 
+def test_rccl_calls_with_one_rank():
+    """Every torch.distributed call of the N > 1 path, with bench.py's argument shapes, on the `nccl` backend (= RCCL) in a
+    world of ONE rank on cuda:0 -- what a 1-GPU box can run of the RCCL path (zero executions so far).
+    In a subprocess: the process group must not outlive the check."""
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get('PYTHONPATH', ''), MASTER_ADDR='127.0.0.1', MASTER_PORT='29577',
+               RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'tests', 'rccl_one_rank_check.py')], env=env, cwd=REPO,
+                         capture_output=True, text=True, timeout=600)
+    # (librccl prints its own path to stdout on the way out: any line, not the last one)
+    assert out.returncode == 0 and any(l.startswith('ok: nccl backend (RCCL), 1 rank') for l in out.stdout.splitlines()), (out.stdout[-500:], out.stderr[-3000:])
+
+
 def test_bench_starts_its_own_ranks_and_delivers_per_step():
     """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's N = 1 command): bench.py re-executes itself
     under torch.distributed.run on 127.0.0.1 with a free port.  Both ranks on cuda:0 over gloo (PE_BENCH_SHARED_GPU=1: this
