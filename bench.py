@@ -598,8 +598,16 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     comm_device = torch.device('cpu') if shared_gpu else device
-    if world > 1:
+    # PE_BENCH_FORCE_DIST=1 (test aid for 1-GPU boxes): a world of ONE rank still creates its process group and issues every
+    # collective of the N > 1 path -- over RCCL, which two ranks on one GPU cannot use.  Nothing crosses xGMI; what runs is the
+    # plumbing (communicator with device_id, barrier(device_ids), the settle-the-collective handshake, gather, clock exchange).
+    force_dist = os.environ.get('PE_BENCH_FORCE_DIST') == '1'
+    multi = world > 1 or force_dist
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', str(rank))
+        os.environ.setdefault('WORLD_SIZE', str(world))
         if shared_gpu:
             dist.init_process_group('gloo')
         else:
@@ -630,7 +638,7 @@ def main():
     probs_base = probs.data_ptr()
 
     def barrier():
-        if world > 1:
+        if multi:
             if shared_gpu:
                 dist.barrier()
             else:
@@ -660,13 +668,13 @@ def main():
         return ev0.elapsed_time(ev1) / n
 
     collective = {'collective': None, 'fallback_reason': None}
-    if world > 1:
+    if multi:
         # Warm the communicator with the timed gather's own shape -- and settle HERE, before anything is timed, which
         # collective the job uses: a gather to rank 0 (one send per peer over its own xGMI link), or, should this RCCL build
         # refuse it, an all-gather.  Every rank must take the same one: the outcome is agreed with an all-reduce (MIN).
         ok = 1
         try:
-            gather_probabilities(probs.to(comm_device), n_global, dst=0)
+            gather_probabilities(probs.to(comm_device), n_global, dst=0, force_collective=force_dist)
         except Exception as ex:                               # noqa: BLE001
             ok = 0
             collective['fallback_reason'] = repr(ex)[:200]
@@ -674,7 +682,7 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         collective['collective'] = 'gather' if int(flag.item()) == 1 else 'all_gather'
         if collective['collective'] == 'all_gather':
-            gather_probabilities(probs.to(comm_device), n_global, dst=None)
+            gather_probabilities(probs.to(comm_device), n_global, dst=None, force_collective=force_dist)
     gather_dst = 0 if collective['collective'] != 'all_gather' else None
     # ---- roofline pass FIRST, on every rank: `roofline.achieved` comes from here.  It also is what takes the GPU out of
     # idle: a 25-launch region entered from an idle GPU runs 8 % slower than the same region after >= 20 ms of
@@ -692,14 +700,14 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(warmup, steps, True)
-    gathered = gather_probabilities(probs.to(comm_device), n_global, dst=gather_dst) if world > 1 else probs      # rank 0 (all ranks after a fallback)
+    gathered = gather_probabilities(probs.to(comm_device), n_global, dst=gather_dst, force_collective=force_dist) if multi else probs      # rank 0 (all ranks after a fallback)
     wait_for_gpu()
     barrier()
     elapsed = time.perf_counter() - t0
     fed += [i % n_res for i in range(warmup)] + [(warmup + i) % n_res for i in range(steps)]
     rank_ms = [1e3 * elapsed / steps]
     ranks_seen = 1
-    if world > 1:
+    if multi:
         ranks_seen = dist.get_world_size()
         mine = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         every = [torch.zeros_like(mine) for _ in range(ranks_seen)]
@@ -728,7 +736,7 @@ def main():
         side = torch.cuda.Stream(device=device)
         host_ring = torch.empty((steps, B), dtype=torch.float32).pin_memory()
         recv = None
-        if mode == 'rccl' and world > 1 and rank == 0:
+        if mode == 'rccl' and multi and rank == 0:
             recv = torch.empty((world, steps, B), dtype=torch.float32, device=comm_device)
         torch.cuda.synchronize()
         barrier()
@@ -742,7 +750,7 @@ def main():
                 engine.update_device(pcm_base + u * chunk_bytes, CHUNK, ring_base + i * B * 4, stream, keep=keep)
                 continue
             engine.update_device(pcm_base + u * chunk_bytes, CHUNK, probs_base + i * B * 4, stream, keep=keep)
-            if mode == 'host' or (mode == 'rccl' and shared_gpu) or world == 1:
+            if mode == 'host' or (mode == 'rccl' and shared_gpu) or not multi:
                 ev = torch.cuda.Event()
                 ev.record()                                       # behind update i on the launch stream
                 side.wait_event(ev)
@@ -751,7 +759,7 @@ def main():
                     done = torch.cuda.Event()
                     done.record()
                 evs.append(done)
-                if mode == 'rccl' and world > 1:                  # shared-GPU test path: gloo needs host tensors, so the host waits per step
+                if mode == 'rccl' and multi:                      # shared-GPU test path: gloo needs host tensors, so the host waits per step
                     done.synchronize()
                     dist.gather(host_ring[i], [recv[r][i] for r in range(world)] if rank == 0 else None, dst=0)
             else:
@@ -764,7 +772,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t1
         fed += [(warmup + i) % n_res for i in range(steps)]
-        if world > 1:
+        if multi:
             mine = torch.tensor([dt], dtype=torch.float64, device=comm_device)
             dist.all_reduce(mine, op=dist.ReduceOp.MAX)
             dt = float(mine.item())
@@ -780,11 +788,11 @@ def main():
                 delivered_ok = bool(torch.equal(recv[0].to(device), probs))
             else:
                 delivered_ok = bool(torch.equal(host_ring.to(device), probs))
-        per_step = {'mode': mode if world > 1 or mode in ('host', 'direct') else 'host (one rank: nothing to gather)',
+        per_step = {'mode': mode if multi or mode in ('host', 'direct') else 'host (one rank: nothing to gather)',
                     'transport': ("the update's output pointer is a row of the rank's own pinned host ring: the network role's final store crosses PCIe "
                                   "(4 B x %d per step), no copy, no side stream" % B if direct else
-                                  'gloo on host copies (PE_BENCH_SHARED_GPU=1: plumbing only, the host waits for every step)' if (mode == 'rccl' and shared_gpu and world > 1)
-                                  else 'RCCL gather to rank 0 per step, asynchronous beside the next update' if (mode == 'rccl' and world > 1)
+                                  'gloo on host copies (PE_BENCH_SHARED_GPU=1: plumbing only, the host waits for every step)' if (mode == 'rccl' and shared_gpu and multi)
+                                  else 'RCCL gather to rank 0 per step, asynchronous beside the next update' if (mode == 'rccl' and multi)
                                   else "each rank's own pinned host ring, one 4 B x %d copy per step on a side stream" % B),
                     'ms_per_step': 1e3 * dt / steps, 'value': n_global * steps / dt, 'unit': 'windows/s',
                     'final_gather_ms_per_step': 1e3 * elapsed / steps, 'delivered_equals_device': delivered_ok}
@@ -1000,7 +1008,7 @@ def main():
             'resident_pcm': {'slabs': n_res, 'mb': n_res * chunk_bytes / 1e6,
                              'note': 'distinct [B][1024] int16 slabs cycled by every pass; independent of --steps'},
             'ranks_seen': ranks_seen, 'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms)},
-            'collective_backend': (dist.get_backend() if world > 1 else None),      # 'nccl' = RCCL over xGMI (one device per rank)
+            'collective_backend': (dist.get_backend() if multi else None),      # 'nccl' = RCCL over xGMI (one device per rank)
             'collective': collective['collective'], 'collective_fallback_reason': collective['fallback_reason'],
             'streams_per_rank': [B] * world,
             # dominant kernel of the timed region: the fused launch (GRU role is its long pole)
@@ -1049,7 +1057,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     engine.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -1987,6 +1987,19 @@ def test_rccl_calls_with_one_rank():
                          capture_output=True, text=True, timeout=600)
     # (librccl prints its own path to stdout on the way out: any line, not the last one)
     assert out.returncode == 0 and any(l.startswith('ok: nccl backend (RCCL), 1 rank') for l in out.stdout.splitlines()), (out.stdout[-500:], out.stderr[-3000:])
+    # ... and bench.py's own N > 1 plumbing over RCCL: PE_BENCH_FORCE_DIST=1 makes a world of one rank create its process group
+    # (nccl, device_id) and issue every collective of the N > 1 path -- settle gather / all-gather, the timed region's gather,
+    # the clock exchange, the asynchronous per-step gather
+    import json
+    env2 = dict(env, PE_BENCH_FORCE_DIST='1', MASTER_PORT='29578')
+    b = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5', '--streams', '512',
+                        '--no-cpu-baseline', '--gather-every-step', 'rccl'], env=env2, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stderr[-3000:]
+    line = json.loads([l for l in b.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['collective_backend'] == 'nccl' and line['collective'] in ('gather', 'all_gather') and line['ranks_seen'] == 1
+    assert line['parity']['ok'] and line['outputs_finite']
+    ps = line['per_step_delivery']
+    assert ps['mode'] == 'rccl' and ps['delivered_equals_device'] is True
 
 
 def test_bench_starts_its_own_ranks_and_delivers_per_step():
