@@ -323,18 +323,24 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
 
     run(0, warmup)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(warmup, steps)
-    wait_for_gpu()
-    elapsed = time.perf_counter() - t0
-    n_check = 256 if stock else 32          # streams replayed by the oracle afterwards (the wide network costs it 35 Mflop per window)
-    n_check = min(n_check, streams)
-    got = out[:n_check].cpu().numpy().astype(np.float64)
+    # two timed passes of `steps` steps, both reported, the better one is `value`: a one-off stall of the host or the allocator
+    # inside a 10 ms region (seen once in a while right after the 4 GB slabs of a 65 536-stream configuration are allocated)
+    # is not the configuration's throughput
+    n_check = min(256 if units == (20,) else 32, streams)      # streams replayed by the oracle afterwards (the wide network costs it 35 Mflop per window)
+    passes, got = [], None
+    for k in range(2):
+        t0 = time.perf_counter()
+        run(warmup + k * steps, steps)
+        wait_for_gpu()
+        passes.append(time.perf_counter() - t0)
+        if k == 0:          # the parity spot-check is on the first pass's last probabilities (the oracle replays warmup + steps updates)
+            got = out[:n_check].cpu().numpy().astype(np.float64)
+    elapsed = min(passes)
     # launch durations: HIP events on the launch stream (bracket of back-to-back updates; the two stages apart)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n_b = min(steps, 100)
     ev0.record()
-    run(warmup + steps, n_b)
+    run(warmup + 2 * steps, n_b)
     ev1.record()
     ev1.synchronize()
     update_ms = ev0.elapsed_time(ev1) / n_b
@@ -342,7 +348,7 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
     engine.set_timing(True)
     g_ms, m_ms = [], []
     for i in range(min(steps, 40)):
-        run(warmup + steps + n_b + i, 1)
+        run(warmup + 2 * steps + n_b + i, 1)
         tm = engine.last_timing()
         m_ms.append(tm[0])
         g_ms.append(tm[1])
@@ -382,6 +388,7 @@ def extra_config(name, device, dev_index, units, streams, mfcc_precision, gru_pr
     res = {'name': name, 'value': streams * steps / elapsed, 'unit': 'windows/s', 'ms_per_step': 1e3 * elapsed / steps,
            'realtime_streams': streams * steps / elapsed / REALTIME_WINDOWS_PER_S,
            'steps': steps, 'warmup': warmup, 'dtype': gru_precision,
+           'timed_passes_ms_per_step': [1e3 * p_ / steps for p_ in passes],      # two passes of `steps` steps; `value` is the better one
            'config': {'workload': name, 'streams_per_gpu': streams, 'gru': 'H=%s' % ','.join(map(str, units)),
                       'mfcc_dtype': mfcc_precision, 'feature_rows': ring_precision,
                       'gru_form': ({0: 'bf16 operands, eight gate values per lane (gru_bf16_device.h)', 1: 'bf16 operands, five gate values per lane (gru_b20_device.h)'}[tiling_used]
@@ -721,13 +728,10 @@ def main():
     if rank == 0 and os.environ.get('PE_BENCH_DUMP'):        # test aid: the timed region's probabilities, rank-ordered
         np.save(os.environ['PE_BENCH_DUMP'], gathered.cpu().numpy())
     # parity of the headline itself (rank 0's own shard: global streams 0 .. 255), from the timed region's own probabilities
+    # (the oracle replay itself runs AFTER the GPU regions below: it keeps the host busy for seconds, the GPU would fall back to
+    #  its idle clocks, and the two secondary regions -- 3 ms each -- would measure the clock ramp: 16.9 instead of 15.2 us per step)
     parity = None
-    if rank == 0:
-        try:
-            parity = headline_parity(pcm, fed, steps, probs.cpu().numpy(), weights, 1e-2 if args.gru_precision == 'bf16' else 1e-4,
-                                     n_check=256 if stock else 16)
-        except Exception as ex:                                  # noqa: BLE001  (the checker must not cost the bench its line)
-            parity = {'error': repr(ex)}
+    parity_inputs = (list(fed), probs.cpu().numpy()) if rank == 0 else None
 
     # ---- --gather-every-step: a second region, same K steps, step u's probabilities leaving while update u + 1 runs ----------
     per_step = None
@@ -738,6 +742,10 @@ def main():
         recv = None
         if mode == 'rccl' and multi and rank == 0:
             recv = torch.empty((world, steps, B), dtype=torch.float32, device=comm_device)
+        # (the host work between the regions -- copies, the pinned allocation above -- lets the GPU fall back to its idle
+        #  clocks, and a 3 ms region entered from there measures the clock ramp: 16.9 instead of 15.2 us per step.  The same
+        #  untimed run of back-to-back launches that precedes the headline's region precedes this one)
+        bracket_pass(roofline_launches)
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
@@ -804,10 +812,10 @@ def main():
         def plain(first, n):
             for i in range(n):
                 engine.update_device(pcm_base + ((first + i) % n_res) * chunk_bytes, CHUNK, scratch.data_ptr(), stream, keep=False)
-        plain(warmup + steps, max(warmup, 5))            # (the first of them moves the kept leftovers to the carry)
+        plain(warmup + steps, roofline_launches)         # (the first of them moves the kept leftovers to the carry; as many untimed launches as in front of the headline's region)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        plain(warmup + steps + max(warmup, 5), steps)
+        plain(warmup + steps + roofline_launches, steps)
         wait_for_gpu()
         dt2 = time.perf_counter() - t2
         carry_path = {'entry_point': 'pe_update_device', 'value': B * steps / dt2, 'unit': 'windows/s', 'ms_per_step': 1e3 * dt2 / steps,
@@ -929,6 +937,14 @@ def main():
                 extras.append(fn())
             except Exception as ex:                                  # noqa: BLE001
                 extras.append({'name': label, 'error': repr(ex)})
+
+    # the headline's parity object, last: every GPU region of this run is behind us
+    if rank == 0:
+        try:
+            parity = headline_parity(pcm, parity_inputs[0], steps, parity_inputs[1], weights, 1e-2 if args.gru_precision == 'bf16' else 1e-4,
+                                     n_check=256 if stock else 16)
+        except Exception as ex:                                  # noqa: BLE001  (the checker must not cost the bench its line)
+            parity = {'error': repr(ex)}
 
     def pmc_traffic(kernel):
         """HBM bytes per launch from the committed rocprofv3 PMC summary (bench.py cannot collect PMC
