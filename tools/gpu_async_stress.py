@@ -1,4 +1,4 @@
-"""(round 5) randomized interleaving of the host-fed pipeline (pe_update_async / pe_wait, pinned and pageable buffers) with every
+"""(round 5; round 6: the pipeline keeps its leftovers in its own device chunks -- masked clears and subset updates added) randomized interleaving of the host-fed pipeline (pe_update_async / pe_wait, pinned and pageable buffers) with every
 other entry point that has to drain it (pe_update, pe_update_many, pe_get_vectors, pe_predict, pe_clear), against an engine that only
 ever takes synchronous updates: every probability and every feature window bit for bit.
     python tools/gpu_async_stress.py [seconds] [seed]"""
@@ -83,6 +83,18 @@ while time.time() - t0 < budget:
         elif op == 9 and rng.integers(0, 4) == 0:
             b.wait(); settle()
             a.clear(); b.clear()
+        elif op == 9 and rng.integers(0, 2) == 0:         # (round 6) a masked clear: the other streams' kept leftovers must survive it
+            mask = rng.random(n) < 0.3
+            a.clear(mask); b.clear(mask)
+            settle()
+        elif op == 9:                                     # (round 6) every stream through the id list, shuffled, after kept-leftover updates
+            x = next_pcm()
+            want = a.update(x)
+            ids = rng.permutation(n).astype(np.int32)
+            got = np.empty(n, np.float32)
+            got[ids] = b.update_subset(ids, x[ids])
+            settle()
+            assert np.array_equal(got, want), ('subset update after async ones differs', n, chunk, kw)
     b.wait(); settle()
     qa, qb = a.stream_state(), b.stream_state()
     assert all(np.array_equal(x, y) for x, y in zip(qa, qb)), ('stream state differs', n, chunk, kw)
