@@ -654,12 +654,20 @@ def main():
     # which slab of the resident PCM every update since the engine's creation was fed (headline_parity replays its tail)
     fed = []
     keep = bool(args.keep)
+    last_slab = [-1]
+
+    def upd(u, out_ptr, keep_=None):
+        """One update from resident slab u.  pe_update_device_keep needs the PREVIOUS call's slab untouched and distinct from this
+        one (the engine refuses overlapping chunks): where two regions of this script meet on the same slab, that one call
+        takes pe_update_device."""
+        k = keep if keep_ is None else keep_
+        engine.update_device(pcm_base + u * chunk_bytes, CHUNK, out_ptr, stream, keep=k and u != last_slab[0])
+        last_slab[0] = u
 
     def run(first_step, n, out_rows):
         for i in range(n):
             u = (first_step + i) % n_res
-            engine.update_device(pcm_base + u * chunk_bytes, CHUNK,
-                                 probs_base + i * B * 4 if out_rows else scratch.data_ptr(), stream, keep=keep)
+            upd(u, probs_base + i * B * 4 if out_rows else scratch.data_ptr())
 
     # The launch the timed region uses (MFCC || GRU roles in one kernel): HIP events on the launch
     # stream bracketing a run of launches (per-launch events would add ~2.5 us of their own to a 22 us
@@ -669,7 +677,7 @@ def main():
         ev0.record()
         for i in range(n):
             u = (warmup + steps + i) % n_res
-            engine.update_device(pcm_base + u * chunk_bytes, CHUNK, scratch.data_ptr(), stream, keep=keep)
+            upd(u, scratch.data_ptr())
         ev1.record()
         ev1.synchronize()
         return ev0.elapsed_time(ev1) / n
@@ -755,9 +763,9 @@ def main():
         for i in range(steps):
             u = (warmup + i) % n_res
             if direct:                                             # pinned host memory is device-visible: the kernel writes it
-                engine.update_device(pcm_base + u * chunk_bytes, CHUNK, ring_base + i * B * 4, stream, keep=keep)
+                upd(u, ring_base + i * B * 4)
                 continue
-            engine.update_device(pcm_base + u * chunk_bytes, CHUNK, probs_base + i * B * 4, stream, keep=keep)
+            upd(u, probs_base + i * B * 4)
             if mode == 'host' or (mode == 'rccl' and shared_gpu) or not multi:
                 ev = torch.cuda.Event()
                 ev.record()                                       # behind update i on the launch stream
@@ -811,7 +819,7 @@ def main():
     if keep and world == 1:
         def plain(first, n):
             for i in range(n):
-                engine.update_device(pcm_base + ((first + i) % n_res) * chunk_bytes, CHUNK, scratch.data_ptr(), stream, keep=False)
+                upd((first + i) % n_res, scratch.data_ptr(), False)
         plain(warmup + steps, roofline_launches)         # (the first of them moves the kept leftovers to the carry; as many untimed launches as in front of the headline's region)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
@@ -829,7 +837,7 @@ def main():
         first, second = [], []
         for i in range(min(steps, 100)):
             u = (warmup + steps + i) % n_res
-            engine.update_device(pcm_base + u * chunk_bytes, CHUNK, scratch.data_ptr(), stream, keep=keep)
+            upd(u, scratch.data_ptr())
             a, b = engine.last_timing()
             first.append(a)
             second.append(b)

@@ -132,7 +132,8 @@ int pe_update_device(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples
  * on its stream (or the engine is destroyed).  Any entry point may follow (a call of another style first moves the leftovers
  * to the carry in one small launch); results are bit-identical to pe_update_device.  Chunks that cannot hold a leftover (odd
  * length, fewer than frame_len - 1 samples, an address that is not 4-byte aligned, a non-stock front end) are taken exactly
- * as pe_update_device takes them.  pe_update_async works this way by itself: its device chunks are the engine's own. */
+ * as pe_update_device takes them.  A call whose chunks overlap the previous keep call's is refused (PE_ERR_INVALID: the leftovers
+ * would be gone; the streams' state is untouched).  pe_update_async works this way by itself: its device chunks are the engine's own. */
 int pe_update_device_keep(pe_engine* e, const int16_t* pcm_dev, int32_t chunk_samples,
                           float* raw_out_dev, void* hip_stream);
 

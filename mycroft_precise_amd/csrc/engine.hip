@@ -969,6 +969,17 @@ int do_update(pe_engine* e, const int16_t* pcm_dev, int chunk, float* raw_out_de
     int rc;
     const bool t = e->timing;
     const bool keep_call = keep && !ids && keep_eligible(e, pcm_dev, chunk);
+    if (keep_call && e->kept) {
+        // the previous call's chunks must still hold its leftovers: a caller that refills ONE buffer for every call has broken
+        // the promise of pe_update_device_keep, and the samples are gone -- refuse instead of computing frames from the wrong audio
+        const char* a0 = reinterpret_cast<const char*>(e->kept);
+        const char* a1 = a0 + (size_t)e->n_streams * e->kept_chunk * sizeof(int16_t);
+        const char* b0 = reinterpret_cast<const char*>(pcm_dev);
+        const char* b1 = b0 + (size_t)e->n_streams * chunk * sizeof(int16_t);
+        if (b0 < a1 && a0 < b1)
+            return fail(e, PE_ERR_INVALID, "pe_update_device_keep: this call's chunks overlap the previous call's (%p), which still hold the "
+                        "streams' leftover samples -- alternate between at least two buffers, or use pe_update_device", (const void*)e->kept);
+    }
     if (!keep_call && (rc = flush_kept(e, s))) return rc;
     e->call_head = keep_call ? e->kept : nullptr; e->call_head_chunk = e->kept_chunk; e->call_keep = keep_call;
     // (whatever happens below, the launches of later calls must not inherit this call's style)

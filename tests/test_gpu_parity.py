@@ -1967,6 +1967,12 @@ def test_kept_leftovers_at_full_batch(stock_weights):
         a.update_device(pcm[i].data_ptr(), 1024, oa.data_ptr(), st)
         b.update_device(pcm[i].data_ptr(), 1024, ob.data_ptr(), st, keep=True)
         assert torch.equal(oa, ob)
+    # refilling ONE buffer breaks the promise: the second keep call on the same address is refused, nothing moves, and the
+    # same chunk through the plain entry point continues the stream correctly
+    with pytest.raises(ValueError):
+        b.update_device(pcm[3].data_ptr(), 1024, ob.data_ptr(), st, keep=True)
+    for x, y in zip(a.stream_state(), b.stream_state()):
+        assert np.array_equal(x, y)
     a.update_many_device(pcm[4:8].data_ptr(), 1024, 4, ma.data_ptr(), st)
     b.update_many_device(pcm[4:8].data_ptr(), 1024, 4, mb.data_ptr(), st)
     assert torch.equal(ma, mb)
